@@ -1,0 +1,48 @@
+"""Name-keyed deterministic weight fill ('Travel rule').
+
+Weights never travel: the reference (in the build container), this oracle and the HIP model
+are all filled from their state-dict KEYS alone, so the three hold identical parameters
+without shipping a checkpoint.  Fan-in scaling keeps activations O(1) through 50 layers in
+eval mode (the reference's own N(0, 0.1) conv init, frb/iresnet.py:152-154, overflows there).
+"""
+import zlib
+
+import torch
+
+
+def fill_state_dict(sd):
+    """Fill every tensor of ``sd`` in place, in state_dict order, from its key."""
+    with torch.no_grad():
+        for key, t in sd.items():
+            g = torch.Generator().manual_seed(zlib.crc32(key.encode()))
+            leaf = key.rsplit(".", 1)[-1]
+            if leaf == "num_batches_tracked":
+                t.zero_()
+            elif leaf == "running_mean":
+                t.copy_(0.1 * torch.randn(t.shape, generator=g))
+            elif leaf == "running_var":
+                t.copy_(1.0 + 0.1 * torch.rand(t.shape, generator=g))
+            elif t.dim() >= 2:                      # conv / deconv / linear / classifier weight
+                fan_in = t[0].numel()
+                t.copy_(torch.randn(t.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+            elif leaf == "bias":
+                t.copy_(0.1 * torch.randn(t.shape, generator=g))
+            elif leaf == "weight":
+                owner = key.rsplit(".", 2)[-2]
+                if "prelu" in owner:
+                    t.copy_(0.25 + 0.05 * torch.randn(t.shape, generator=g))
+                else:                               # BatchNorm gamma
+                    t.copy_(1.0 + 0.1 * torch.randn(t.shape, generator=g))
+            else:
+                raise KeyError(key)
+    return sd
+
+
+def fill_module(module):
+    fill_state_dict(module.state_dict())
+    # frb.features.weight is frozen at 1.0 in the reference (iresnet.py:118-120)
+    feats = getattr(getattr(module, "frb", module), "features", None)
+    if feats is not None:
+        with torch.no_grad():
+            feats.weight.fill_(1.0)
+    return module
