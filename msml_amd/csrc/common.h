@@ -1,0 +1,138 @@
+// Shared device/host helpers for libmsml_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/msml_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+void msml_set_error(const char* fmt, ...);
+
+#define MSML_CHECK(cond, code, ...)          \
+  do {                                       \
+    if (!(cond)) {                           \
+      msml_set_error(__VA_ARGS__);           \
+      return (code);                         \
+    }                                        \
+  } while (0)
+
+// call after every launch: reports launch-configuration errors without synchronising
+#define MSML_LAUNCH_OK(name)                                                     \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      msml_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+      return MSML_ERR_LAUNCH;                                                    \
+    }                                                                            \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- storage element helpers ------------------------------------------------------------
+// Activations are stored either as f32 or bf16; arithmetic is always f32.
+__device__ __forceinline__ float bf2f(unsigned short v) {
+  return __uint_as_float(((unsigned int)v) << 16);
+}
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  // plain cast -> v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+// 8 consecutive channels of one pixel, as f32
+struct Vec8 {
+  float v[8];
+};
+
+template <typename T>
+__device__ __forceinline__ Vec8 load8(const T* p);
+template <>
+__device__ __forceinline__ Vec8 load8<float>(const float* p) {
+  Vec8 r;
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    r.v[i] = a[i];
+    r.v[4 + i] = b[i];
+  }
+  return r;
+}
+template <>
+__device__ __forceinline__ Vec8 load8<unsigned short>(const unsigned short* p) {
+  Vec8 r;
+  u32x4 a = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    r.v[2 * i] = __uint_as_float(a[i] << 16);
+    r.v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+  }
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const Vec8& r);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const Vec8& r) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    a[i] = r.v[i];
+    b[i] = r.v[4 + i];
+  }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <>
+__device__ __forceinline__ void store8<unsigned short>(unsigned short* p, const Vec8& r) {
+  u32x4 a;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    a[i] = (unsigned int)f2bf(r.v[2 * i]) | ((unsigned int)f2bf(r.v[2 * i + 1]) << 16);
+  *reinterpret_cast<u32x4*>(p) = a;
+}
+
+template <typename T>
+__device__ __forceinline__ float load1(const T* p);
+template <>
+__device__ __forceinline__ float load1<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float load1<unsigned short>(const unsigned short* p) { return bf2f(*p); }
+template <typename T>
+__device__ __forceinline__ void store1(T* p, float v);
+template <>
+__device__ __forceinline__ void store1<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void store1<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
+
+// wave (64-lane) sum
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// dtype dispatch: DT is unsigned short for bf16 storage, float for f32 storage
+#define MSML_DISPATCH_DTYPE(dtype, name, ...)                       \
+  if ((dtype) == MSML_F32) {                                        \
+    typedef float DT;                                               \
+    __VA_ARGS__                                                     \
+  } else if ((dtype) == MSML_BF16) {                                \
+    typedef unsigned short DT;                                      \
+    __VA_ARGS__                                                     \
+  } else {                                                          \
+    msml_set_error("%s: unsupported dtype %d", name, (int)(dtype)); \
+    return MSML_ERR_DTYPE;                                          \
+  }

@@ -1,0 +1,16 @@
+// Error reporting + version for libmsml_hip.so.
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void msml_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int msml_version(void) { return MSML_ABI_VERSION; }
+extern "C" const char* msml_last_error(void) { return g_err; }

@@ -1,0 +1,117 @@
+// Boundary layout kernels: NCHW f32 <-> NHWC (channel-padded) storage, weight packing.
+#include "common.h"
+
+// One thread per (n, h, w, 8-channel chunk); reads are strided over C (small C at the
+// boundary: 3 input channels / 2 output channels), writes are 16 B (bf16) / 32 B (f32).
+template <typename T>
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, T* __restrict__ dst, int N, int C,
+                               int HW, int Cp) {
+  long total = (long)N * HW * (Cp / 8);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    int c8 = (int)(i % (Cp / 8));
+    long pix = i / (Cp / 8);
+    int n = (int)(pix / HW);
+    int hw = (int)(pix % HW);
+    Vec8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      int c = c8 * 8 + j;
+      v.v[j] = c < C ? src[((long)n * C + c) * HW + hw] : 0.f;
+    }
+    store8<T>(dst + pix * Cp + c8 * 8, v);
+  }
+}
+
+// NHWC -> NCHW through an LDS transpose tile: 64 pixels x 8 channels per wave step would
+// be overkill for the tiny boundary tensors; lanes run along hw for coalesced f32 writes.
+template <typename T>
+__global__ void k_nhwc_to_nchw(const T* __restrict__ src, float* __restrict__ dst, int N, int C,
+                               int HW, int Cp) {
+  long total = (long)N * C * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    int hw = (int)(i % HW);
+    long nc = i / HW;
+    int c = (int)(nc % C);
+    int n = (int)(nc / C);
+    dst[i] = load1<T>(src + ((long)n * HW + hw) * Cp + c);
+  }
+}
+
+extern "C" int msml_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int Cp,
+                                 int dtype, void* stream) {
+  MSML_CHECK(N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && Cp % 8 == 0, MSML_ERR_SHAPE,
+             "nchw_to_nhwc: bad shape N=%d C=%d H=%d W=%d Cp=%d", N, C, H, W, Cp);
+  long total = (long)N * H * W * (Cp / 8);
+  int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  MSML_DISPATCH_DTYPE(dtype, "nchw_to_nhwc",
+                      k_nchw_to_nhwc<DT><<<grid, 256, 0, (hipStream_t)stream>>>(
+                          src, (DT*)dst, N, C, H * W, Cp);)
+  MSML_LAUNCH_OK("nchw_to_nhwc");
+  return MSML_OK;
+}
+
+extern "C" int msml_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int Cp,
+                                 int dtype, void* stream) {
+  MSML_CHECK(N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && Cp % 8 == 0, MSML_ERR_SHAPE,
+             "nhwc_to_nchw: bad shape N=%d C=%d H=%d W=%d Cp=%d", N, C, H, W, Cp);
+  long total = (long)N * C * H * W;
+  int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  MSML_DISPATCH_DTYPE(dtype, "nhwc_to_nchw",
+                      k_nhwc_to_nchw<DT><<<grid, 256, 0, (hipStream_t)stream>>>(
+                          (const DT*)src, dst, N, C, H * W, Cp);)
+  MSML_LAUNCH_OK("nhwc_to_nchw");
+  return MSML_OK;
+}
+
+// dst[ko][seg][r][s][c] <- w[a][b][r][s]; one thread per destination element (the packed
+// weights are at most ~25 MB per layer and are rewritten once per optimizer step).
+template <typename T>
+__global__ void k_pack_weight(const float* __restrict__ w, T* __restrict__ dst, int A, int B, int R,
+                              int S, int transpose, int C1, int C1p, int C2, int C2p, int KOp,
+                              int K0, int Ktot) {
+  long total = (long)KOp * Ktot;
+  int KO = transpose ? B : A;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    int k = (int)(i % Ktot);
+    int ko = (int)(i / Ktot);
+    int seg = k >= K0;
+    int kk = seg ? k - K0 : k;
+    int cp = seg ? C2p : C1p;
+    int cn = seg ? C2 : C1;
+    int c = kk % cp;
+    int tap = kk / cp;
+    float v = 0.f;
+    if (ko < KO && tap < R * S && c < cn) {
+      int r = tap / S, s = tap % S;
+      int ci = c + (seg ? C1 : 0);
+      int a = transpose ? ci : ko;
+      int b = transpose ? ko : ci;
+      v = w[(((long)a * B + b) * R + r) * S + s];
+    }
+    store1<T>(dst + i, v);
+  }
+}
+
+extern "C" int msml_pack_weight(const float* w, void* dst, int A, int B, int R, int S,
+                                int transpose, int C1, int C1p, int C2, int C2p, int KOp,
+                                int dtype, void* stream) {
+  int CI = transpose ? A : B;
+  int KO = transpose ? B : A;
+  MSML_CHECK(A > 0 && B > 0 && R > 0 && S > 0 && C1 > 0 && C2 >= 0 && C1 + C2 == CI &&
+                 C1p >= C1 && C1p % 8 == 0 && C2p >= C2 && C2p % 8 == 0 && KOp >= KO,
+             MSML_ERR_SHAPE, "pack_weight: bad shape A=%d B=%d R=%d S=%d C1=%d/%d C2=%d/%d KOp=%d",
+             A, B, R, S, C1, C1p, C2, C2p, KOp);
+  int K0 = (R * S * C1p + 31) / 32 * 32;
+  int K1 = C2 > 0 ? (R * S * C2p + 31) / 32 * 32 : 0;
+  int Ktot = K0 + K1;
+  long total = (long)KOp * Ktot;
+  int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  MSML_DISPATCH_DTYPE(dtype, "pack_weight",
+                      k_pack_weight<DT><<<grid, 256, 0, (hipStream_t)stream>>>(
+                          w, (DT*)dst, A, B, R, S, transpose, C1, C1p, C2, C2p, KOp, K0, Ktot);)
+  MSML_LAUNCH_OK("pack_weight");
+  return MSML_OK;
+}

@@ -1,0 +1,98 @@
+"""GPU parity: boundary layout kernels, weight packing, FM fusion (fwd + bwd) vs the oracle
+formulas.  Calls go through the C ABI (msml_amd._lib.call)."""
+import pytest
+import torch
+
+from msml_amd import _lib
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+DT = [(_lib.F32, 1e-6), (_lib.BF16, 1e-2)]
+
+
+@pytest.mark.parametrize("dtype,tol", DT)
+@pytest.mark.parametrize("C,Cp", [(3, 8), (18, 24), (64, 64)])
+def test_layout_roundtrip(dtype, tol, C, Cp):
+    x = torch.randn(3, C, 14, 10)
+    d = torch.empty(3, 14, 10, Cp, dtype=_lib.TORCH_DTYPE[dtype], device="cuda")
+    _lib.call("msml_nchw_to_nhwc", x.cuda(), d, 3, C, 14, 10, Cp, dtype)
+    ref = torch.zeros(3, 14, 10, Cp)
+    ref[..., :C] = x.permute(0, 2, 3, 1)
+    assert (d.float().cpu() - ref).abs().max() <= tol * 4
+    assert (d[..., C:] == 0).all()
+    back = torch.empty(3, C, 14, 10, device="cuda")
+    _lib.call("msml_nhwc_to_nchw", d, back, 3, C, 14, 10, Cp, dtype)
+    assert (back.cpu() - x).abs().max() <= tol * 4
+
+
+@pytest.mark.parametrize("transpose", [0, 1])
+def test_pack_weight(transpose):
+    A, B, R, S = 5, 26, 3, 3
+    w = torch.randn(A, B, R, S)
+    CI, KO = (A, B) if transpose else (B, A)
+    C1 = CI - 2 if CI > 4 else CI
+    C2 = CI - C1
+    C1p = (C1 + 7) // 8 * 8
+    C2p = (C2 + 7) // 8 * 8
+    KOp = 32
+    K0 = (R * S * C1p + 31) // 32 * 32
+    K1 = (R * S * C2p + 31) // 32 * 32 if C2 else 0
+    dst = torch.full((KOp, K0 + K1), 7.0, device="cuda")
+    _lib.call("msml_pack_weight", w.cuda(), dst, A, B, R, S, transpose, C1, C1p, C2, C2p, KOp,
+              _lib.F32)
+    wt = w.permute(1, 0, 2, 3) if transpose else w          # [KO][CI][R][S]
+    ref = torch.zeros(KOp, K0 + K1)
+    seg0 = torch.zeros(KO, R, S, C1p)
+    seg0[..., :C1] = wt[:, :C1].permute(0, 2, 3, 1)
+    ref[:KO, :R * S * C1p] = seg0.reshape(KO, -1)
+    if C2:
+        seg1 = torch.zeros(KO, R, S, C2p)
+        seg1[..., :C2] = wt[:, C1:].permute(0, 2, 3, 1)
+        ref[:KO, K0:K0 + R * S * C2p] = seg1.reshape(KO, -1)
+    assert torch.equal(dst.cpu(), ref)
+
+
+ACTS = {"tanh": 0, "sigmoid": 1}
+ARITHS = {"add": 0, "sub": 1, "mul": 2, "div": 3}
+
+
+@pytest.mark.parametrize("dtype,tol", DT)
+@pytest.mark.parametrize("act", list(ACTS))
+@pytest.mark.parametrize("arith", list(ARITHS))
+def test_fm_fuse(dtype, tol, act, arith):
+    g = torch.Generator().manual_seed(3)
+    tdt = _lib.TORCH_DTYPE[dtype]
+    x = torch.randn(2, 28, 28, 128, generator=g).to(tdt).float()
+    yf = torch.randn(2, 28, 28, 128, generator=g).to(tdt).float()
+    if arith == "div":
+        x = x.abs() + 0.5            # keep 1/M tame: the domain where div is usable at all
+    dz = torch.randn(2, 28, 28, 128, generator=g).to(tdt).float()
+    xr = x.clone().requires_grad_(True)
+    yr = yf.clone().requires_grad_(True)
+    m = om._ACT[act](xr)
+    zref = om._ARITH[arith](yr, m) + yr
+    zref.backward(dz)
+    xd, yd, dzd = x.cuda().to(tdt), yf.cuda().to(tdt), dz.cuda().to(tdt)
+    z = torch.empty_like(xd)
+    _lib.call("msml_fm_fuse_fwd", xd, yd, z, x.numel(), ACTS[act], ARITHS[arith], dtype)
+    dx, dyf = torch.empty_like(xd), torch.empty_like(xd)
+    _lib.call("msml_fm_fuse_bwd", dzd, xd, yd, dx, dyf, x.numel(), ACTS[act], ARITHS[arith], dtype)
+
+    def close(a, b):
+        return ((a.float().cpu() - b).abs() <= tol * (1 + b.abs())).all()
+    assert close(z, zref.detach())
+    assert close(dx, xr.grad)
+    assert close(dyf, yr.grad)
+
+
+def test_fm_full_size_linearity():
+    """BASELINE size (256 x 64 x 56 x 56), size-independent property: for arith=add the op is
+    affine in yf:  z(yf1 + yf2) - z(yf1) == 2 * yf2 exactly in exact arithmetic."""
+    n = 256 * 56 * 56 * 64
+    x = torch.randn(n, device="cuda")
+    y1 = torch.randn(n, device="cuda")
+    y2 = torch.randn(n, device="cuda")
+    za, zb = torch.empty_like(x), torch.empty_like(x)
+    _lib.call("msml_fm_fuse_fwd", x, y1, za, n, 0, 0, _lib.F32)
+    _lib.call("msml_fm_fuse_fwd", x, y1 + y2, zb, n, 0, 0, _lib.F32)
+    assert ((zb - za) - 2 * y2).abs().max().item() < 1e-5
