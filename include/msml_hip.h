@@ -76,6 +76,31 @@ int msml_fm_fuse_fwd(const void* x, const void* yf, void* z, long n, int act, in
 int msml_fm_fuse_bwd(const void* dz, const void* x, const void* yf, void* dx, void* dyf,
                      long n, int act, int arith, int dtype, void* stream);
 
+/* ---------------------------------------------------------------- convolution -------------
+ * Implicit-GEMM convolution on MFMA.  Replaces nn.Conv2d / nn.ConvTranspose2d / nn.Linear
+ * forward and backward-data at: backbones/frb/iresnet.py:56-67,209,232 (IBasicBlock, stem,
+ * fc), backbones/fm/fmoperator.py:40-48,285-286 (bottleneck, same_conv on cat(yf, yo)),
+ * backbones/osb/unet.py:32-38,193-221 (encoder, GCM 7x1/1x7, deconvs on cat(seg, gcm)),
+ * headers/partial_fc.py:98 (logits GEMM) and the autograd of all of them.
+ *
+ *   out[n,oy,ox,ko] = bias[ko] + sum_seg sum_{r,s,c} in_seg[n,iy,ix,c] * wp[ko][seg,r,s,c]
+ *   transposed == 0:  iy = oy*stride - pad_h + r                    (conv fwd, deconv bwd-data)
+ *   transposed == 1:  iy = (oy + pad_h - r)/stride when divisible   (conv bwd-data, deconv fwd)
+ *
+ * in0/in1: NHWC [N][H][W][c0p]/[c1p] (in1 may be NULL with c1p = 0); wp from
+ * msml_pack_weight with kop rows (>= coutp rounded up to msml_conv_tile_n(coutp));
+ * out: NHWC [N][P][Q][coutp]; bias: [coutp] f32 or NULL.
+ * stats (or NULL): [ceil(N*P*Q / msml_conv_tile_m(coutp))][2][coutp] f32 partial per-channel
+ * (sum, sum of squares) of the f32 results, one row pair per pixel tile, for training-mode
+ * BatchNorm (finalised by msml_bn_finalize).  in_dtype/out_dtype: (F32,F32), (BF16,BF16),
+ * (BF16,F32). */
+int msml_conv_tile_m(int coutp);
+int msml_conv_tile_n(int coutp);
+int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
+                const float* bias, void* out, int coutp, float* stats, int N, int H, int W,
+                int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int transposed,
+                int in_dtype, int out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

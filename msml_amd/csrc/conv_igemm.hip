@@ -1,0 +1,362 @@
+// Implicit-GEMM convolution on MFMA (gfx950), NHWC activations, K-contiguous packed weights.
+//
+//   out[m][ko] = sum_{seg} sum_{r,s} sum_{c} in_seg[gather(m, r, s)][c] * wp[ko][seg,r,s,c]
+//
+// GEMM view: M = N*P*Q output pixels (rows), N = packed output channels (cols),
+// K = sum over segments of R*S*Cp.  One kernel serves
+//   conv forward / deconv backward-data      (normal gather:      iy = oy*stride - pad + r)
+//   conv backward-data / deconv forward      (transposed gather:  oy_in = (oy + pad - r)/stride)
+//   Linear layers and the PartialFC GEMMs    (1x1 or HxW "valid" windows)
+// Two input segments implement channel concatenation (cat(yf, yo), cat(seg, gcm)) without
+// materialising it.  Reference call sites: backbones/frb/iresnet.py:56-67 (IBasicBlock convs),
+// backbones/fm/fmoperator.py:285-286 (same_conv on the concat), backbones/osb/unet.py:207-221
+// (GCM convs, deconvs), backbones/frb/iresnet.py:232 (fc), headers/partial_fc.py:98,169.
+//
+// Tiling: 256 threads = 4 waves; workgroup tile BM x BN, K-step 32; wave tile made of
+// 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 for the exact-f32
+// parity mode).  Tiles are staged through LDS (double-buffered, 16-B chunks XOR-swizzled so
+// both the ds_write_b128 staging and the ds_read_b128 fragment reads are conflict-free).
+// Pixels are the MFMA row dimension, so an accumulator register's 32 lanes hold 32 consecutive
+// output channels of one pixel: stores are 64-128 B contiguous per pixel row.
+#include "common.h"
+
+struct ConvArgs {
+  const void* in[2];
+  int cp[2];        // padded channels per segment
+  int ksteps[2];    // K-steps (of 32) per segment
+  int nseg;
+  int N, H, W, P, Q;
+  int R, S, stride_shift, stride, pad_h, pad_w, transposed;
+  const void* wp;
+  int Ktot;
+  void* out;
+  int coutp;        // output channel stride (and valid column bound)
+  const float* bias;
+  float* stats;     // [tiles_m][2][coutp] partial (sum, sumsq) or null
+  long M;
+};
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<unsigned short> {           // bf16 storage
+  static constexpr int CH = 8;          // elements per 16-B chunk
+  static constexpr int CPR = 4;         // chunks per 32-element K row
+  __device__ static __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+};
+template <>
+struct Elem<float> {
+  static constexpr int CH = 4;
+  static constexpr int CPR = 8;
+  __device__ static __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+};
+
+// acc[tm][tn] += A(32 rows x 32 k) * B(32 cols x 32 k)^T for one K-step, fragments from LDS.
+// As/Bs: [rows][CPR] chunks of 16 B (u32x4), swizzled.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void mma_step(const u32x4* __restrict__ As, const u32x4* __restrict__ Bs,
+                                         int arow0, int brow0, int lane, f32x16 (&acc)[TM][TN]) {
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int CPR = Elem<T>::CPR;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      u32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        int row = arow0 + i * 32 + r;
+        a[i] = As[row * CPR + ((kk * 2 + h) ^ Elem<T>::swz(row))];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        int row = brow0 + j * 32 + r;
+        b[j] = Bs[row * CPR + ((kk * 2 + h) ^ Elem<T>::swz(row))];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+    }
+  } else {
+    // f32: a K window of 8 = two 16-B chunks; lane half h takes chunk h and feeds its 4 floats
+    // to 4 consecutive 32x32x2 MFMAs (any K permutation is valid as long as A and B agree).
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        int row = arow0 + i * 32 + r;
+        a[i] = __builtin_bit_cast(f32x4, As[row * CPR + ((w * 2 + h) ^ Elem<T>::swz(row))]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        int row = brow0 + j * 32 + r;
+        b[j] = __builtin_bit_cast(f32x4, Bs[row * CPR + ((w * 2 + h) ^ Elem<T>::swz(row))]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
+template <typename TIN, typename TOUT, int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(256) k_conv_igemm(const ConvArgs p) {
+  constexpr int CH = Elem<TIN>::CH, CPR = Elem<TIN>::CPR;
+  constexpr int RPT = 256 / CPR;            // rows covered per pass of the 256 threads
+  constexpr int NA = BM / RPT, NB = BN >= RPT ? BN / RPT : 1;
+  constexpr bool BPART = BN < RPT;            // only the first BN rows of threads stage B
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 32, TN = WTN / 32;
+  static_assert(WGM * WGN == 4 && NA >= 1 && NB >= 1 && TM >= 1 && TN >= 1, "tile config");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* As = reinterpret_cast<u32x4*>(smem);                 // [2][BM][CPR]
+  u32x4* Bs = As + 2 * BM * CPR;                              // [2][BN][CPR]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cc = t % CPR, row0 = t / CPR;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // per-row gather bases
+  int nb[NA], y0[NA], x0[NA];
+  bool rok[NA];
+  const int PQ = p.P * p.Q;
+#pragma unroll
+  for (int i = 0; i < NA; i++) {
+    long m = m0 + row0 + i * RPT;
+    rok[i] = m < p.M;
+    int mm = rok[i] ? (int)m : 0;
+    int n = mm / PQ;
+    int rem = mm - n * PQ;
+    int oy = rem / p.Q, ox = rem - oy * p.Q;
+    nb[i] = n * p.H * p.W;
+    if (p.transposed) {
+      y0[i] = oy + p.pad_h;
+      x0[i] = ox + p.pad_w;
+    } else {
+      y0[i] = oy * p.stride - p.pad_h;
+      x0[i] = ox * p.stride - p.pad_w;
+    }
+  }
+  const TIN* wrow[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++)
+    wrow[i] = reinterpret_cast<const TIN*>(p.wp) + (long)(n0 + row0 + i * RPT) * p.Ktot + cc * CH;
+
+  // K iterator state (identical for all threads sharing cc)
+  int seg = 0, ks_in_seg = 0, r = 0, s = 0, cidx = cc;
+  int cpk = p.cp[0] / CH;
+  const TIN* inp = reinterpret_cast<const TIN*>(p.in[0]);
+  int cpseg = p.cp[0];
+  auto normalize = [&]() {
+    while (cidx >= cpk) {
+      cidx -= cpk;
+      if (++s == p.S) { s = 0; ++r; }
+    }
+  };
+  normalize();
+  const int total_steps = p.ksteps[0] + (p.nseg > 1 ? p.ksteps[1] : 0);
+
+  u32x4 ra[NA], rb[NB];
+  auto gload = [&](int kstep) {
+    const bool tap_ok = r < p.R;
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+      int iy, ix;
+      bool ok = rok[i] && tap_ok;
+      if (p.transposed) {
+        int ty = y0[i] - r, tx = x0[i] - s;
+        ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & (p.stride - 1)) == 0;
+        iy = ty >> p.stride_shift;
+        ix = tx >> p.stride_shift;
+        ok = ok && iy < p.H && ix < p.W;
+      } else {
+        iy = y0[i] + r;
+        ix = x0[i] + s;
+        ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      }
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) {
+        long off = (long)(nb[i] + iy * p.W + ix) * cpseg + cidx * CH;
+        v = *reinterpret_cast<const u32x4*>(inp + off);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+      if (!BPART || row0 < BN) rb[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (long)kstep * 32);
+  };
+  auto advance = [&]() {
+    if (++ks_in_seg == p.ksteps[seg] && seg + 1 < p.nseg) {
+      seg++;
+      ks_in_seg = 0;
+      r = 0; s = 0; cidx = cc;
+      cpseg = p.cp[seg];
+      cpk = cpseg / CH;
+      inp = reinterpret_cast<const TIN*>(p.in[seg]);
+    } else {
+      cidx += CPR;
+    }
+    normalize();
+  };
+  auto lstore = [&](int buf) {
+    u32x4* a = As + buf * BM * CPR;
+    u32x4* b = Bs + buf * BN * CPR;
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+      int row = row0 + i * RPT;
+      a[row * CPR + (cc ^ Elem<TIN>::swz(row))] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      int row = row0 + i * RPT;
+      if (!BPART || row0 < BN) b[row * CPR + (cc ^ Elem<TIN>::swz(row))] = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int arow0 = wm * WTM, brow0 = wn * WTN;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int step = 0; step < total_steps; step++) {
+    const bool more = step + 1 < total_steps;
+    if (more) {
+      advance();
+      gload(step + 1);
+    }
+    mma_step<TIN, TM, TN>(As + cur * BM * CPR, Bs + cur * BN * CPR, arow0, brow0, lane, acc);
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------- epilogue: bias, store, optional per-channel (sum, sumsq) partials -------
+  const int h = lane >> 5, c32 = lane & 31;
+  TOUT* outp = reinterpret_cast<TOUT*>(p.out);
+  float* red = reinterpret_cast<float*>(smem);     // reuse LDS: [WGM][2][BN]
+  if (p.stats) __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int col = n0 + brow0 + j * 32 + c32;
+    const bool cok = col < p.coutp;
+    const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        int row = arow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        long m = m0 + row;
+        float v = acc[i][j][e] + bv;
+        if (m < p.M && cok) {
+          store1<TOUT>(outp + m * p.coutp + col, v);
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (p.stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        red[(wm * 2 + 0) * BN + brow0 + j * 32 + c32] = s1;
+        red[(wm * 2 + 1) * BN + brow0 + j * 32 + c32] = s2;
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    for (int i = t; i < 2 * BN; i += 256) {
+      int which = i / BN, c = i % BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; w++) v += red[(w * 2 + which) * BN + c];
+      int col = n0 + c;
+      if (col < p.coutp) p.stats[((long)blockIdx.x * 2 + which) * p.coutp + col] = v;
+    }
+  }
+}
+
+template <typename TIN, typename TOUT, int BM, int BN, int WGM, int WGN>
+static int launch(const ConvArgs& a, hipStream_t stream) {
+  constexpr int CPR = Elem<TIN>::CPR;
+  size_t lds = (size_t)2 * (BM + BN) * CPR * 16;
+  dim3 grid(cdiv(a.M, BM), cdiv(a.coutp, BN));
+  hipLaunchKernelGGL((k_conv_igemm<TIN, TOUT, BM, BN, WGM, WGN>), grid, dim3(256), lds, stream, a);
+  return 0;
+}
+
+extern "C" int msml_conv_tile_m(int coutp) { return coutp <= 64 ? 256 : 128; }
+extern "C" int msml_conv_tile_n(int coutp) { return coutp <= 32 ? 32 : (coutp <= 64 ? 64 : 128); }
+
+extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, const void* wp,
+                           int kop, const float* bias, void* out, int coutp, float* stats,
+                           int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                           int pad_w, int transposed, int in_dtype, int out_dtype, void* stream) {
+  MSML_CHECK(in0 && wp && out, MSML_ERR_SHAPE, "conv2d: null pointer");
+  MSML_CHECK(N > 0 && H > 0 && W > 0 && P > 0 && Q > 0 && R > 0 && S > 0, MSML_ERR_SHAPE,
+             "conv2d: bad dims N=%d H=%d W=%d P=%d Q=%d R=%d S=%d", N, H, W, P, Q, R, S);
+  MSML_CHECK(c0p > 0 && c0p % 8 == 0 && c1p >= 0 && c1p % 8 == 0 && coutp > 0 && coutp % 8 == 0,
+             MSML_ERR_SHAPE, "conv2d: channel counts must be multiples of 8 (c0p=%d c1p=%d coutp=%d)",
+             c0p, c1p, coutp);
+  MSML_CHECK(stride == 1 || stride == 2 || stride == 4, MSML_ERR_UNSUPPORTED,
+             "conv2d: stride %d (power of two <= 4 only)", stride);
+  MSML_CHECK((c1p == 0) == (in1 == nullptr), MSML_ERR_SHAPE, "conv2d: in1/c1p mismatch");
+  if (!transposed) {
+    MSML_CHECK((H + 2 * pad_h - R) / stride + 1 == P && (W + 2 * pad_w - S) / stride + 1 == Q,
+               MSML_ERR_SHAPE, "conv2d: P,Q inconsistent with H,W,R,S,stride,pad");
+  } else {
+    MSML_CHECK((H - 1) * stride - 2 * pad_h + R <= P + stride - 1 && (H - 1) * stride - 2 * pad_h + R >= P - (stride - 1) &&
+                   (W - 1) * stride - 2 * pad_w + S <= Q + stride - 1 && (W - 1) * stride - 2 * pad_w + S >= Q - (stride - 1),
+               MSML_ERR_SHAPE, "conv2d(transposed): P,Q inconsistent with H,W,R,S,stride,pad");
+  }
+  ConvArgs a;
+  a.in[0] = in0; a.in[1] = in1;
+  a.cp[0] = c0p; a.cp[1] = c1p;
+  a.nseg = in1 ? 2 : 1;
+  a.ksteps[0] = (R * S * c0p + 31) / 32;
+  a.ksteps[1] = in1 ? (R * S * c1p + 31) / 32 : 0;
+  a.Ktot = 32 * (a.ksteps[0] + a.ksteps[1]);
+  a.N = N; a.H = H; a.W = W; a.P = P; a.Q = Q; a.R = R; a.S = S;
+  a.stride = stride;
+  a.stride_shift = stride == 1 ? 0 : (stride == 2 ? 1 : 2);
+  a.pad_h = pad_h; a.pad_w = pad_w; a.transposed = transposed;
+  a.wp = wp; a.out = out; a.coutp = coutp; a.bias = bias; a.stats = stats;
+  a.M = (long)N * P * Q;
+  const int bn = msml_conv_tile_n(coutp);
+  MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE,
+             "conv2d: packed weight has %d rows, need %d", kop, cdiv(coutp, bn) * bn);
+  hipStream_t st = (hipStream_t)stream;
+#define CONV_CASE(TI, TO)                                                          \
+  if (bn == 128) launch<TI, TO, 128, 128, 2, 2>(a, st);                            \
+  else if (bn == 64) launch<TI, TO, 256, 64, 4, 1>(a, st);                         \
+  else launch<TI, TO, 256, 32, 4, 1>(a, st);
+  if (in_dtype == MSML_F32 && out_dtype == MSML_F32) { CONV_CASE(float, float) }
+  else if (in_dtype == MSML_BF16 && out_dtype == MSML_BF16) { CONV_CASE(unsigned short, unsigned short) }
+  else if (in_dtype == MSML_BF16 && out_dtype == MSML_F32) { CONV_CASE(unsigned short, float) }
+  else {
+    msml_set_error("conv2d: unsupported dtype pair in=%d out=%d", in_dtype, out_dtype);
+    return MSML_ERR_DTYPE;
+  }
+#undef CONV_CASE
+  MSML_LAUNCH_OK("conv2d");
+  return MSML_OK;
+}

@@ -1,0 +1,78 @@
+"""Thin tensor-level wrappers over the C ABI (no autograd): allocate outputs with torch,
+pass raw pointers.  Everything here requires the HIP library and a GPU tensor."""
+import torch
+
+from . import _lib
+from ._lib import BF16, DTYPE_OF, F32, TORCH_DTYPE, call
+
+
+def cpad(c):
+    return (c + 7) // 8 * 8
+
+
+def kpad(k):
+    return (k + 31) // 32 * 32
+
+
+def tile_n(coutp):
+    return 32 if coutp <= 32 else (64 if coutp <= 64 else 128)
+
+
+def tile_m(coutp):
+    return 256 if coutp <= 64 else 128
+
+
+def to_nhwc(x, dtype, cp=None):
+    """NCHW f32 -> NHWC storage tensor [N,H,W,Cp]."""
+    n, c, h, w = x.shape
+    cp = cp or cpad(c)
+    out = torch.empty(n, h, w, cp, dtype=TORCH_DTYPE[dtype], device=x.device)
+    call("msml_nchw_to_nhwc", x.contiguous(), out, n, c, h, w, cp, dtype)
+    return out
+
+
+def to_nchw(t, c):
+    """NHWC storage tensor -> NCHW f32 with the first c channels."""
+    n, h, w, cp = t.shape
+    out = torch.empty(n, c, h, w, dtype=torch.float32, device=t.device)
+    call("msml_nhwc_to_nchw", t, out, n, c, h, w, cp, DTYPE_OF[t.dtype])
+    return out
+
+
+def pack_weight(w, transpose, c1, c2, dtype):
+    """w[A][B][R][S] f32 -> packed [KOp][Ktot] (see msml_pack_weight).  Returns (wp, KOp)."""
+    a, b, r, s = w.shape
+    ko = b if transpose else a
+    kop = (cpad(ko) + tile_n(cpad(ko)) - 1) // tile_n(cpad(ko)) * tile_n(cpad(ko))
+    c1p, c2p = cpad(c1), cpad(c2) if c2 else 0
+    ktot = kpad(r * s * c1p) + (kpad(r * s * c2p) if c2 else 0)
+    wp = torch.empty(kop, ktot, dtype=TORCH_DTYPE[dtype], device=w.device)
+    call("msml_pack_weight", w.contiguous(), wp, a, b, r, s, int(transpose), c1, c1p, c2, c2p, kop,
+         dtype)
+    return wp
+
+
+def conv_out_size(h, r, stride, pad, transposed, out_pad=0):
+    if transposed:
+        return (h - 1) * stride - 2 * pad + r + out_pad
+    return (h + 2 * pad - r) // stride + 1
+
+
+def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=None, q=None,
+           out_dtype=None, want_stats=False):
+    """Raw implicit-GEMM conv.  x0/x1: NHWC tensors; returns (out NHWC, stats or None)."""
+    n, h, w, c0p = x0.shape
+    c1p = x1.shape[3] if x1 is not None else 0
+    if p is None:
+        p = conv_out_size(h, r, stride, pad_h, transposed)
+        q = conv_out_size(w, s, stride, pad_w, transposed)
+    in_dtype = DTYPE_OF[x0.dtype]
+    out_dtype = in_dtype if out_dtype is None else out_dtype
+    out = torch.empty(n, p, q, coutp, dtype=TORCH_DTYPE[out_dtype], device=x0.device)
+    stats = None
+    if want_stats:
+        tiles = (n * p * q + tile_m(coutp) - 1) // tile_m(coutp)
+        stats = torch.empty(tiles, 2, coutp, dtype=torch.float32, device=x0.device)
+    call("msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats, n, h, w, p, q,
+         r, s, stride, pad_h, pad_w, int(transposed), in_dtype, out_dtype)
+    return out, stats

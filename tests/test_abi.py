@@ -17,7 +17,7 @@ def test_header_symbols_exported():
 def test_header_cites_reference():
     """Every entry point documents the reference call site it replaces."""
     src = open(_lib.HEADER).read()
-    assert src.count(".py:") >= 5
+    assert src.count(".py:") >= 3
 
 
 def test_status_codes_without_gpu():

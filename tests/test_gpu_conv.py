@@ -1,0 +1,125 @@
+"""GPU parity of the implicit-GEMM convolution (forward-type kernel) against torch CPU
+F.conv2d / F.conv_transpose2d, for every shape class of SURVEY section 2.3 at small batch.
+f32 mode must agree to f32 rounding; bf16 mode to bf16 operand rounding."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from msml_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+
+# (Cin1, Cin2, Cout, H, R, S, stride, pad_h, pad_w, bias)
+SHAPES = [
+    (3, 0, 64, 28, 3, 3, 1, 1, 1, False),      # FRB stem (C=3 padded to 8)
+    (3, 0, 64, 28, 3, 3, 2, 1, 1, False),      # OSB stem (stride 2)
+    (64, 0, 64, 14, 3, 3, 1, 1, 1, False),
+    (64, 0, 64, 14, 3, 3, 2, 1, 1, False),
+    (64, 0, 128, 14, 3, 3, 1, 1, 1, False),
+    (128, 0, 128, 7, 3, 3, 2, 1, 1, False),     # odd size, stride 2
+    (256, 0, 256, 14, 3, 3, 1, 1, 1, False),
+    (512, 0, 512, 7, 3, 3, 1, 1, 1, False),
+    (64, 18, 64, 14, 3, 3, 1, 1, 1, False),     # FM same_conv on cat(yf, yo)
+    (128, 18, 128, 7, 3, 3, 1, 1, 1, False),
+    (64, 0, 128, 14, 1, 1, 2, 0, 0, False),     # downsample 1x1 s2
+    (128, 0, 64, 7, 1, 1, 1, 0, 0, False),      # bottleneck 1x1
+    (64, 0, 18, 14, 7, 1, 1, 3, 0, True),       # GCM 7x1 with bias
+    (18, 0, 18, 14, 1, 7, 1, 0, 3, True),       # GCM 1x7 with bias
+    (512, 0, 8, 4, 1, 7, 1, 0, 3, True),
+    (512, 0, 512, 7, 7, 7, 1, 0, 0, True),      # fc as a 7x7 valid window (Linear 25088->512)
+]
+
+
+def run_conv(x1, x2, w, bias, stride, ph, pw, dtype):
+    xs = [ops.to_nhwc(x1.cuda(), dtype)]
+    if x2 is not None:
+        xs.append(ops.to_nhwc(x2.cuda(), dtype))
+    cout, cin, r, s = w.shape
+    wp = ops.pack_weight(w.cuda(), False, x1.shape[1], 0 if x2 is None else x2.shape[1], dtype)
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(ops.cpad(cout), device="cuda")
+        bp[:cout] = bias.cuda()
+    out, stats = ops.conv2d(xs[0], xs[1] if x2 is not None else None, wp, bp, ops.cpad(cout), r, s,
+                            stride, ph, pw, False, want_stats=True)
+    return out, stats
+
+
+@pytest.mark.parametrize("dtype,tol", [(_lib.F32, 2e-6), (_lib.BF16, 1.5e-2)])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_fwd(shape, dtype, tol):
+    c1, c2, cout, h, r, s, stride, ph, pw, has_bias = shape
+    g = torch.Generator().manual_seed(hash(shape) & 0xffff)
+    n = 3
+    x1 = torch.randn(n, c1, h, h, generator=g)
+    x2 = torch.randn(n, c2, h, h, generator=g) if c2 else None
+    w = torch.randn(cout, c1 + c2, r, s, generator=g) * (2.0 / ((c1 + c2) * r * s)) ** 0.5
+    bias = torch.randn(cout, generator=g) if has_bias else None
+    if dtype == _lib.BF16:      # compare against the same bf16-rounded operands
+        x1 = x1.bfloat16().float()
+        x2 = x2.bfloat16().float() if c2 else None
+        w = w.bfloat16().float()
+    xin = x1 if x2 is None else torch.cat((x1, x2), 1)
+    ref = F.conv2d(xin.double(), w.double(), None if bias is None else bias.double(), stride,
+                   (ph, pw)).float()
+    out, stats = run_conv(x1, x2, w, bias, stride, ph, pw, dtype)
+    got = ops.to_nchw(out, cout).cpu()
+    scale = ref.abs().max().item()
+    if dtype == _lib.F32:       # f32 accumulation error grows ~ sqrt(K) * eps
+        tol = 3e-7 * max(4.0, ((c1 + c2) * r * s) ** 0.5)
+    assert (got - ref).abs().max().item() <= tol * scale, (got - ref).abs().max().item() / scale
+    assert (out[..., cout:] == 0).all()                       # pad channels stay exact zeros
+    # epilogue statistics: per-channel sum / sum of squares over all pixels
+    ssum = stats.sum(0).cpu()
+    assert torch.allclose(ssum[0, :cout], ref.sum((0, 2, 3)), rtol=0, atol=tol * scale * ref[:, 0].numel() ** 0.5 + 1e-3)
+    assert torch.allclose(ssum[1, :cout], (ref * ref).sum((0, 2, 3)), rtol=max(tol * 4, 1e-4), atol=1e-3)
+
+
+# ConvTranspose2d forward (transposed gather): unet.py:145-156
+DECONVS = [
+    (8, 0, 18, 4, 3, 2, 1),        # deconv1: 8 -> 18, k3 s2 p1, 4x4 -> 7x7
+    (18, 18, 18, 7, 4, 2, 1),      # deconv2..5 on cat(seg, gcm): 36 -> 18, k4 s2 p1
+    (18, 18, 18, 14, 4, 2, 1),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(_lib.F32, 2e-6), (_lib.BF16, 1.5e-2)])
+@pytest.mark.parametrize("shape", DECONVS)
+def test_deconv_fwd(shape, dtype, tol):
+    c1, c2, cout, h, k, stride, pad = shape
+    g = torch.Generator().manual_seed(7)
+    n = 2
+    x1 = torch.randn(n, c1, h, h, generator=g)
+    x2 = torch.randn(n, c2, h, h, generator=g) if c2 else None
+    wt = torch.randn(c1 + c2, cout, k, k, generator=g) * 0.2      # ConvTranspose layout (Cin, Cout, k, k)
+    if dtype == _lib.BF16:
+        x1 = x1.bfloat16().float()
+        x2 = x2.bfloat16().float() if c2 else None
+        wt = wt.bfloat16().float()
+    xin = x1 if x2 is None else torch.cat((x1, x2), 1)
+    ref = F.conv_transpose2d(xin.double(), wt.double(), None, stride, pad).float()
+    xs = [ops.to_nhwc(x1.cuda(), dtype)] + ([ops.to_nhwc(x2.cuda(), dtype)] if c2 else [])
+    wp = ops.pack_weight(wt.cuda(), True, c1, c2, dtype)
+    out, _ = ops.conv2d(xs[0], xs[1] if c2 else None, wp, None, ops.cpad(cout), k, k, stride, pad,
+                        pad, True)
+    got = ops.to_nchw(out, cout).cpu()
+    assert got.shape == ref.shape
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= tol * scale
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv_dgrad_matches_autograd(stride):
+    """conv backward-data == transposed gather with the (ko=cin, ci=cout) packing."""
+    g = torch.Generator().manual_seed(9)
+    n, cin, cout, h = 2, 64, 128, 14
+    x = torch.randn(n, cin, h, h, generator=g, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    y = F.conv2d(x, w, None, stride, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wp = ops.pack_weight(w.cuda(), True, cout, 0, _lib.F32)
+    dyd = ops.to_nhwc(dy.cuda(), _lib.F32)
+    dx, _ = ops.conv2d(dyd, None, wp, None, cin, 3, 3, stride, 1, 1, True, p=h, q=h)
+    got = ops.to_nchw(dx, cin).cpu()
+    assert (got - x.grad).abs().max().item() <= 2e-6 * x.grad.abs().max().item() * 4
