@@ -101,6 +101,21 @@ int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, const void* 
                 int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int transposed,
                 int in_dtype, int out_dtype, void* stream);
 
+/* Weight gradient of the same family of layers (autograd of the call sites above, and
+ * headers/partial_fc.py:169 sub_weight.grad):
+ *   dw[a][boff+b][r][s] (+)= sum_{n,py,px} u[n,py,px,a] * v[n, py*stride-pad_h+r, px*stride-pad_w+s, b]
+ * u: NHWC [N][P][Q][up] on the natural grid; v: NHWC [N][H][W][vp] shifted operand.
+ * Conv2d: u = dY, v = X -> dw = [Cout][Cin][R][S]; ConvTranspose2d: u = X, v = dY ->
+ * dw = [Cin][Cout][R][S].  dw is f32 in the parameter's own layout with Btot columns; only
+ * a < A and b < Breal are written (channel-concat inputs call once per segment with boff).
+ * Deterministic split-K: partial slabs in `workspace` (msml_conv_wgrad_workspace bytes),
+ * summed in a fixed order.  N*P*Q must be < 2^24. */
+long msml_conv_wgrad_workspace(int up, int vp, int N, int P, int Q, int R, int S);
+int msml_conv_wgrad(const void* u, int up, const void* v, int vp, float* dw, int A, int Breal,
+                    int Btot, int boff, int N, int H, int W, int P, int Q, int R, int S,
+                    int stride, int pad_h, int pad_w, int accumulate, void* workspace,
+                    long ws_bytes, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,7 @@ def parse_header(path=HEADER):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\s*\*)\s+(msml_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int|long|const char\s*\*)\s+(msml_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         params = []
         if args and args != "void":
@@ -43,7 +43,8 @@ def parse_header(path=HEADER):
                 else:
                     ty, pn = a.rsplit(" ", 1)
                     params.append((_CT[ty.replace("const ", "").strip()], pn))
-        protos[name] = (ctypes.c_int if ret == "int" else ctypes.c_char_p, params)
+        rt = {"int": ctypes.c_int, "long": ctypes.c_long}.get(ret, ctypes.c_char_p)
+        protos[name] = (rt, params)
     return protos
 
 
@@ -93,6 +94,8 @@ def call(name, *args):
     if len(cargs) != len(params):
         raise TypeError("%s expects %d arguments, got %d" % (name, len(params), len(cargs)))
     rc = fn(*cargs)
+    if _protos[name][0] is not ctypes.c_int:
+        return rc
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.msml_last_error().decode()))
     return rc

@@ -1,0 +1,307 @@
+// Weight-gradient implicit GEMM on MFMA (gfx950).
+//
+//   dW[a][b][r][s] = sum_{n,py,px} U[n,py,px,a] * V[n, py*stride - pad_h + r, px*stride - pad_w + s, b]
+//
+// U is the operand on the natural pixel grid (P x Q), V the shifted one (H x W):
+//   Conv2d wgrad:           U = dY (a = cout), V = X  (b = cin)   -> dW[cout][cin][r][s]
+//   ConvTranspose2d wgrad:  U = X  (a = cin),  V = dY (b = cout)  -> dWt[cin][cout][r][s]
+//   Linear / PartialFC:     1x1 (or HxW valid) windows of the same form.
+// Replaces the autograd weight gradients of every conv/deconv/linear cited in conv_igemm.hip
+// and of headers/partial_fc.py:169 (sub_weight.grad).
+//
+// GEMM view: rows = a, cols = (tap, b), K = pixels (N*P*Q, up to 3.2 M) -> split-K over pixel
+// ranges; every split writes an f32 partial slab ws[split][a][tap][b] with plain stores and a
+// second kernel sums the slabs in a fixed order (deterministic, no float atomics) and scatters
+// into the parameter's own [A][Btot][R][S] layout.
+//
+// Both operands are pixel-major (channels contiguous), i.e. K-major: bf16 fragments are read
+// from LDS with the gfx950 transposing read ds_read_b64_tr_b16 (rows = pixels, 16-channel
+// blocks); LDS rows are padded to a pitch == 64 (mod 256) bytes so the four pixel rows of a
+// block fall in disjoint bank windows.  f32 fragments are plain ds_read_b32 (one k per lane).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+struct WgradArgs {
+  const void* u; int up;      // U: [N][P][Q][up]
+  const void* v; int vp;      // V: [N][H][W][vp]
+  int N, H, W, P, Q, R, S, stride, pad_h, pad_w;
+  float* ws;                  // [splits][arows][taps][vp]
+  int arows;                  // rows of a covered by the slab (= up)
+  long Mpix;                  // N*P*Q
+  int chunk;                  // pixels per split (multiple of 32)
+  float rcp_pq, rcp_q;
+};
+
+__device__ __forceinline__ void divmod(int m, int d, float rcp, int& q, int& r) {
+  q = (int)((float)m * rcp);
+  r = m - q * d;
+  if (r < 0) { r += d; q--; }
+  if (r >= d) { r -= d; q++; }
+}
+
+template <typename T, int BA, int BB>
+struct WTile {
+  static constexpr int ES = sizeof(T);
+  // pitch in bytes per pixel row of the U / V tiles
+  static constexpr int PU = BA * ES + (ES == 2 ? 64 : 0);
+  static constexpr int PV = BB * ES + (ES == 2 ? 64 : 0);
+  static constexpr int STAGE = 32 * (PU + PV);
+};
+
+__device__ __forceinline__ s16x8 tr_frag(const char* base, int pitch, int chan0, int pix0, int lane) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const char* addr = base + (pix0 + 8 * (g >> 1) + q) * pitch + (chan0 + 16 * (g & 1) + 4 * pp) * 2;
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(addr));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(addr + 4 * pitch));
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+template <typename T, int BA, int BB>
+__global__ void __launch_bounds__(256) k_conv_wgrad(const WgradArgs p) {
+  using WT = WTile<T, BA, BB>;
+  constexpr int CH = 16 / sizeof(T);           // elements per 16-B chunk
+  constexpr int CU = BA / CH, CV = BB / CH;    // chunks per pixel row
+  constexpr int PPU = 256 / CU, PPV = 256 / CV;   // pixels covered per pass
+  constexpr int NU = 32 / PPU > 0 ? 32 / PPU : 1, NV = 32 / PPV > 0 ? 32 / PPV : 1;
+  constexpr bool UPART = PPU > 32, VPART = PPV > 32;
+  constexpr int TM = BA / 64, TN = BB / 64;    // 2x2 waves, each (BA/2) x (BB/2)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int btiles = (p.vp + BB - 1) / BB;
+  const int a0 = blockIdx.x * BA;
+  const int tap = blockIdx.y / btiles, b0 = (blockIdx.y % btiles) * BB;
+  const int r = tap / p.S, s = tap % p.S;
+  const int split = blockIdx.z;
+  const long k_begin = (long)split * p.chunk;
+  long k_end = k_begin + p.chunk;
+  if (k_end > p.Mpix) k_end = p.Mpix;
+  const int nsteps = k_begin < k_end ? (int)((k_end - k_begin + 31) / 32) : 0;
+  const int PQ = p.P * p.Q;
+
+  const int ucc = t % CU, upx = t / CU;
+  const int vcc = t % CV, vpx = t / CV;
+  const bool u_chan_ok = a0 + ucc * CH < p.up;
+  const bool v_chan_ok = b0 + vcc * CH < p.vp;
+  const T* U = reinterpret_cast<const T*>(p.u);
+  const T* V = reinterpret_cast<const T*>(p.v);
+
+  u32x4 ru[NU], rv[NV];
+  auto gload = [&](int step) {
+    const long kb = k_begin + (long)step * 32;
+#pragma unroll
+    for (int i = 0; i < NU; i++) {
+      int j = upx + i * PPU;
+      long m = kb + j;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if ((!UPART || j < 32) && m < k_end && u_chan_ok)
+        val = *reinterpret_cast<const u32x4*>(U + m * p.up + a0 + ucc * CH);
+      ru[i] = val;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      int j = vpx + i * PPV;
+      long m = kb + j;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if ((!VPART || j < 32) && m < k_end && v_chan_ok) {
+        int n, rem, py, px;
+        divmod((int)m, PQ, p.rcp_pq, n, rem);
+        divmod(rem, p.Q, p.rcp_q, py, px);
+        int iy = py * p.stride - p.pad_h + r, ix = px * p.stride - p.pad_w + s;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          val = *reinterpret_cast<const u32x4*>(V + ((long)(n * p.H + iy) * p.W + ix) * p.vp + b0 +
+                                                vcc * CH);
+      }
+      rv[i] = val;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* ub = smem + buf * WT::STAGE;
+    char* vb = ub + 32 * WT::PU;
+#pragma unroll
+    for (int i = 0; i < NU; i++) {
+      int j = upx + i * PPU;
+      if (!UPART || j < 32) *reinterpret_cast<u32x4*>(ub + j * WT::PU + ucc * 16) = ru[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      int j = vpx + i * PPV;
+      if (!VPART || j < 32) *reinterpret_cast<u32x4*>(vb + j * WT::PV + vcc * 16) = rv[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int arow0 = wm * (BA / 2), bcol0 = wn * (BB / 2);
+
+  if (nsteps > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int step = 0; step < nsteps; step++) {
+    const bool more = step + 1 < nsteps;
+    if (more) gload(step + 1);
+    const char* ub = smem + cur * WT::STAGE;
+    const char* vb = ub + 32 * WT::PU;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        s16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) a[i] = tr_frag(ub, WT::PU, arow0 + 32 * i, 16 * kk, lane);
+#pragma unroll
+        for (int j = 0; j < TN; j++) b[j] = tr_frag(vb, WT::PV, bcol0 + 32 * j, 16 * kk, lane);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const int i32 = lane & 31, h = lane >> 5;
+#pragma unroll 4
+      for (int kk = 0; kk < 16; kk++) {
+        float a[TM], b[TN];
+        const int pix = 2 * kk + h;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+          a[i] = *reinterpret_cast<const float*>(ub + pix * WT::PU + (arow0 + 32 * i + i32) * 4);
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          b[j] = *reinterpret_cast<const float*>(vb + pix * WT::PV + (bcol0 + 32 * j + i32) * 4);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // partial slab: ws[split][a][tap][b]
+  const int h = lane >> 5, c32 = lane & 31;
+  const int taps = p.R * p.S;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int b = b0 + bcol0 + 32 * j + c32;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int a = a0 + arow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (a < p.arows && b < p.vp)
+          p.ws[(((long)split * p.arows + a) * taps + tap) * p.vp + b] = acc[i][j][e];
+      }
+    }
+}
+
+// dst[a][boff + b][tap] = sum_split ws[split][a][tap][b]   (a < A, b < Breal)
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dst,
+                                                      int splits, int arows, int taps, int vp, int A,
+                                                      int Breal, int Btot, int boff, int accumulate) {
+  long total = (long)A * taps * vp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    int b = (int)(i % vp);
+    long at = i / vp;
+    int tap = (int)(at % taps);
+    int a = (int)(at / taps);
+    if (b >= Breal) continue;
+    float sum = 0.f;
+    for (int sp = 0; sp < splits; sp++) sum += ws[(((long)sp * arows + a) * taps + tap) * vp + b];
+    long o = ((long)a * Btot + boff + b) * taps + tap;
+    dst[o] = accumulate ? dst[o] + sum : sum;
+  }
+}
+
+static int pick_tile(int c) { return c > 64 ? 128 : 64; }
+
+// number of pixel splits: enough workgroups to fill 256 CUs a few times over, chunks >= 256 px
+static int pick_splits(long mpix, int out_tiles) {
+  long want = (1024 + out_tiles - 1) / out_tiles;
+  long max_by_chunk = (mpix + 255) / 256;
+  long s = want < max_by_chunk ? want : max_by_chunk;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  return (int)s;
+}
+
+extern "C" long msml_conv_wgrad_workspace(int up, int vp, int N, int P, int Q, int R, int S) {
+  int ba = pick_tile(up), bb = pick_tile(vp);
+  int tiles = cdiv(up, ba) * cdiv(vp, bb) * R * S;
+  int splits = pick_splits((long)N * P * Q, tiles);
+  return (long)splits * up * R * S * vp * (long)sizeof(float);
+}
+
+extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, float* dw, int A,
+                               int Breal, int Btot, int boff, int N, int H, int W, int P, int Q,
+                               int R, int S, int stride, int pad_h, int pad_w, int accumulate,
+                               void* workspace, long ws_bytes, int dtype, void* stream) {
+  MSML_CHECK(u && v && dw && workspace, MSML_ERR_SHAPE, "conv_wgrad: null pointer");
+  MSML_CHECK(up > 0 && up % 8 == 0 && vp > 0 && vp % 8 == 0 && A > 0 && A <= up && Breal > 0 &&
+                 Breal <= vp && boff >= 0 && boff + Breal <= Btot,
+             MSML_ERR_SHAPE, "conv_wgrad: bad channels up=%d vp=%d A=%d Breal=%d Btot=%d boff=%d", up,
+             vp, A, Breal, Btot, boff);
+  MSML_CHECK(N > 0 && H > 0 && W > 0 && P > 0 && Q > 0 && R > 0 && S > 0 && stride >= 1,
+             MSML_ERR_SHAPE, "conv_wgrad: bad dims");
+  MSML_CHECK((long)N * P * Q < (1L << 24), MSML_ERR_UNSUPPORTED,
+             "conv_wgrad: N*P*Q = %ld exceeds 2^24 (float-reciprocal pixel decode)", (long)N * P * Q);
+  long need = msml_conv_wgrad_workspace(up, vp, N, P, Q, R, S);
+  MSML_CHECK(ws_bytes >= need, MSML_ERR_WORKSPACE, "conv_wgrad: workspace %ld < %ld bytes", ws_bytes, need);
+  WgradArgs a;
+  a.u = u; a.up = up; a.v = v; a.vp = vp;
+  a.N = N; a.H = H; a.W = W; a.P = P; a.Q = Q; a.R = R; a.S = S;
+  a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.ws = (float*)workspace;
+  a.arows = up;
+  a.Mpix = (long)N * P * Q;
+  a.rcp_pq = 1.0f / (float)(P * Q);
+  a.rcp_q = 1.0f / (float)Q;
+  const int ba = pick_tile(up), bb = pick_tile(vp);
+  const int atiles = cdiv(up, ba), btiles = cdiv(vp, bb), taps = R * S;
+  const int splits = pick_splits(a.Mpix, atiles * btiles * taps);
+  a.chunk = (int)(((a.Mpix + splits - 1) / splits + 31) / 32 * 32);
+  dim3 grid(atiles, btiles * taps, splits);
+  hipStream_t st = (hipStream_t)stream;
+#define WG_LAUNCH(T, BA_, BB_)                                                    \
+  {                                                                               \
+    typedef WTile<T, BA_, BB_> WT_;                                               \
+    k_conv_wgrad<T, BA_, BB_><<<grid, dim3(256), 2 * WT_::STAGE, st>>>(a);        \
+  }
+#define WG_CASE(T)                                            \
+  if (ba == 128 && bb == 128) WG_LAUNCH(T, 128, 128)          \
+  else if (ba == 128) WG_LAUNCH(T, 128, 64)                   \
+  else if (bb == 128) WG_LAUNCH(T, 64, 128)                   \
+  else WG_LAUNCH(T, 64, 64)
+  if (dtype == MSML_F32) { WG_CASE(float) }
+  else if (dtype == MSML_BF16) { WG_CASE(unsigned short) }
+  else {
+    msml_set_error("conv_wgrad: unsupported dtype %d", dtype);
+    return MSML_ERR_DTYPE;
+  }
+  MSML_LAUNCH_OK("conv_wgrad");
+  long total = (long)A * taps * vp;
+  int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  k_wgrad_reduce<<<rgrid, 256, 0, st>>>(a.ws, dw, splits, up, taps, vp, A, Breal, Btot, boff, accumulate);
+  MSML_LAUNCH_OK("conv_wgrad_reduce");
+  return MSML_OK;
+}

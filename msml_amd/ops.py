@@ -76,3 +76,26 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
     call("msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats, n, h, w, p, q,
          r, s, stride, pad_h, pad_w, int(transposed), in_dtype, out_dtype)
     return out, stats
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device (stream-ordered reuse on the current stream)."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[device] = buf
+    return buf
+
+
+def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accumulate=False):
+    """dw[a][boff+b][r][s] = sum_pix u[pix][a] * v[shift(pix, r, s)][b] (see msml_conv_wgrad)."""
+    n, p, q, up = u.shape
+    _, h, w, vp = v.shape
+    need = _lib.load().msml_conv_wgrad_workspace(up, vp, n, p, q, r, s)
+    ws = workspace(need, u.device)
+    call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
+         pad_h, pad_w, int(accumulate), ws, ws.numel(), DTYPE_OF[u.dtype])
+    return dw

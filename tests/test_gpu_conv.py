@@ -123,3 +123,58 @@ def test_conv_dgrad_matches_autograd(stride):
     dx, _ = ops.conv2d(dyd, None, wp, None, cin, 3, 3, stride, 1, 1, True, p=h, q=h)
     got = ops.to_nchw(dx, cin).cpu()
     assert (got - x.grad).abs().max().item() <= 2e-6 * x.grad.abs().max().item() * 4
+
+
+WGRADS = [
+    # (cin1, cin2, cout, h, r, s, stride, ph, pw)
+    (64, 0, 64, 14, 3, 3, 1, 1, 1),
+    (64, 0, 128, 14, 3, 3, 2, 1, 1),
+    (128, 18, 128, 7, 3, 3, 1, 1, 1),     # two-segment input: one call per segment
+    (3, 0, 64, 28, 3, 3, 1, 1, 1),
+    (256, 0, 256, 14, 3, 3, 1, 1, 1),
+    (64, 0, 128, 14, 1, 1, 2, 0, 0),
+    (64, 0, 18, 14, 7, 1, 1, 3, 0),
+    (512, 0, 512, 7, 7, 7, 1, 0, 0),      # fc
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(_lib.F32, 1e-5), (_lib.BF16, 1.5e-2)])
+@pytest.mark.parametrize("shape", WGRADS)
+def test_conv_wgrad(shape, dtype, tol):
+    c1, c2, cout, h, r, s, stride, ph, pw = shape
+    g = torch.Generator().manual_seed(21)
+    n = 3
+    x = torch.randn(n, c1 + c2, h, h, generator=g)
+    p = (h + 2 * ph - r) // stride + 1
+    q = (h + 2 * pw - s) // stride + 1
+    dy = torch.randn(n, cout, p, q, generator=g)
+    if dtype == _lib.BF16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    w = torch.zeros(cout, c1 + c2, r, s, dtype=torch.double, requires_grad=True)
+    F.conv2d(x.double(), w, None, stride, (ph, pw)).backward(dy.double())
+    ref = w.grad.float()
+    dyd = ops.to_nhwc(dy.cuda(), dtype)
+    dw = torch.full((cout, c1 + c2, r, s), 3.0, device="cuda")
+    ops.conv_wgrad(dyd, ops.to_nhwc(x[:, :c1].cuda(), dtype), dw, cout, c1, c1 + c2, 0, r, s, stride,
+                   ph, pw)
+    if c2:
+        ops.conv_wgrad(dyd, ops.to_nhwc(x[:, c1:].cuda(), dtype), dw, cout, c2, c1 + c2, c1, r, s,
+                       stride, ph, pw)
+    scale = ref.abs().max().item()
+    assert (dw.cpu() - ref).abs().max().item() <= tol * scale
+
+
+def test_deconv_wgrad():
+    """ConvTranspose2d weight gradient: u = x (natural grid), v = dy (shifted), roles swapped."""
+    g = torch.Generator().manual_seed(23)
+    n, cin, cout, h, k = 2, 36, 18, 7, 4
+    x = torch.randn(n, cin, h, h, generator=g)
+    wt = torch.zeros(cin, cout, k, k, dtype=torch.double, requires_grad=True)
+    y = F.conv_transpose2d(x.double(), wt, None, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    ref = wt.grad.float()
+    dw = torch.zeros(cin, cout, k, k, device="cuda")
+    xd = ops.to_nhwc(x.cuda(), _lib.F32)
+    ops.conv_wgrad(xd, ops.to_nhwc(dy.cuda(), _lib.F32), dw, cin, cout, cout, 0, k, k, 2, 1, 1)
+    assert (dw.cpu() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
