@@ -116,6 +116,89 @@ int msml_conv_wgrad(const void* u, int up, const void* v, int vp, float* dw, int
                     int stride, int pad_h, int pad_w, int accumulate, void* workspace,
                     long ws_bytes, int dtype, void* stream);
 
+/* ---------------------------------------------------------------- BatchNorm / PReLU --------
+ * nn.BatchNorm2d(eps=1e-5, momentum=0.1) + nn.PReLU + residual of IBasicBlock
+ * (backbones/frb/iresnet.py:56-67, backbones/osb/unet.py:80-91), resblock_bottle
+ * (backbones/fm/fmoperator.py:53-68), the stems (iresnet.py:209-211, unet.py:193-195), bn2 and
+ * BatchNorm1d `features` (iresnet.py:225,233).  Tensors are [M pixels][C], C % 8 == 0.
+ *
+ * msml_bn_stats: per-channel partial (sum, sumsq) rows -> partial[msml_bn_stats_rows(M,C)][2][C]
+ * (the conv kernel's `stats` output has the same row format).
+ * msml_bn_finalize: rows > 0 (training): mean / biased var from the partial rows (f64, fixed
+ *   order), running stats updated in place like torch (unbiased var, momentum), mean/invstd saved;
+ *   rows == 0 (eval): coefficients from the running stats.  Outputs scale = gamma*invstd,
+ *   shift = beta - mean*scale.  gamma/beta NULL mean 1/0.
+ * msml_bn_act_fwd: res_first == 0: y = prelu(x*scale[c] + shift[c], alpha[c]) + residual
+ *   (IBasicBlock); res_first == 1: y = prelu(x*scale[c] + shift[c] + residual, alpha[c])
+ *   (resblock_bottle, fmoperator.py:65-67).  alpha / residual optional.
+ * msml_bn_act_bwd (training statistics): dx, dgamma, dbeta, dalpha from dy and the saved x;
+ *   residual_first (the saved residual, only for res_first == 1) and dres (gradient flowing
+ *   to that residual) optional; workspace >= rows*3*C + 2*C floats. */
+int msml_bn_stats_rows(long M, int C);
+int msml_bn_stats(const void* x, long M, int C, float* partial, int dtype, void* stream);
+int msml_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                     void* stream);
+int msml_bn_act_fwd(const void* x, const float* scale, const float* shift, const float* alpha,
+                    const void* residual, int res_first, void* y, long M, int C, int dtype,
+                    void* stream);
+int msml_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
+                    const float* alpha, const float* save_mean, const float* save_invstd,
+                    const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,
+                    float* dalpha, long M, int C, float* workspace, long ws_floats, int dtype,
+                    void* stream);
+/* db[c] = sum over pixels of dy (biased GCM convs, backbones/osb/unet.py:23-30);
+ * workspace >= msml_bn_stats_rows(M,Cp)*2*Cp floats. */
+int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* db, float* workspace,
+                   long ws_floats, int dtype, void* stream);
+/* out = a + b (GCM branch sum unet.py:37; gradient joins) */
+int msml_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- OSB tail + seg loss -------
+ * msml_dap_fwd: DAP = PixelShuffle(3)->AvgPool2d(3) (backbones/osb/unet.py:158-161,223) == mean
+ *   over 9-channel groups; x NHWC [N][H][W][Cp>=18] -> seg NCHW f32 [N][2][H][W] and (optional)
+ *   mask[N][H][W] u8 = argmax over the 2 classes, ties -> 0 (train.py:357). */
+int msml_dap_fwd(const void* x, float* seg, unsigned char* mask, int N, int H, int W, int Cp,
+                 int dtype, void* stream);
+int msml_dap_bwd(const float* dseg, void* dx, int N, int H, int W, int Cp, int dtype, void* stream);
+/* StructureConsensuLossFunction(alpha, beta, 'idx', 'idx')(logit, msk, msk)
+ * (tricks/consensus_loss.py:65-167, train.py:258).  logit NCHW f32 [N][2][H][W], msk int64
+ * [N][H][W] in {0,1}; loss[1]; dlogit (optional) = d loss / d logit.  workspace >= 20*N floats. */
+int msml_seg_consensus_loss(const float* logit, const long* msk, int N, int H, int W, float alpha,
+                            float beta, float* loss, float* dlogit, float* workspace,
+                            long ws_floats, void* stream);
+
+/* ---------------------------------------------------------------- classification head -------
+ * kind: 0 = AMArcFace (headers/margin_losses.py:356-418), 1 = AMCosFace (:241-305).
+ * msml_rownorm_fwd: F.normalize rows of w[R][E] (margin_losses.py:371, partial_fc.py:115) into
+ *   dst[Rp][ld] (storage dtype, zero padded) + inv_norm[R].
+ * msml_rownorm_bwd: dw (+)= (dy - y<y,dy>) * inv_norm  with dy f32 [R][ldy].
+ * msml_gather_target / msml_margin_fwd / msml_margin_bwd: margin on the target logits, in place
+ *   on the f32 cosine matrix [N][ld]; backward emits dcos in storage dtype [N][ldo].
+ * msml_pfc_rowstats / msml_pfc_grad: the two local passes of PartialFC's distributed
+ *   softmax-CE (partial_fc.py:132-167) around the max / sum / loss all-reduces; the margin is
+ *   applied on the fly so the logits are never materialised. */
+int msml_rownorm_fwd(const float* w, int R, int Rp, int E, void* dst, int ld, float* inv_norm,
+                     int dtype, void* stream);
+int msml_rownorm_bwd(const float* w, const float* inv_norm, const float* dy, int ldy, int R, int E,
+                     float* dw, int accumulate, void* stream);
+int msml_gather_target(const float* cosm, int ld, const long* label, int N, float* out,
+                       void* stream);
+int msml_margin_fwd(float* cosm, const long* label, int N, int C, int ld, int kind, float s,
+                    float m, float a, float k, void* stream);
+int msml_margin_bwd(const float* dlogit, int ldg, const long* label, const float* cos_t, int N,
+                    int C, void* dcos, int ldo, int kind, float s, float m, float a, float k,
+                    int dtype, void* stream);
+int msml_pfc_rowstats(const float* cosm, int ld, int N, int C, const long* label, int kind, float s,
+                      float m, float a, float k, float* rowmax, float* rowsum, void* stream);
+int msml_pfc_grad(const float* cosm, int ld, int N, int C, const long* label, int kind, float s,
+                  float m, float a, float k, const float* gmax, const float* gsum, float eps_ls,
+                  float inv_n, void* dcos, int ldo, float* ptarget, int dtype, void* stream);
+/* torch.optim.SGD(momentum, weight_decay) step on one flat f32 buffer (train.py:179-191). */
+int msml_sgd_momentum(float* w, const float* grad, float* mom, long n, float lr, float mu, float wd,
+                      int first_step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

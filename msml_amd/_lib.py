@@ -99,3 +99,9 @@ def call(name, *args):
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.msml_last_error().decode()))
     return rc
+
+
+def value(name, *args):
+    """Call a pure query function (tile sizes, workspace sizes) and return its result."""
+    lib = load()
+    return getattr(lib, name)(*[_arg(a) for a in args])

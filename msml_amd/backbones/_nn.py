@@ -1,0 +1,36 @@
+"""Glue between torch parameter containers (nn.Conv2d, nn.BatchNorm2d, nn.PReLU ... kept so
+that names, shapes and initialisation equal the reference's) and the HIP autograd functions.
+The containers' own forward() is never called: all arithmetic goes through the C ABI."""
+import torch.nn as nn
+
+from .. import functional as Fh
+from ..ops import pack_weight
+from .._lib import DTYPE_OF
+
+
+def conv(m, x0, x1=None, want_stats=False, c0=None, c1=0):
+    """Run nn.Conv2d / nn.ConvTranspose2d `m` on NHWC input(s).  x1: second concat segment."""
+    deconv = isinstance(m, nn.ConvTranspose2d)
+    cin = m.in_channels
+    if c0 is None:
+        c0 = cin - c1
+    assert c0 + c1 == cin
+    assert m.groups == 1 and m.dilation == (1, 1) and m.stride[0] == m.stride[1]
+    cfg = {"deconv": deconv, "c0": c0, "c1": c1, "cout": m.out_channels, "stride": m.stride[0],
+           "pad_h": m.padding[0], "pad_w": m.padding[1], "want_stats": want_stats}
+    wp = None
+    if not m.weight.requires_grad or not m.training:
+        # inference: cache the packed weight until the parameter changes
+        key = (m.weight._version, m.weight.data_ptr(), x0.dtype)
+        cache = m.__dict__.get("_msml_wp")
+        if cache is None or cache[0] != key:
+            cache = (key, pack_weight(m.weight.detach(), deconv, c0, c1, DTYPE_OF[x0.dtype]))
+            m.__dict__["_msml_wp"] = cache
+        wp = cache[1]
+    return Fh.conv(x0, x1, m.weight, m.bias, cfg, wp)
+
+
+def conv_bn(conv_m, bn_m, x0, x1=None, prelu=None, residual=None, c1=0, res_first=False):
+    """conv -> BatchNorm (-> PReLU) (+ residual); BN statistics come from the conv epilogue."""
+    y, stats = conv(conv_m, x0, x1, want_stats=bn_m.training, c1=c1)
+    return Fh.bn_act(y, stats, bn_m, prelu, residual, res_first)

@@ -1,0 +1,100 @@
+"""MSML on the MI355X HIP path: drop-in for backbones/msml.py of the reference.
+
+Same constructor (msml.py:20-33), same forward(x, label=None, ori=None) (msml.py:150-174):
+training returns (final_cls, final_seg, kd), eval returns (feature, final_seg); state-dict keys
+are `frb.*`, `osb.*`, `classification.*` exactly as the reference's.
+
+`fp16` selects the compute mode of the whole net: False -> exact-f32 MFMA (parity mode, matches
+the reference's fp32 results to rounding), True -> bf16 operands with f32 accumulation
+(the reference's autocast analogue; see DESIGN.md for the measured error).
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as Fh
+from .._lib import BF16, F32
+from ..headers import AMArcFace, AMCosFace, Softmax
+from .fm import FMCnn, FMNone
+from .frb import iresnet18, iresnet34, iresnet50, iresnet100
+from .osb import unet
+
+__all__ = ["MSML"]
+
+
+class MSML(nn.Module):
+    frb_type_list = ("iresnet18", "iresnet34", "iresnet50", "iresnet100")
+    osb_type_list = ("unet",)
+    head_type_list = ("Softmax", "AMArcFace", "AMCosFace")
+
+    def __init__(self, frb_type: str, osb_type: str, fm_layers: tuple, num_classes: int,
+                 fp16: bool = False, frb_pretrained: bool = False,
+                 fm_params: tuple = (3, 2, "tanh", "add"), header_type: str = "Softmax",
+                 header_params: tuple = (64.0, 0.5, 0.0, 0.0), dropout: float = 0.,
+                 use_osb: bool = True, peer_params: dict = None):
+        super().__init__()
+        assert len(fm_layers) == 4
+        if "iresnet" not in frb_type:
+            raise ValueError("FRB type error (msml_amd builds the IResNet FRB only)")
+        if "unet" not in osb_type:
+            raise ValueError("OSB type error")
+        self.input_size, self.gray = 112, False
+        self.heights = (56, 28, 14, 7)
+        self.f_channels = (64, 128, 256, 512)
+        self.dim_feature = 512
+        self.s_channels = (18, 18, 18, 18)
+        peer_params = dict(peer_params or {})
+        peer_params["header_type"] = header_type
+        kernel_size, num_res, act, arith = fm_params
+        fm_ops = []
+        for i in range(4):
+            if fm_layers[i] == 0:
+                fm_ops.append(FMNone())
+            elif fm_layers[i] == 1:
+                fm_ops.append(FMCnn(self.heights[i], self.heights[i], self.f_channels[i], kernel_size,
+                                    num_res, act, arith, peer_params))
+            else:
+                raise ValueError("FM Operators type error")
+        self.fm_ops = fm_ops          # plain list, like the reference (registered under frb)
+        ctor = None
+        for key, fn in (("100", iresnet100), ("18", iresnet18), ("34", iresnet34), ("50", iresnet50)):
+            if key in frb_type:
+                ctor = fn
+                break
+        if ctor is None:
+            raise ValueError("IResNet type {} not found".format(frb_type))
+        self.frb = ctor(self.fm_ops, pretrained=frb_pretrained, dropout=dropout,
+                        peer_params=peer_params)
+        self.osb = unet(backbone="r18", gray=self.gray, input_size=self.input_size)
+        self.num_classes = num_classes
+        assert header_type in self.head_type_list
+        s, m, a, k = header_params
+        if "Softmax" in header_type:
+            self.classification = Softmax(self.dim_feature, num_classes, device_id=None)
+        elif "AMCosFace" in header_type:
+            self.classification = AMCosFace(self.dim_feature, num_classes, device_id=None, s=s, m=m,
+                                            a=a, k=k)
+        else:
+            self.classification = AMArcFace(self.dim_feature, num_classes, device_id=None, s=s, m=m,
+                                            a=a, k=k)
+        self.fp16 = fp16
+        self.classification.fp16 = fp16
+        self.use_osb = use_osb
+
+    def forward(self, x, label=None, ori=None):
+        if not x.is_cuda:
+            raise RuntimeError("msml_amd.MSML runs on an MI355X only (no CPU path); got a CPU tensor")
+        if not self.use_osb:
+            raise NotImplementedError("msml_amd: use_osb=False is not built")
+        xh = Fh.to_nhwc(x, BF16 if self.fp16 else F32)
+        seg_list = self.osb(xh)                    # [seg0, seg1, seg2, seg3, seg5]
+        final_seg = seg_list[4]
+        segs = [seg_list[3], seg_list[2], seg_list[1], seg_list[0]]
+        feature, kd = self.frb(xh, segs, ori)
+        if self.training:
+            if label is None:
+                # head-less training return for the PartialFC path (train.py:283): the reference's
+                # dead op2 branch calls backbone(img) and feeds the embedding to PartialFC.
+                return feature, final_seg, kd
+            final_cls = self.classification(feature, label) + kd
+            return final_cls, final_seg, kd
+        return feature, final_seg

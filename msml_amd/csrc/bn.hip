@@ -1,0 +1,360 @@
+// BatchNorm (train + eval) / PReLU / residual kernels on NHWC [M pixels][C] tensors, C % 8 == 0.
+//
+// Reference call sites: nn.BatchNorm2d + nn.PReLU + `out += identity` in IBasicBlock
+// (backbones/frb/iresnet.py:56-67, backbones/osb/unet.py:80-91), resblock_bottle
+// (backbones/fm/fmoperator.py:53-68), stems (iresnet.py:209-211), bn2 / BatchNorm1d features
+// (iresnet.py:225,233).  BN is per-GPU (no SyncBN: train.py:135-137).
+//
+// HBM-bound streaming kernels; per-channel reductions are two-level: every workgroup reduces
+// its pixel slab in registers -> LDS -> one partial row in a workspace (plain stores), and a
+// tiny finalize kernel sums the rows in f64 in a fixed order (deterministic; no float atomics).
+#include "common.h"
+
+#define RED_ROWS_MAX 1024      // partial rows produced by the standalone reduction kernels
+
+// ------------------------------------------------------------------ per-channel reduction ---
+// Generic slab reducer: thread (cx, py) accumulates NQ quantities x 8 channels over pixels
+// py, py+PY, ... of the block's slab, then LDS-reduces over py.  F: functor
+//   void operator()(long pix, int c8, float (&q)[NQ][8])  adds one pixel chunk's contribution.
+template <int NQ, typename F>
+__device__ __forceinline__ void slab_reduce(long M, int C, float* __restrict__ partial, F f) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);            // [PY][NQ][C]
+  const int C8 = C / 8;
+  const int PY = 256 / C8 > 0 ? 256 / C8 : 1;                 // pixel lanes per block
+  const int t = threadIdx.x;
+  const int cx = t % C8, py = t / C8;
+  float q[NQ][8];
+#pragma unroll
+  for (int a = 0; a < NQ; a++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[a][j] = 0.f;
+  const long per = (M + gridDim.x - 1) / gridDim.x;
+  const long beg = blockIdx.x * per;
+  long end = beg + per;
+  if (end > M) end = M;
+  if (py < PY)
+    for (long pix = beg + py; pix < end; pix += PY) f(pix, cx, q);
+  // C8 may exceed 256 only if C > 2048: not supported by the launchers
+  if (py < PY) {
+#pragma unroll
+    for (int a = 0; a < NQ; a++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) red[(py * NQ + a) * C + cx * 8 + j] = q[a][j];
+  }
+  __syncthreads();
+  for (int i = t; i < NQ * C; i += blockDim.x) {
+    float s = 0.f;
+    for (int y = 0; y < PY; y++) s += red[y * NQ * C + i];
+    partial[(long)blockIdx.x * NQ * C + i] = s;
+  }
+}
+
+static inline int red_rows(long M, int C) {
+  int py = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
+  long rows = (M + (long)py * 16 - 1) / ((long)py * 16);     // >= 16 pixels per thread
+  if (rows < 1) rows = 1;
+  if (rows > RED_ROWS_MAX) rows = RED_ROWS_MAX;
+  return (int)rows;
+}
+static inline size_t red_lds(int NQ, int C) {
+  int py = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
+  return (size_t)py * NQ * C * sizeof(float);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_bn_stats(const T* __restrict__ x, long M, int C,
+                                                  float* __restrict__ partial) {
+  slab_reduce<2>(M, C, partial, [&](long pix, int c8, float(&q)[2][8]) {
+    Vec8 v = load8<T>(x + pix * C + c8 * 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      q[0][j] += v.v[j];
+      q[1][j] += v.v[j] * v.v[j];
+    }
+  });
+}
+
+extern "C" int msml_bn_stats_rows(long M, int C) { return red_rows(M, C); }
+
+extern "C" int msml_bn_stats(const void* x, long M, int C, float* partial, int dtype, void* stream) {
+  MSML_CHECK(x && partial && M > 0 && C > 0 && C % 8 == 0 && C <= 2048, MSML_ERR_SHAPE,
+             "bn_stats: bad shape M=%ld C=%d", M, C);
+  int rows = red_rows(M, C);
+  MSML_DISPATCH_DTYPE(dtype, "bn_stats",
+                      k_bn_stats<DT><<<rows, 256, red_lds(2, C), (hipStream_t)stream>>>(
+                          (const DT*)x, M, C, partial);)
+  MSML_LAUNCH_OK("bn_stats");
+  return MSML_OK;
+}
+
+// ------------------------------------------------------------------ finalize (forward) -------
+// partial: [rows][2][C] (sum, sumsq).  rows == 0 -> eval mode: coefficients from running stats.
+// Training also updates the running statistics exactly like nn.BatchNorm (momentum, unbiased
+// variance) and stores mean / invstd for the backward.
+__global__ void k_bn_finalize(const float* __restrict__ partial, int rows, int C, double count,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                              float eps, float* __restrict__ scale, float* __restrict__ shift,
+                              float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, invstd;
+  if (rows > 0) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; r++) {
+      s1 += (double)partial[((long)r * 2 + 0) * C + c];
+      s2 += (double)partial[((long)r * 2 + 1) * C + c];
+    }
+    double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+      double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+  } else {
+    mean = rmean[c];
+    invstd = 1.0f / sqrtf(rvar[c] + eps);
+  }
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * invstd;
+  shift[c] = b - mean * g * invstd;
+  if (save_mean) {
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+  }
+}
+
+extern "C" int msml_bn_finalize(const float* partial, int rows, int C, double count,
+                                const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float momentum, float eps, float* scale,
+                                float* shift, float* save_mean, float* save_invstd, void* stream) {
+  MSML_CHECK(C > 0 && scale && shift && rows >= 0, MSML_ERR_SHAPE, "bn_finalize: bad args");
+  MSML_CHECK(rows > 0 ? (partial && count > 0) : (running_mean && running_var), MSML_ERR_SHAPE,
+             "bn_finalize: train needs partials, eval needs running stats");
+  k_bn_finalize<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(
+      partial, rows, C, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+      save_mean, save_invstd);
+  MSML_LAUNCH_OK("bn_finalize");
+  return MSML_OK;
+}
+
+// ------------------------------------------------------------------ apply (forward) ----------
+// y = prelu(x * scale[c] + shift[c]) + residual      (alpha == null: no PReLU; residual optional)
+template <typename T>
+__global__ void __launch_bounds__(256) k_bn_act_fwd(const T* __restrict__ x, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift,
+                                                    const float* __restrict__ alpha,
+                                                    const T* __restrict__ residual, int res_first,
+                                                    T* __restrict__ y, long n8, int C8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % C8) * 8;
+    Vec8 v = load8<T>(x + i * 8);
+    Vec8 r;
+    if (residual) r = load8<T>(residual + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float z = v.v[j] * scale[c0 + j] + shift[c0 + j];
+      if (residual && res_first) z += r.v[j];
+      if (alpha) z = z > 0.f ? z : z * alpha[c0 + j];
+      if (residual && !res_first) z += r.v[j];
+      v.v[j] = z;
+    }
+    store8<T>(y + i * 8, v);
+  }
+}
+
+static inline int ew_grid(long n8) {
+  long b = (n8 + 255) / 256;
+  return (int)(b < 2048 ? b : 2048);
+}
+
+extern "C" int msml_bn_act_fwd(const void* x, const float* scale, const float* shift,
+                               const float* alpha, const void* residual, int res_first, void* y,
+                               long M, int C, int dtype, void* stream) {
+  MSML_CHECK(x && y && scale && shift && M > 0 && C > 0 && C % 8 == 0, MSML_ERR_SHAPE,
+             "bn_act_fwd: bad shape M=%ld C=%d", M, C);
+  long n8 = M * (C / 8);
+  MSML_DISPATCH_DTYPE(dtype, "bn_act_fwd",
+                      k_bn_act_fwd<DT><<<ew_grid(n8), 256, 0, (hipStream_t)stream>>>(
+                          (const DT*)x, scale, shift, alpha, (const DT*)residual, res_first, (DT*)y, n8,
+                          C / 8);)
+  MSML_LAUNCH_OK("bn_act_fwd");
+  return MSML_OK;
+}
+
+// ------------------------------------------------------------------ backward ------------------
+// With z = x*scale + shift, g = dy * prelu'(z), xhat = (x - mean) * invstd:
+//   reduce: s1 = sum g, s2 = sum g * xhat, s3 = sum dy * min(z, 0)   (d alpha)
+//   apply:  dx = gamma * invstd * (g - s1/n - xhat * s2/n)
+template <typename T>
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy, const T* __restrict__ x,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const float* __restrict__ alpha,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const T* __restrict__ res, long M, int C,
+                                                       float* __restrict__ partial) {
+  slab_reduce<3>(M, C, partial, [&](long pix, int c8, float(&q)[3][8]) {
+    Vec8 g = load8<T>(dy + pix * C + c8 * 8);
+    Vec8 v = load8<T>(x + pix * C + c8 * 8);
+    Vec8 rr;
+    if (res) rr = load8<T>(res + pix * C + c8 * 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      int c = c8 * 8 + j;
+      float gg = g.v[j];
+      if (alpha) {
+        float z = v.v[j] * scale[c] + shift[c];
+        if (res) z += rr.v[j];
+        if (z <= 0.f) {
+          q[2][j] += gg * z;
+          gg *= alpha[c];
+        }
+      }
+      float xh = (v.v[j] - mean[c]) * invstd[c];
+      q[0][j] += gg;
+      q[1][j] += gg * xh;
+    }
+  });
+}
+
+__global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int rows, int C, double count,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                  float* __restrict__ dalpha, float* __restrict__ coef) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int r = 0; r < rows; r++) {
+    s1 += (double)partial[((long)r * 3 + 0) * C + c];
+    s2 += (double)partial[((long)r * 3 + 1) * C + c];
+    s3 += (double)partial[((long)r * 3 + 2) * C + c];
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  if (dalpha) dalpha[c] = (float)s3;
+  coef[c] = (float)(s1 / count);
+  coef[C + c] = (float)(s2 / count);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ shift,
+                                                      const float* __restrict__ alpha,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd,
+                                                      const float* __restrict__ coef,
+                                                      const T* __restrict__ res, T* __restrict__ dx,
+                                                      T* __restrict__ dres, long n8, int C8) {
+  const int C = C8 * 8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % C8) * 8;
+    Vec8 g = load8<T>(dy + i * 8);
+    Vec8 v = load8<T>(x + i * 8);
+    Vec8 rr;
+    if (res) rr = load8<T>(res + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      int c = c0 + j;
+      float gg = g.v[j];
+      if (alpha) {
+        float z = v.v[j] * scale[c] + shift[c];
+        if (res) z += rr.v[j];
+        if (z <= 0.f) gg *= alpha[c];
+      }
+      float xh = (v.v[j] - mean[c]) * invstd[c];
+      // scale[c] == gamma * invstd
+      v.v[j] = scale[c] * (gg - coef[c] - xh * coef[C + c]);
+      g.v[j] = gg;
+    }
+    store8<T>(dx + i * 8, v);
+    if (dres) store8<T>(dres + i * 8, g);
+  }
+}
+
+extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
+                               const float* alpha, const float* save_mean, const float* save_invstd,
+                               const void* residual_first, void* dx, void* dres, float* dgamma,
+                               float* dbeta, float* dalpha, long M, int C, float* workspace,
+                               long ws_floats, int dtype, void* stream) {
+  MSML_CHECK(dy && x && dx && scale && shift && save_mean && save_invstd && workspace && M > 0 &&
+                 C > 0 && C % 8 == 0 && C <= 2048,
+             MSML_ERR_SHAPE, "bn_act_bwd: bad args M=%ld C=%d", M, C);
+  int rows = red_rows(M, C);
+  long need = (long)rows * 3 * C + 2 * C;
+  MSML_CHECK(ws_floats >= need, MSML_ERR_WORKSPACE, "bn_act_bwd: workspace %ld < %ld floats", ws_floats, need);
+  float* partial = workspace;
+  float* coef = workspace + (long)rows * 3 * C;
+  hipStream_t st = (hipStream_t)stream;
+  long n8 = M * (C / 8);
+  MSML_DISPATCH_DTYPE(
+      dtype, "bn_act_bwd",
+      k_bn_bwd_reduce<DT><<<rows, 256, red_lds(3, C), st>>>((const DT*)dy, (const DT*)x, scale, shift,
+                                                            alpha, save_mean, save_invstd,
+                                                            (const DT*)residual_first, M, C, partial);
+      MSML_LAUNCH_OK("bn_bwd_reduce");
+      k_bn_bwd_finalize<<<cdiv(C, 128), 128, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef);
+      MSML_LAUNCH_OK("bn_bwd_finalize");
+      k_bn_bwd_apply<DT><<<ew_grid(n8), 256, 0, st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
+                                                     save_mean, save_invstd, coef, (const DT*)residual_first,
+                                                     (DT*)dx, (DT*)dres, n8, C / 8);)
+  MSML_LAUNCH_OK("bn_bwd_apply");
+  return MSML_OK;
+}
+
+// ------------------------------------------------------------------ bias gradient ------------
+// db[c] = sum over pixels of dy[.., c]  (GCM convs carry a bias: backbones/osb/unet.py:23-30)
+__global__ void k_colsum_finalize(const float* __restrict__ partial, int rows, int C, int stride_q,
+                                  float* __restrict__ out, int Creal) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Creal) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; r++) s += (double)partial[(long)r * stride_q * C + c];
+  out[c] = (float)s;
+}
+
+extern "C" int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* db, float* workspace,
+                              long ws_floats, int dtype, void* stream) {
+  MSML_CHECK(dy && db && workspace && M > 0 && Cp > 0 && Cp % 8 == 0 && Creal <= Cp, MSML_ERR_SHAPE,
+             "bias_grad: bad args");
+  int rows = red_rows(M, Cp);
+  MSML_CHECK(ws_floats >= (long)rows * 2 * Cp, MSML_ERR_WORKSPACE, "bias_grad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  MSML_DISPATCH_DTYPE(dtype, "bias_grad",
+                      k_bn_stats<DT><<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace);)
+  MSML_LAUNCH_OK("bias_grad");
+  k_colsum_finalize<<<cdiv(Creal, 128), 128, 0, st>>>(workspace, rows, Cp, 2, db, Creal);
+  MSML_LAUNCH_OK("bias_grad_finalize");
+  return MSML_OK;
+}
+
+// ------------------------------------------------------------------ plain element-wise -------
+// out = a + b (residual joins in backward, GCM left+right branch sum: unet.py:37)
+template <typename T>
+__global__ void __launch_bounds__(256) k_add(const T* __restrict__ a, const T* __restrict__ b,
+                                             T* __restrict__ o, long n8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8;
+       i += (long)gridDim.x * blockDim.x) {
+    Vec8 x = load8<T>(a + i * 8), y = load8<T>(b + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) x.v[j] += y.v[j];
+    store8<T>(o + i * 8, x);
+  }
+}
+
+extern "C" int msml_add(const void* a, const void* b, void* out, long n, int dtype, void* stream) {
+  MSML_CHECK(a && b && out && n > 0 && n % 8 == 0, MSML_ERR_SHAPE, "add: n=%ld", n);
+  MSML_DISPATCH_DTYPE(dtype, "add",
+                      k_add<DT><<<ew_grid(n / 8), 256, 0, (hipStream_t)stream>>>(
+                          (const DT*)a, (const DT*)b, (DT*)out, n / 8);)
+  MSML_LAUNCH_OK("add");
+  return MSML_OK;
+}

@@ -1,0 +1,406 @@
+"""Autograd functions over the C ABI.  Every tensor that flows between them is an NHWC storage
+tensor [N, H, W, Cp] (f32 or bf16); parameters stay f32 in the reference's layouts, so
+state dicts and optimizers see exactly what they see with the reference modules.
+
+Backward functions run on PyTorch's autograd thread; the library is reentrant and every call
+passes torch's current stream explicitly.
+"""
+import torch
+
+from . import ops
+from ._lib import BF16, DTYPE_OF, F32, TORCH_DTYPE, call
+from .ops import cpad
+
+
+class _ToNHWC(torch.autograd.Function):
+    """MSML.forward boundary: NCHW f32 image -> NHWC storage (backbones/msml.py:150)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        return ops.to_nhwc(x.float(), dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None
+
+
+def to_nhwc(x, dtype):
+    return _ToNHWC.apply(x, dtype)
+
+
+def _slice_w(w, deconv, off, n):
+    if deconv:
+        return w[off:off + n]
+    return w[:, off:off + n].contiguous()
+
+
+class _Conv(torch.autograd.Function):
+    """Conv2d / ConvTranspose2d (+bias) on up to two channel-concatenated inputs, with optional
+    per-channel (sum, sumsq) partials of the output for a following training-mode BatchNorm."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, cfg, wp):
+        deconv = cfg["deconv"]
+        c0, c1 = cfg["c0"], cfg["c1"]
+        cout = cfg["cout"]
+        r, s = weight.shape[2], weight.shape[3]
+        dtype = DTYPE_OF[x0.dtype]
+        if wp is None:
+            wp = ops.pack_weight(weight.detach(), deconv, c0, c1, dtype)
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(cpad(cout), dtype=torch.float32, device=x0.device)
+            bp[:cout] = bias.detach()
+        y, stats = ops.conv2d(x0, x1, wp, bp, cpad(cout), r, s, cfg["stride"], cfg["pad_h"],
+                              cfg["pad_w"], deconv, out_dtype=cfg.get("out_dtype"),
+                              want_stats=cfg.get("want_stats", False))
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x0, x1, weight)
+        if stats is None:
+            stats = x0.new_empty(0)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x0, x1, weight = ctx.saved_tensors
+        cfg = ctx.cfg
+        deconv, c0, c1, cout = cfg["deconv"], cfg["c0"], cfg["c1"], cfg["cout"]
+        stride, ph, pw = cfg["stride"], cfg["pad_h"], cfg["pad_w"]
+        r, s = weight.shape[2], weight.shape[3]
+        dy = dy.contiguous()
+        if DTYPE_OF[dy.dtype] != DTYPE_OF[x0.dtype]:
+            dy = dy.to(x0.dtype)
+        dtype = DTYPE_OF[x0.dtype]
+        w = weight.detach()
+        n, h, wd, _ = x0.shape
+        grads = [None, None]
+        for i, (x, off, ci) in enumerate(((x0, 0, c0), (x1, c0, c1))):
+            if x is None or not ctx.needs_input_grad[i]:
+                continue
+            ws = _slice_w(w, deconv, off, ci)
+            if deconv:      # backward-data of a transposed conv = strided conv of dy
+                wp = ops.pack_weight(ws, False, cout, 0, dtype)
+                grads[i], _ = ops.conv2d(dy, None, wp, None, cpad(ci), r, s, stride, ph, pw, False,
+                                         p=h, q=wd)
+            else:           # backward-data of a conv = transposed gather of dy
+                wp = ops.pack_weight(ws, True, cout, 0, dtype)
+                grads[i], _ = ops.conv2d(dy, None, wp, None, cpad(ci), r, s, stride, ph, pw, True,
+                                         p=h, q=wd)
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(w)
+            for x, off, ci in ((x0, 0, c0), (x1, c0, c1)):
+                if x is None:
+                    continue
+                if deconv:
+                    ops.conv_wgrad(x, dy, dw[off:off + ci], ci, cout, cout, 0, r, s, stride, ph, pw)
+                else:
+                    ops.conv_wgrad(dy, x, dw, cout, ci, c0 + c1, off, r, s, stride, ph, pw)
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            m = dy.numel() // dy.shape[-1]
+            cp = dy.shape[-1]
+            rows = ops.bn_stats_rows(m, cp)
+            wsb = ops.workspace(rows * 2 * cp * 4, dy.device)
+            db = torch.empty(cout, dtype=torch.float32, device=dy.device)
+            call("msml_bias_grad", dy, m, cp, cout, db, wsb, wsb.numel() // 4, dtype)
+        return grads[0], grads[1], dw, db, None, None
+
+
+def conv(x0, x1, weight, bias, cfg, wp=None):
+    y, stats = _Conv.apply(x0, x1, weight, bias, cfg, wp)
+    return y, (stats if stats.numel() else None)
+
+
+class _BnAct(torch.autograd.Function):
+    """y = prelu(batch_norm(x)) + residual (PReLU and residual optional)."""
+
+    @staticmethod
+    def forward(ctx, x, stats, gamma, beta, alpha, residual, rmean, rvar, training, momentum, eps,
+                res_first):
+        c = x.shape[-1]
+        m = x.numel() // c
+        dtype = DTYPE_OF[x.dtype]
+        dev = x.device
+        coef = torch.empty(4, c, dtype=torch.float32, device=dev)   # scale, shift, mean, invstd
+        if training:
+            if stats is None:
+                rows = ops.bn_stats_rows(m, c)
+                stats = torch.empty(rows, 2, c, dtype=torch.float32, device=dev)
+                call("msml_bn_stats", x, m, c, stats, dtype)
+            call("msml_bn_finalize", stats, stats.shape[0], c, float(m), gamma, beta, rmean, rvar,
+                 momentum, eps, coef[0], coef[1], coef[2], coef[3])
+        else:
+            call("msml_bn_finalize", None, 0, c, 0.0, gamma, beta, rmean, rvar, momentum, eps,
+                 coef[0], coef[1], coef[2], coef[3])
+        y = torch.empty_like(x)
+        call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, int(res_first), y, m, c, dtype)
+        ctx.training = training
+        ctx.has = (gamma is not None, beta is not None, alpha is not None, residual is not None)
+        ctx.res_first = bool(res_first) and residual is not None and alpha is not None
+        ctx.save_for_backward(x, coef, alpha, residual if ctx.res_first else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, coef, alpha, res = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("msml_amd: backward through eval-mode BatchNorm is not supported")
+        c = x.shape[-1]
+        m = x.numel() // c
+        dtype = DTYPE_OF[x.dtype]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        pg = torch.empty(3, c, dtype=torch.float32, device=x.device)
+        rows = ops.bn_stats_rows(m, c)
+        need = (rows * 3 * c + 2 * c) * 4
+        ws = ops.workspace(need, x.device)
+        dres = torch.empty_like(x) if ctx.res_first else None
+        call("msml_bn_act_bwd", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, dx, dres,
+             pg[0], pg[1], pg[2] if alpha is not None else None, m, c, ws, ws.numel() // 4, dtype)
+        has_g, has_b, has_a, has_r = ctx.has
+        if ctx.res_first:
+            dy = dres
+        return (dx, None,
+                pg[0] if has_g and ctx.needs_input_grad[2] else None,
+                pg[1] if has_b and ctx.needs_input_grad[3] else None,
+                pg[2] if has_a and ctx.needs_input_grad[4] else None,
+                dy if has_r else None, None, None, None, None, None, None)
+
+
+def bn_act(x, stats, bn, prelu=None, residual=None, res_first=False):
+    """Apply an nn.BatchNorm module `bn` (+ optional nn.PReLU, + residual) to an NHWC tensor.
+    res_first: prelu(bn(x) + residual) instead of prelu(bn(x)) + residual."""
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return _BnAct.apply(x, stats, bn.weight, bn.bias, prelu.weight if prelu is not None else None,
+                        residual, bn.running_mean, bn.running_var, training,
+                        0.1 if bn.momentum is None else bn.momentum, bn.eps, res_first)
+
+
+class _FmFuse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, yf, act, arith):
+        z = torch.empty_like(yf)
+        call("msml_fm_fuse_fwd", x, yf, z, x.numel(), act, arith, DTYPE_OF[x.dtype])
+        ctx.save_for_backward(x, yf)
+        ctx.mode = (act, arith)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, yf = ctx.saved_tensors
+        dz = dz.contiguous()
+        dx, dyf = torch.empty_like(x), torch.empty_like(yf)
+        call("msml_fm_fuse_bwd", dz, x, yf, dx, dyf, x.numel(), ctx.mode[0], ctx.mode[1],
+             DTYPE_OF[x.dtype])
+        return dx, dyf, None, None
+
+
+ACTS = {"tanh": 0, "sigmoid": 1}
+ARITHS = {"add": 0, "sub": 1, "mul": 2, "div": 3}
+
+
+def fm_fuse(x, yf, act, arith):
+    return _FmFuse.apply(x, yf, ACTS[act], ARITHS[arith])
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        call("msml_add", a, b, out, a.numel(), DTYPE_OF[a.dtype])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Dap(torch.autograd.Function):
+    """NHWC 18-channel map -> final_seg NCHW f32 (N, 2, H, W)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, h, w, cp = x.shape
+        seg = torch.empty(n, 2, h, w, dtype=torch.float32, device=x.device)
+        call("msml_dap_fwd", x, seg, None, n, h, w, cp, DTYPE_OF[x.dtype])
+        ctx.meta = (x.shape, x.dtype)
+        return seg
+
+    @staticmethod
+    def backward(ctx, dseg):
+        shape, dt = ctx.meta
+        dx = torch.empty(shape, dtype=dt, device=dseg.device)
+        call("msml_dap_bwd", dseg.contiguous().float(), dx, shape[0], shape[1], shape[2], shape[3],
+             DTYPE_OF[dt])
+        return dx
+
+
+def dap(x):
+    return _Dap.apply(x)
+
+
+def mask_index(final_seg):
+    """Occlusion-mask index (train.py:357): uint8 (N, H, W), 0 = occluded, 1 = clean."""
+    n, _, h, w = final_seg.shape
+    a, b = final_seg[:, 0], final_seg[:, 1]
+    return (b > a).to(torch.uint8)
+
+
+class _ToVec(torch.autograd.Function):
+    """NHWC [N,1,1,C] storage -> (N, C) f32 feature (and back for the gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.meta = (x.shape, x.dtype)
+        return x.reshape(x.shape[0], -1)[:, :c].float()
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dt = ctx.meta
+        out = torch.zeros(shape, dtype=dt, device=g.device)
+        out.reshape(shape[0], -1)[:, :g.shape[1]] = g.to(dt)
+        return out, None
+
+
+def to_vec(x, c):
+    return _ToVec.apply(x, c)
+
+
+class _SegLoss(torch.autograd.Function):
+    """StructureConsensuLossFunction(alpha, beta, 'idx', 'idx')(logit, msk, msk)."""
+
+    @staticmethod
+    def forward(ctx, logit, msk, alpha, beta):
+        n, c, h, w = logit.shape
+        assert c == 2
+        logit = logit.contiguous().float()
+        msk = msk.to(device=logit.device, dtype=torch.int64).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=logit.device)
+        dlogit = torch.empty_like(logit)
+        ws = torch.empty(20 * n, dtype=torch.float32, device=logit.device)
+        call("msml_seg_consensus_loss", logit, msk, n, h, w, alpha, beta, loss, dlogit, ws,
+             ws.numel())
+        ctx.save_for_backward(dlogit)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogit,) = ctx.saved_tensors
+        return dlogit * g, None, None, None
+
+
+def seg_consensus_loss(logit, msk, alpha=10.0, beta=5.0):
+    return _SegLoss.apply(logit, msk, alpha, beta)
+
+
+# --------------------------------------------------------------------------- cosine heads
+HEAD_KIND = {"arc": 0, "cos": 1}
+
+
+class _CosMarginHead(torch.autograd.Function):
+    """s * margin(normalize(emb) @ normalize(W).T) -- AMArcFace / AMCosFace forward
+    (headers/margin_losses.py:371-418 / :257-303) with explicit backward."""
+
+    @staticmethod
+    def forward(ctx, emb, weight, label, kind, s, m, a, k, dtype):
+        b, e = emb.shape
+        c = weight.shape[0]
+        dev = emb.device
+        tdt = TORCH_DTYPE[dtype]
+        cp = cpad(c)
+        kop = (cp + ops.tile_n(cp) - 1) // ops.tile_n(cp) * ops.tile_n(cp)
+        xn = torch.empty(b, 1, 1, e, dtype=tdt, device=dev)
+        inv_x = torch.empty(b, dtype=torch.float32, device=dev)
+        call("msml_rownorm_fwd", emb.detach().contiguous(), b, b, e, xn, e, inv_x, dtype)
+        wn = torch.empty(kop, e, dtype=tdt, device=dev)
+        inv_w = torch.empty(c, dtype=torch.float32, device=dev)
+        call("msml_rownorm_fwd", weight.detach(), c, kop, e, wn, e, inv_w, dtype)
+        cosm, _ = ops.conv2d(xn, None, wn, None, cp, 1, 1, 1, 0, 0, False, out_dtype=F32)
+        cosm = cosm.reshape(b, cp)
+        label = label.to(device=dev, dtype=torch.int64).contiguous()
+        cos_t = torch.empty(b, dtype=torch.float32, device=dev)
+        call("msml_gather_target", cosm, cp, label, b, cos_t)
+        call("msml_margin_fwd", cosm, label, b, c, cp, kind, s, m, a, k)
+        ctx.save_for_backward(emb, weight, label, xn, wn, inv_x, inv_w, cos_t)
+        ctx.prm = (kind, s, m, a, k, dtype)
+        return cosm[:, :c]
+
+    @staticmethod
+    def backward(ctx, dlogit):
+        emb, weight, label, xn, wn, inv_x, inv_w, cos_t = ctx.saved_tensors
+        kind, s, m, a, k, dtype = ctx.prm
+        b, e = emb.shape
+        c = weight.shape[0]
+        dev = emb.device
+        tdt = TORCH_DTYPE[dtype]
+        cp = cpad(c)
+        dlogit = dlogit.contiguous().float()
+        dcos = torch.empty(b, 1, 1, cp, dtype=tdt, device=dev)
+        call("msml_margin_bwd", dlogit, dlogit.shape[1], label, cos_t, b, c, dcos, cp, kind, s, m,
+             a, k, dtype)
+        demb = dw = None
+        if ctx.needs_input_grad[0]:
+            # dXn = dcos @ Wn : GEMM with K = classes -> weights packed transposed [E][Cp]
+            wnt = ops.pack_weight(wn[:c].float().reshape(c, e, 1, 1), True, c, 0, dtype)
+            dxn, _ = ops.conv2d(dcos, None, wnt, None, e, 1, 1, 1, 0, 0, False, out_dtype=F32)
+            demb = torch.empty_like(emb)
+            call("msml_rownorm_bwd", emb.detach().contiguous(), inv_x, dxn.reshape(b, e), e, b, e,
+                 demb, 0)
+        if ctx.needs_input_grad[1]:
+            dwn = torch.empty(c, e, dtype=torch.float32, device=dev)
+            ops.conv_wgrad(dcos, xn, dwn, c, e, e, 0, 1, 1, 1, 0, 0)
+            dw = torch.empty_like(weight)
+            call("msml_rownorm_bwd", weight.detach(), inv_w, dwn, e, c, e, dw, 0)
+        return demb, dw, None, None, None, None, None, None, None
+
+
+def cos_margin_head(emb, weight, label, kind, s, m, a, k, dtype):
+    return _CosMarginHead.apply(emb, weight, label, HEAD_KIND[kind], s, m, a, k, dtype)
+
+
+class _Linear(torch.autograd.Function):
+    """Plain F.linear(emb, W, b) (Softmax head, headers/margin_losses.py:53) on the MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, emb, weight, bias, dtype):
+        b, e = emb.shape
+        c = weight.shape[0]
+        tdt = TORCH_DTYPE[dtype]
+        x = emb.detach().to(tdt).reshape(b, 1, 1, e).contiguous()
+        wp = ops.pack_weight(weight.detach().reshape(c, e, 1, 1), False, e, 0, dtype)
+        bp = torch.zeros(cpad(c), dtype=torch.float32, device=emb.device)
+        bp[:c] = bias.detach()
+        y, _ = ops.conv2d(x, None, wp, bp, cpad(c), 1, 1, 1, 0, 0, False, out_dtype=F32)
+        ctx.save_for_backward(x, weight)
+        ctx.dtype = dtype
+        return y.reshape(b, -1)[:, :c]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dtype = ctx.dtype
+        tdt = TORCH_DTYPE[dtype]
+        b, e = x.shape[0], x.shape[3]
+        c = weight.shape[0]
+        cp = cpad(c)
+        g = torch.zeros(b, 1, 1, cp, dtype=tdt, device=dy.device)
+        g.reshape(b, cp)[:, :c] = dy.to(tdt)
+        wt = ops.pack_weight(weight.detach().reshape(c, e, 1, 1), True, c, 0, dtype)
+        dx, _ = ops.conv2d(g, None, wt, None, e, 1, 1, 1, 0, 0, False, out_dtype=F32)
+        dw = torch.empty_like(weight)
+        ops.conv_wgrad(g, x, dw, c, e, e, 0, 1, 1, 1, 0, 0)
+        db = dy.float().sum(0)
+        return dx.reshape(b, e), dw, db, None
+
+
+def linear(emb, weight, bias, dtype):
+    return _Linear.apply(emb, weight, bias, dtype)

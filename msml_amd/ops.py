@@ -52,6 +52,10 @@ def pack_weight(w, transpose, c1, c2, dtype):
     return wp
 
 
+def bn_stats_rows(m, c):
+    return _lib.value("msml_bn_stats_rows", m, c)
+
+
 def conv_out_size(h, r, stride, pad, transposed, out_pad=0):
     if transposed:
         return (h - 1) * stride - 2 * pad + r + out_pad
@@ -94,7 +98,7 @@ def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accum
     """dw[a][boff+b][r][s] = sum_pix u[pix][a] * v[shift(pix, r, s)][b] (see msml_conv_wgrad)."""
     n, p, q, up = u.shape
     _, h, w, vp = v.shape
-    need = _lib.load().msml_conv_wgrad_workspace(up, vp, n, p, q, r, s)
+    need = _lib.value("msml_conv_wgrad_workspace", up, vp, n, p, q, r, s)
     ws = workspace(need, u.device)
     call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
          pad_h, pad_w, int(accumulate), ws, ws.numel(), DTYPE_OF[u.dtype])

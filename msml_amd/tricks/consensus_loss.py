@@ -1,0 +1,23 @@
+"""Segmentation loss on the HIP path (reference: tricks/consensus_loss.py:28-179).
+
+Only the configuration the reference trains with is built: reduce_pixel='idx',
+reduce_pixel_kl='idx', blobs == target (train.py:228-229,258)."""
+import torch.nn as nn
+
+from .. import functional as Fh
+
+
+class StructureConsensuLossFunction(nn.Module):
+    def __init__(self, consensus_loss_alpha=10.0, consensus_loss_beta=5.0, reduce_pixel="idx",
+                 reduce_pixel_kl="idx"):
+        super().__init__()
+        if reduce_pixel != "idx" or reduce_pixel_kl != "idx":
+            raise NotImplementedError("msml_amd: only the 'idx'/'idx' reductions are built")
+        self.consensus_loss_alpha = consensus_loss_alpha
+        self.consensus_loss_beta = consensus_loss_beta
+
+    def forward(self, logit, blobs, target):
+        if blobs is not target and not bool((blobs == target).all()):
+            raise NotImplementedError("msml_amd: blobs must equal target (as in train.py:258)")
+        return Fh.seg_consensus_loss(logit, target, float(self.consensus_loss_alpha),
+                                     float(self.consensus_loss_beta))
