@@ -147,7 +147,13 @@ def test_train_step_g4(variant):
     for key in g.files:
         if key.startswith("grad_pick/"):
             n = key.split("/", 1)[1]
-            e = rel_err(pick(params[n].grad, 32), g[key])
+            got = pick(params[n].grad, 32)
+            if n == "frb.fc.bias":
+                # followed by train-mode BatchNorm1d: the exact gradient is 0, both sides hold
+                # rounding noise only
+                assert np.abs(got).max() < 1e-5 and np.abs(g[key]).max() < 1e-5
+                continue
+            e = rel_err(got, g[key])
             worst = max(worst, e)
             assert e < 1e-2, (n, e)
     print("train step %s: worst picked-grad rel err %.3e" % (variant, worst))
