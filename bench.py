@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""Benchmark of the MSML hot path on MI355X (driver contract, see DESIGN.md 'Measurement').
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one full training pass over one synthetic batch: MSML (OSB + FRB + FM) forward,
+PartialFC/ArcFace head forward+backward (class-parallel over the N ranks), consensus seg loss,
+backbone backward, gradient all-reduce (N > 1), fused clip + SGD on backbone and head.
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): ires50-MSML + 85 742-id
+PartialFC, 112x112, batch 256 per GPU, bf16 operands / f32 accumulation.  Weak scaling.
+
+Rank 0 prints ONE JSON line: images/sec over all ranks, plus
+  roofline     -- the implicit-GEMM conv kernel: algorithmic FLOP of its launches in the timed
+                  region / their summed duration (HIP events on the launch stream) vs the dense
+                  bf16 MFMA peak
+  cpu_baseline -- (N == 1 only) the CPU oracle's training step on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # MI355X_MICROARCH.md (dense)
+PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frb", default="iresnet50")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=85742)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    return ap.parse_args()
+
+
+class Trainer:
+    """The training step of train.py:252-318 (op2 / PartialFC branch) on the HIP path."""
+
+    def __init__(self, args, rank, local_rank, world):
+        from msml_amd import functional as Fh
+        from msml_amd.backbones import MSML
+        from msml_amd.headers import ArcMargin, PartialFC
+        from msml_amd.optim import FlatSGD, reference_param_groups
+        from msml_amd.tricks.consensus_loss import StructureConsensuLossFunction
+        from msml_amd import synthetic
+        self.Fh = Fh
+        self.world = world
+        fp16 = args.dtype == "bf16"
+        dev = torch.device("cuda", local_rank)
+        torch.manual_seed(1234)                      # same init on every rank (train.py:133-134)
+        self.model = MSML(args.frb, "unet", (1, 1, 1, 1), 8, fp16=fp16,
+                          fm_params=(3, 2, "sigmoid", "mul"), header_type="AMArcFace",
+                          header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(PEER_OFF)).to(dev)
+        for p in self.model.classification.parameters():   # live full-class head unused here
+            p.requires_grad_(False)
+        self.model.train()
+        self.pfc = PartialFC(rank, local_rank, world, args.batch, False,
+                             ArcMargin(64.0, 0.48, 0.0, 0.0), args.classes, fp16=fp16)
+        self.opt = FlatSGD(reference_param_groups(self.model, args.batch, world), 0.9, 5e-4, 5.0)
+        self.opt_pfc = FlatSGD([{"params": [self.pfc.sub_weight], "lr": 0.1 / 512 * args.batch * world}],
+                               0.9, 5e-4, None)
+        self.pfc.weight = self.pfc.sub_weight.data
+        self.seg_crit = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")
+        # a short stream of synthetic batches resident in HBM (cycled), so the head cannot
+        # simply memorise one batch during the run
+        self.batches = []
+        for i in range(4):
+            seed = 1 + rank + 100 * i
+            x = synthetic.images(args.batch, seed=seed)
+            x, msk = synthetic.rect_occlusion(x, seed=seed)
+            lab = synthetic.labels(args.batch, args.classes, seed=seed)
+            self.batches.append((x.to(dev), msk.to(dev), lab.to(dev)))
+        self.it = 0
+
+    def step(self):
+        Fh = self.Fh
+        x, msk, label = self.batches[self.it % len(self.batches)]
+        self.it += 1
+        self.opt.zero_grad()
+        feature, final_seg, kd = self.model(x)                   # head-less training return
+        fn = Fh.normalize(feature)
+        x_grad, loss_v = self.pfc.forward_backward(label, fn, None)
+        seg_loss = self.seg_crit(final_seg, msk, msk)
+        torch.autograd.backward([fn, seg_loss], [x_grad, None])
+        self.opt.all_reduce_grads(self.world)
+        self.opt.step()
+        self.opt_pfc.flat_g.copy_(self.pfc.sub_weight.grad.reshape(-1))
+        self.opt_pfc.step()
+        return loss_v, seg_loss
+
+
+class Inferer:
+    """Config 5: embedding extraction, orig + h-flip passes summed (qeval_mxnet.py:326-390)."""
+
+    def __init__(self, args, rank, local_rank, world):
+        from msml_amd.backbones import MSML
+        from msml_amd import synthetic
+        dev = torch.device("cuda", local_rank)
+        torch.manual_seed(1234)
+        self.model = MSML(args.frb, "unet", (1, 1, 1, 1), 8, fp16=args.dtype == "bf16",
+                          fm_params=(3, 2, "sigmoid", "mul"), header_type="AMArcFace",
+                          header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(PEER_OFF)).to(dev).eval()
+        a, b, _ = synthetic.occluded_pairs(args.batch // 2, seed=1 + rank)
+        self.x = torch.cat((a, b)).to(dev)
+
+    @torch.no_grad()
+    def step(self):
+        f1, _ = self.model(self.x)
+        f2, _ = self.model(self.x.flip(3))
+        return torch.nn.functional.normalize(f1 + f2), None
+
+
+def cpu_baseline(args):
+    """The CPU oracle's training step on a bounded sample (rank 0, N == 1)."""
+    from msml_amd import synthetic
+    from oracle import model as om
+    bs = 8
+    torch.manual_seed(0)
+    m = om.MSML(args.frb, "unet", (1, 1, 1, 1), 8, fm_params=(3, 2, "sigmoid", "mul"),
+                header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0))
+    m.train()
+    w = torch.randn(args.classes, 512) * 0.01
+    mom = torch.zeros_like(w)
+    x = synthetic.images(bs, 1)
+    x, msk = synthetic.rect_occlusion(x, 1)
+    label = synthetic.labels(bs, args.classes, 1)
+    params = [p for n, p in m.named_parameters() if "classification" not in n and p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.1 / 512 * bs, momentum=0.9, weight_decay=5e-4)
+    margin = lambda lg, lab: om.margin_logits(lg, lab, "arc", 64.0, 0.48, 0.0, 0.0)  # noqa: E731
+
+    def step():
+        opt.zero_grad()
+        seg = m.osb(x)
+        feat, _ = m.frb(x, [seg[3], seg[2], seg[1], seg[0]], None)
+        fn = torch.nn.functional.normalize(feat)
+        loss, dx, dw = om.pfc_rank_step(fn.detach(), label, w, 0, margin, lambda t: t, lambda t: t)
+        seg_loss = om.consensus_loss(seg[4], msk)
+        torch.autograd.backward([fn, seg_loss], [dx, None])
+        torch.nn.utils.clip_grad_norm_(params, 5, 2)
+        opt.step()
+        g = dw + 5e-4 * w
+        mom.mul_(0.9).add_(g)
+        w.sub_(0.1 / 512 * bs * mom)
+    step()
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < 12 and n < 6):
+        step()
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n * bs / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d training steps of the CPU oracle (%s-MSML + %d-id head), batch %d, f32"
+                      % (n, args.frb, args.classes, bs)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from msml_amd import ops
+    runner = (Trainer if args.mode == "train" else Inferer)(args, rank, local_rank, world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.step()
+    barrier()
+    if not args.no_kernel_events:
+        ops.PROFILE.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = runner.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.PROFILE.stop() if not args.no_kernel_events else {}
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tt, dist.ReduceOp.MAX)
+        dt = tt.item()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    imgs = args.batch * world * args.steps
+    value = imgs / dt
+    rec = {
+        "metric": "images/sec (112x112) %s-MSML+PartialFC %s step" % (args.frb.replace("iresnet", "ires"),
+                                                                     "training" if args.mode == "train" else "embedding-extraction"),
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": "%s-MSML (OSB r18 + FM x4) + %d-id ArcFace PartialFC, 112x112, batch %d/GPU, %s"
+                               % (args.frb, args.classes, args.batch,
+                                  "fwd+bwd+clip+SGD" if args.mode == "train" else "orig+flip forward"),
+                   "global_batch": args.batch * world, "parallelism": "dp%d+class-parallel head" % world},
+    }
+    if args.mode == "train" and out[0] is not None:
+        rec["loss"] = round(float(out[0]), 4)
+    k = prof.get("conv_igemm")
+    if k:
+        peak = PEAK_TFLOPS[args.dtype]
+        ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        rec["roofline"] = {"bound": "mfma", "kernel": "k_conv_igemm (implicit-GEMM conv fwd/dgrad)",
+                           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(ach / peak, 4), "traffic": None,
+                           "launches": k["n"], "avg_us": round(k["ms"] * 1e3 / k["n"], 2)}
+        rec["kernels"] = {name: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["n"] // args.steps,
+                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                 "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
+                          for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    if world == 1 and not args.no_cpu_baseline and args.mode == "train":
+        rec["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,9 +195,15 @@ int msml_pfc_rowstats(const float* cosm, int ld, int N, int C, const long* label
 int msml_pfc_grad(const float* cosm, int ld, int N, int C, const long* label, int kind, float s,
                   float m, float a, float k, const float* gmax, const float* gsum, float eps_ls,
                   float inv_n, void* dcos, int ldo, float* ptarget, int dtype, void* stream);
-/* torch.optim.SGD(momentum, weight_decay) step on one flat f32 buffer (train.py:179-191). */
+/* torch.optim.SGD(momentum, weight_decay) step on one flat, 16-B aligned f32 buffer
+ * (train.py:179-191); clip_coef (device scalar or NULL) multiplies the gradient first.
+ * msml_grad_norm_clip: out2[0] = global L2 norm of grad[n], out2[1] = min(1, max_norm /
+ * (norm + 1e-6)) = torch.nn.utils.clip_grad_norm_'s factor (train.py:270,275), on device, no
+ * host sync; workspace >= 1024 floats. */
 int msml_sgd_momentum(float* w, const float* grad, float* mom, long n, float lr, float mu, float wd,
-                      int first_step, float grad_scale, void* stream);
+                      int first_step, const float* clip_coef, void* stream);
+int msml_grad_norm_clip(const float* grad, long n, float max_norm, float* out2, float* workspace,
+                        long ws_floats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -281,14 +281,34 @@ extern "C" int msml_pfc_grad(const float* cosm, int ld, int N, int C, const long
   return MSML_OK;
 }
 
-// ------------------------------------------------------------------ fused SGD -----------------
+// ------------------------------------------------------------------ fused SGD + clip ---------
 // torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False) (train.py:179-191):
-//   g = grad + wd * w;  buf = first ? g : mu * buf + g;  w -= lr * buf
+//   g = grad * coef + wd * w;  buf = first ? g : mu * buf + g;  w -= lr * buf
+// coef (device scalar, optional) is the clip_grad_norm_ factor (train.py:270,275) so that
+// clipping costs no extra pass over the gradients and no host synchronisation.
 __global__ void __launch_bounds__(256) k_sgd(float* __restrict__ w, const float* __restrict__ grad,
-                                             float* __restrict__ mom, long n, float lr, float mu, float wd,
-                                             int first, float gscale) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float g = grad[i] * gscale + wd * w[i];
+                                             float* __restrict__ mom, long n4, long n, float lr, float mu,
+                                             float wd, int first, const float* __restrict__ coef_ptr) {
+  const float coef = coef_ptr ? coef_ptr[0] : 1.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 ww = reinterpret_cast<f32x4*>(w)[i];
+    f32x4 gg = reinterpret_cast<const f32x4*>(grad)[i];
+    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+    if (!first) bb = reinterpret_cast<f32x4*>(mom)[i];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float g = gg[j] * coef + wd * ww[j];
+      float b = first ? g : mu * bb[j] + g;
+      bb[j] = b;
+      ww[j] -= lr * b;
+    }
+    reinterpret_cast<f32x4*>(mom)[i] = bb;
+    reinterpret_cast<f32x4*>(w)[i] = ww;
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    long i = n4 * 4 + threadIdx.x;
+    float g = grad[i] * coef + wd * w[i];
     float b = first ? g : mu * mom[i] + g;
     mom[i] = b;
     w[i] -= lr * b;
@@ -296,11 +316,54 @@ __global__ void __launch_bounds__(256) k_sgd(float* __restrict__ w, const float*
 }
 
 extern "C" int msml_sgd_momentum(float* w, const float* grad, float* mom, long n, float lr, float mu,
-                                 float wd, int first_step, float grad_scale, void* stream) {
+                                 float wd, int first_step, const float* clip_coef, void* stream) {
   MSML_CHECK(w && grad && mom && n > 0, MSML_ERR_SHAPE, "sgd_momentum: bad args");
-  long b = (n + 255) / 256;
-  k_sgd<<<(int)(b < 4096 ? b : 4096), 256, 0, (hipStream_t)stream>>>(w, grad, mom, n, lr, mu, wd, first_step,
-                                                                    grad_scale);
+  MSML_CHECK(((uintptr_t)w & 15) == 0 && ((uintptr_t)grad & 15) == 0 && ((uintptr_t)mom & 15) == 0,
+             MSML_ERR_SHAPE, "sgd_momentum: buffers must be 16-byte aligned");
+  long n4 = n / 4;
+  long b = (n4 + 255) / 256;
+  if (b < 1) b = 1;
+  k_sgd<<<(int)(b < 4096 ? b : 4096), 256, 0, (hipStream_t)stream>>>(w, grad, mom, n4, n, lr, mu, wd, first_step,
+                                                                    clip_coef);
   MSML_LAUNCH_OK("sgd_momentum");
+  return MSML_OK;
+}
+
+// Global L2 norm of a flat gradient buffer and the clip factor min(1, max_norm / (norm + 1e-6))
+// (torch.nn.utils.clip_grad_norm_, train.py:270,275).  Two-level deterministic reduction.
+__global__ void __launch_bounds__(256) k_sumsq(const float* __restrict__ x, long n, float* __restrict__ partial) {
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    s += v * v;
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void k_norm_finalize(const float* __restrict__ partial, int rows, float max_norm,
+                                float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < rows; i++) s += (double)partial[i];
+    float norm = (float)sqrt(s);
+    out[0] = norm;
+    float c = max_norm / (norm + 1e-6f);
+    out[1] = c < 1.f ? c : 1.f;
+  }
+}
+
+extern "C" int msml_grad_norm_clip(const float* grad, long n, float max_norm, float* out2,
+                                   float* workspace, long ws_floats, void* stream) {
+  MSML_CHECK(grad && out2 && workspace && n > 0, MSML_ERR_SHAPE, "grad_norm_clip: bad args");
+  long b = (n + 255) / 256;
+  int rows = (int)(b < 1024 ? b : 1024);
+  MSML_CHECK(ws_floats >= rows, MSML_ERR_WORKSPACE, "grad_norm_clip: workspace too small");
+  k_sumsq<<<rows, 256, 0, (hipStream_t)stream>>>(grad, n, workspace);
+  MSML_LAUNCH_OK("grad_norm_clip");
+  k_norm_finalize<<<1, 64, 0, (hipStream_t)stream>>>(workspace, rows, max_norm, out2);
+  MSML_LAUNCH_OK("grad_norm_finalize");
   return MSML_OK;
 }

@@ -53,7 +53,7 @@ class _Conv(torch.autograd.Function):
             bp[:cout] = bias.detach()
         y, stats = ops.conv2d(x0, x1, wp, bp, cpad(cout), r, s, cfg["stride"], cfg["pad_h"],
                               cfg["pad_w"], deconv, out_dtype=cfg.get("out_dtype"),
-                              want_stats=cfg.get("want_stats", False))
+                              want_stats=cfg.get("want_stats", False), real=(c0 + c1, cout))
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x0, x1, weight)
@@ -83,11 +83,11 @@ class _Conv(torch.autograd.Function):
             if deconv:      # backward-data of a transposed conv = strided conv of dy
                 wp = ops.pack_weight(ws, False, cout, 0, dtype)
                 grads[i], _ = ops.conv2d(dy, None, wp, None, cpad(ci), r, s, stride, ph, pw, False,
-                                         p=h, q=wd)
+                                         p=h, q=wd, real=(cout, ci))
             else:           # backward-data of a conv = transposed gather of dy
                 wp = ops.pack_weight(ws, True, cout, 0, dtype)
                 grads[i], _ = ops.conv2d(dy, None, wp, None, cpad(ci), r, s, stride, ph, pw, True,
-                                         p=h, q=wd)
+                                         p=h, q=wd, real=(cout, ci))
         dw = None
         if ctx.needs_input_grad[2]:
             dw = torch.empty_like(w)
@@ -129,14 +129,16 @@ class _BnAct(torch.autograd.Function):
             if stats is None:
                 rows = ops.bn_stats_rows(m, c)
                 stats = torch.empty(rows, 2, c, dtype=torch.float32, device=dev)
-                call("msml_bn_stats", x, m, c, stats, dtype)
+                with ops.PROFILE.rec("bn_stats", 0.0, x.numel() * x.element_size()):
+                    call("msml_bn_stats", x, m, c, stats, dtype)
             call("msml_bn_finalize", stats, stats.shape[0], c, float(m), gamma, beta, rmean, rvar,
                  momentum, eps, coef[0], coef[1], coef[2], coef[3])
         else:
             call("msml_bn_finalize", None, 0, c, 0.0, gamma, beta, rmean, rvar, momentum, eps,
                  coef[0], coef[1], coef[2], coef[3])
         y = torch.empty_like(x)
-        call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, int(res_first), y, m, c, dtype)
+        with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
+            call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, int(res_first), y, m, c, dtype)
         ctx.training = training
         ctx.has = (gamma is not None, beta is not None, alpha is not None, residual is not None)
         ctx.res_first = bool(res_first) and residual is not None and alpha is not None
@@ -158,8 +160,9 @@ class _BnAct(torch.autograd.Function):
         need = (rows * 3 * c + 2 * c) * 4
         ws = ops.workspace(need, x.device)
         dres = torch.empty_like(x) if ctx.res_first else None
-        call("msml_bn_act_bwd", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, dx, dres,
-             pg[0], pg[1], pg[2] if alpha is not None else None, m, c, ws, ws.numel() // 4, dtype)
+        with ops.PROFILE.rec("bn_act_bwd", 0.0, x.numel() * x.element_size() * (5 + (3 if ctx.res_first else 0))):
+            call("msml_bn_act_bwd", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, dx, dres,
+                 pg[0], pg[1], pg[2] if alpha is not None else None, m, c, ws, ws.numel() // 4, dtype)
         has_g, has_b, has_a, has_r = ctx.has
         if ctx.res_first:
             dy = dres
@@ -185,7 +188,8 @@ class _FmFuse(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, yf, act, arith):
         z = torch.empty_like(yf)
-        call("msml_fm_fuse_fwd", x, yf, z, x.numel(), act, arith, DTYPE_OF[x.dtype])
+        with ops.PROFILE.rec("fm_fuse_fwd", 0.0, 3 * x.numel() * x.element_size()):
+            call("msml_fm_fuse_fwd", x, yf, z, x.numel(), act, arith, DTYPE_OF[x.dtype])
         ctx.save_for_backward(x, yf)
         ctx.mode = (act, arith)
         return z
@@ -195,8 +199,9 @@ class _FmFuse(torch.autograd.Function):
         x, yf = ctx.saved_tensors
         dz = dz.contiguous()
         dx, dyf = torch.empty_like(x), torch.empty_like(yf)
-        call("msml_fm_fuse_bwd", dz, x, yf, dx, dyf, x.numel(), ctx.mode[0], ctx.mode[1],
-             DTYPE_OF[x.dtype])
+        with ops.PROFILE.rec("fm_fuse_bwd", 0.0, 5 * x.numel() * x.element_size()):
+            call("msml_fm_fuse_bwd", dz, x, yf, dx, dyf, x.numel(), ctx.mode[0], ctx.mode[1],
+                 DTYPE_OF[x.dtype])
         return dx, dyf, None, None
 
 
@@ -404,3 +409,29 @@ class _Linear(torch.autograd.Function):
 
 def linear(emb, weight, bias, dtype):
     return _Linear.apply(emb, weight, bias, dtype)
+
+
+class _Normalize(torch.autograd.Function):
+    """F.normalize(x, dim=1) on (B, E) f32 embeddings (rownorm kernels)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        b, e = x.shape
+        x = x.contiguous().float()
+        y = torch.empty_like(x)
+        inv = torch.empty(b, dtype=torch.float32, device=x.device)
+        call("msml_rownorm_fwd", x, b, b, e, y, e, inv, F32)
+        ctx.save_for_backward(x, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, inv = ctx.saved_tensors
+        b, e = x.shape
+        dx = torch.empty_like(x)
+        call("msml_rownorm_bwd", x, inv, dy.contiguous().float(), e, b, e, dx, 0)
+        return dx
+
+
+def normalize(x):
+    return _Normalize.apply(x)

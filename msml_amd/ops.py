@@ -6,6 +6,56 @@ from . import _lib
 from ._lib import BF16, DTYPE_OF, F32, TORCH_DTYPE, call
 
 
+class _Profile:
+    """Per-kernel-family timing with HIP events on the launch stream (bench.py roofline).
+    Off by default; when on, every instrumented launch is bracketed by an event pair."""
+
+    def __init__(self):
+        self.on = False
+        self.recs = []
+
+    def start(self):
+        self.recs = []
+        self.on = True
+
+    def rec(self, name, flops=0.0, nbytes=0.0):
+        return _Rec(self, name, flops, nbytes)
+
+    def stop(self):
+        self.on = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, nbytes, e0, e1 in self.recs:
+            d = out.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["n"] += 1
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        self.recs = []
+        return out
+
+
+class _Rec:
+    def __init__(self, prof, name, flops, nbytes):
+        self.prof, self.name, self.flops, self.nbytes = prof, name, flops, nbytes
+
+    def __enter__(self):
+        if self.prof.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.prof.on:
+            self.e1.record()
+            self.prof.recs.append((self.name, self.flops, self.nbytes, self.e0, self.e1))
+        return False
+
+
+PROFILE = _Profile()
+
+
 def cpad(c):
     return (c + 7) // 8 * 8
 
@@ -63,7 +113,7 @@ def conv_out_size(h, r, stride, pad, transposed, out_pad=0):
 
 
 def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=None, q=None,
-           out_dtype=None, want_stats=False):
+           out_dtype=None, want_stats=False, real=None):
     """Raw implicit-GEMM conv.  x0/x1: NHWC tensors; returns (out NHWC, stats or None)."""
     n, h, w, c0p = x0.shape
     c1p = x1.shape[3] if x1 is not None else 0
@@ -77,8 +127,12 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
     if want_stats:
         tiles = (n * p * q + tile_m(coutp) - 1) // tile_m(coutp)
         stats = torch.empty(tiles, 2, coutp, dtype=torch.float32, device=x0.device)
-    call("msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats, n, h, w, p, q,
-         r, s, stride, pad_h, pad_w, int(transposed), in_dtype, out_dtype)
+    cin, cout = real if real is not None else (c0p + c1p, coutp)
+    # algorithmic FLOP: 2*N*Cout*P*Q*Cin*R*S, deconv form 2*N*Cin*H*W*Cout*R*S
+    pix = n * h * w if transposed else n * p * q
+    with PROFILE.rec("conv_igemm", 2.0 * pix * cin * cout * r * s):
+        call("msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats, n, h, w, p,
+             q, r, s, stride, pad_h, pad_w, int(transposed), in_dtype, out_dtype)
     return out, stats
 
 
@@ -100,6 +154,7 @@ def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accum
     _, h, w, vp = v.shape
     need = _lib.value("msml_conv_wgrad_workspace", up, vp, n, p, q, r, s)
     ws = workspace(need, u.device)
-    call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
-         pad_h, pad_w, int(accumulate), ws, ws.numel(), DTYPE_OF[u.dtype])
+    with PROFILE.rec("conv_wgrad", 2.0 * n * p * q * a * breal * r * s):
+        call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
+             pad_h, pad_w, int(accumulate), ws, ws.numel(), DTYPE_OF[u.dtype])
     return dw

@@ -1,0 +1,94 @@
+"""Flat-arena SGD with fused gradient clipping (the training glue of train.py:153-196,267-277).
+
+All parameters of a model are re-homed as views into ONE flat f32 buffer per learning-rate
+group, their .grad as views into a matching flat gradient buffer and their momentum likewise,
+so that per step the optimizer is: one L2-norm reduction over the flat gradient
+(clip_grad_norm_(5, 2)) + one fused clip*grad -> weight-decay -> momentum -> update kernel per
+group, with no host synchronisation; DDP reduces the same flat gradient in a few large
+messages (sized for xGMI, not for NVSwitch).  Semantics equal torch.optim.SGD(momentum,
+weight_decay) + torch.nn.utils.clip_grad_norm_.
+"""
+import torch
+import torch.distributed as dist
+
+from ._lib import call
+
+
+def reference_param_groups(model, batch_size, world_size, lr=0.1):
+    """LR groups of the reference (train.py:153-178, conf.pretrained False): parameters whose
+    name contains 'osb' train at 0.01/512*bs*W, everything else at lr/512*bs*W."""
+    base = lr / 512 * batch_size * world_size
+    osb = 0.01 / 512 * batch_size * world_size
+    groups = {"osb": ([], osb), "rest": ([], base)}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        groups["osb" if "osb" in name else "rest"][0].append(p)
+    return [{"params": ps, "lr": glr} for ps, glr in groups.values() if ps]
+
+
+class FlatSGD:
+    def __init__(self, param_groups, momentum=0.9, weight_decay=5e-4, max_norm=5.0):
+        self.momentum, self.weight_decay, self.max_norm = momentum, weight_decay, max_norm
+        self.groups = []
+        params = [p for g in param_groups for p in g["params"]]
+        dev = params[0].device
+        total = sum((p.numel() + 3) // 4 * 4 for p in params)
+        self.flat_w = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self.offsets = {}
+        for g in param_groups:
+            start = off
+            for p in g["params"]:
+                n = p.numel()
+                self.flat_w[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_w[off:off + n].view_as(p.data)
+                p.grad = self.flat_g[off:off + n].view_as(p.data)
+                self.offsets[id(p)] = off
+                off += (n + 3) // 4 * 4
+            self.groups.append({"start": start, "end": off, "lr": g["lr"], "base_lr": g["lr"]})
+        self.params = params
+        self.steps = 0
+        self.norm_coef = torch.ones(2, dtype=torch.float32, device=dev)
+        self.ws = torch.empty(1024, dtype=torch.float32, device=dev)
+
+    def set_lr_factor(self, factor):
+        for g in self.groups:
+            g["lr"] = g["base_lr"] * factor
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        base = self.flat_g.data_ptr()
+        for p in self.params:        # re-attach the views if something replaced .grad
+            off = self.offsets[id(p)]
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                p.grad = self.flat_g[off:off + p.numel()].view_as(p.data)
+
+    def all_reduce_grads(self, world_size, bucket_bytes=64 << 20):
+        """DDP gradient averaging on the flat arena: a few large all-reduces."""
+        if world_size == 1:
+            return
+        n = self.flat_g.numel()
+        step = bucket_bytes // 4
+        for s in range(0, n, step):
+            dist.all_reduce(self.flat_g[s:min(n, s + step)], op=dist.ReduceOp.SUM)
+        self.flat_g.mul_(1.0 / world_size)
+
+    def step(self):
+        n = self.flat_g.numel()
+        clip = None
+        if self.max_norm is not None:
+            call("msml_grad_norm_clip", self.flat_g, n, float(self.max_norm), self.norm_coef, self.ws,
+                 self.ws.numel())
+            clip = self.norm_coef[1:]
+        for g in self.groups:
+            s, e = g["start"], g["end"]
+            call("msml_sgd_momentum", self.flat_w[s:e], self.flat_g[s:e], self.flat_m[s:e], e - s,
+                 float(g["lr"]), float(self.momentum), float(self.weight_decay),
+                 int(self.steps == 0), clip)
+        self.steps += 1
+
+    def grad_norm(self):
+        return self.norm_coef[0]

@@ -162,3 +162,46 @@ def test_train_step_g4(variant):
         if key.startswith("stat/"):
             n = key.split("/", 1)[1]
             assert rel_err(m.state_dict()[n].cpu().numpy(), g[key]) < 1e-3, n
+
+
+def test_partial_fc_w1_g6():
+    """PartialFC.forward_backward on the HIP backend, W = 1, against the reference's golden."""
+    from msml_amd.headers import ArcMargin, PartialFC
+    from oracle.inputs import PFC_B, PFC_C, PFC_E, pfc_inputs
+    g = load("g6_partial_fc.npz")
+    feat, label, w = pfc_inputs(1, 0)
+    p = PartialFC(0, 0, 1, PFC_B, False, ArcMargin(64.0, 0.48, 0.0, 0.0), PFC_C,
+                  embedding_size=PFC_E)
+    with torch.no_grad():
+        p.weight.copy_(w)
+    opt = torch.optim.SGD([{"params": p.parameters()}], lr=0.1 / 512 * PFC_B, momentum=0.9,
+                          weight_decay=5e-4)
+    x_grad, loss_v = p.forward_backward(label.cuda(), feat.cuda(), opt)
+    assert abs(loss_v.item() - g["w1/r0/loss"]) < 1e-4 * abs(g["w1/r0/loss"])
+    assert rel_err(x_grad.cpu().numpy(), g["w1/r0/x_grad"]) < 1e-4
+    assert rel_err(pick(p.sub_weight.grad, 256), g["w1/r0/wgrad_pick"]) < 1e-4
+    opt.step()
+    assert rel_err(pick(p.sub_weight.data, 256), g["w1/r0/wnew_pick"]) < 1e-5
+
+
+def test_flat_sgd_matches_torch():
+    """FlatSGD (fused clip + momentum SGD on the flat arena) == clip_grad_norm_ + torch SGD."""
+    from msml_amd.optim import FlatSGD
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in [(7, 5), (33,), (4, 3, 3, 3)]]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    fo = FlatSGD([{"params": ps[:2], "lr": 0.1}, {"params": ps[2:], "lr": 0.01}], 0.9, 5e-4, 5.0)
+    to = torch.optim.SGD([{"params": qs[:2], "lr": 0.1}, {"params": qs[2:], "lr": 0.01}],
+                         lr=0.1, momentum=0.9, weight_decay=5e-4)
+    for step in range(3):
+        fo.zero_grad()
+        to.zero_grad()
+        gs = [torch.randn_like(p) * 3 for p in ps]
+        for p, q, gr in zip(ps, qs, gs):
+            p.grad.add_(gr)
+            q.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(qs, 5.0, 2)
+        fo.step()
+        to.step()
+        for p, q in zip(ps, qs):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), step
