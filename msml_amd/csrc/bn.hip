@@ -92,22 +92,47 @@ extern "C" int msml_bn_stats(const void* x, long M, int C, float* partial, int d
 // partial: [rows][2][C] (sum, sumsq).  rows == 0 -> eval mode: coefficients from running stats.
 // Training also updates the running statistics exactly like nn.BatchNorm (momentum, unbiased
 // variance) and stores mean / invstd for the backward.
-__global__ void k_bn_finalize(const float* __restrict__ partial, int rows, int C, double count,
+// One workgroup per 32 channels: 32 row-lanes x 32 channels, f64 accumulation, fixed-order
+// LDS tree (deterministic).  Rows go up to M/128 (6272 at 64x112x112, batch 256).
+#define FIN_LANES 32
+template <int NQ>
+__device__ __forceinline__ void fin_reduce(const float* __restrict__ partial, int rows, int C, int c,
+                                           bool cok, double (&out)[NQ]) {
+  __shared__ double red[FIN_LANES][NQ][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+  if (cok)
+    for (int r = ry; r < rows; r += FIN_LANES)
+#pragma unroll
+      for (int q = 0; q < NQ; q++) acc[q] += (double)partial[((long)r * NQ + q) * C + c];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) red[ry][q][cx] = acc[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    double s = 0.0;
+    if (ry == 0)
+      for (int y = 0; y < FIN_LANES; y++) s += red[y][q][cx];
+    out[q] = s;
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_bn_finalize(const float* __restrict__ partial, int rows, int C, double count,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                               float eps, float* __restrict__ scale, float* __restrict__ shift,
                               float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float mean, invstd;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool cok = c < C;
+  float mean = 0.f, invstd = 1.f;
   if (rows > 0) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < rows; r++) {
-      s1 += (double)partial[((long)r * 2 + 0) * C + c];
-      s2 += (double)partial[((long)r * 2 + 1) * C + c];
-    }
-    double m = s1 / count;
-    double var = s2 / count - m * m;
+    double s[2];
+    fin_reduce<2>(partial, rows, C, c, cok, s);
+    if (threadIdx.x >= 32 || !cok) return;
+    double m = s[0] / count;
+    double var = s[1] / count - m * m;
     if (var < 0.0) var = 0.0;
     mean = (float)m;
     invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -117,6 +142,7 @@ __global__ void k_bn_finalize(const float* __restrict__ partial, int rows, int C
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
     }
   } else {
+    if (threadIdx.x >= 32 || !cok) return;
     mean = rmean[c];
     invstd = 1.0f / sqrtf(rvar[c] + eps);
   }
@@ -136,7 +162,7 @@ extern "C" int msml_bn_finalize(const float* partial, int rows, int C, double co
   MSML_CHECK(C > 0 && scale && shift && rows >= 0, MSML_ERR_SHAPE, "bn_finalize: bad args");
   MSML_CHECK(rows > 0 ? (partial && count > 0) : (running_mean && running_var), MSML_ERR_SHAPE,
              "bn_finalize: train needs partials, eval needs running stats");
-  k_bn_finalize<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(
+  k_bn_finalize<<<cdiv(C, 32), 1024, 0, (hipStream_t)stream>>>(
       partial, rows, C, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
       save_mean, save_invstd);
   MSML_LAUNCH_OK("bn_finalize");
@@ -145,23 +171,43 @@ extern "C" int msml_bn_finalize(const float* partial, int rows, int C, double co
 
 // ------------------------------------------------------------------ apply (forward) ----------
 // y = prelu(x * scale[c] + shift[c]) + residual      (alpha == null: no PReLU; residual optional)
+// The grid is sized so that (threads in grid) % (C/8) == 0: a thread's 8-channel chunk is then
+// loop-invariant and its coefficients live in registers (one load each, not one per pixel).
+struct Coef8 {
+  float v[8];
+};
+__device__ __forceinline__ Coef8 ldc8(const float* p, int c0, float dflt) {
+  Coef8 r;
+  if (p) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p + c0);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + c0 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { r.v[i] = a[i]; r.v[4 + i] = b[i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = dflt;
+  }
+  return r;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_bn_act_fwd(const T* __restrict__ x, const float* __restrict__ scale,
                                                     const float* __restrict__ shift,
                                                     const float* __restrict__ alpha,
                                                     const T* __restrict__ residual, int res_first,
                                                     T* __restrict__ y, long n8, int C8) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % C8) * 8;
+  const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int c0 = (int)(tid % C8) * 8;
+  const Coef8 sc = ldc8(scale, c0, 1.f), sh = ldc8(shift, c0, 0.f), al = ldc8(alpha, c0, 1.f);
+  for (long i = tid; i < n8; i += (long)gridDim.x * blockDim.x) {
     Vec8 v = load8<T>(x + i * 8);
     Vec8 r;
     if (residual) r = load8<T>(residual + i * 8);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      float z = v.v[j] * scale[c0 + j] + shift[c0 + j];
+      float z = v.v[j] * sc.v[j] + sh.v[j];
       if (residual && res_first) z += r.v[j];
-      if (alpha) z = z > 0.f ? z : z * alpha[c0 + j];
+      if (alpha) z = z > 0.f ? z : z * al.v[j];
       if (residual && !res_first) z += r.v[j];
       v.v[j] = z;
     }
@@ -173,15 +219,26 @@ static inline int ew_grid(long n8) {
   long b = (n8 + 255) / 256;
   return (int)(b < 2048 ? b : 2048);
 }
+// grid whose total thread count is a multiple of C8 (C8 <= 256 or a multiple of 256)
+static inline int ew_grid_c(long n8, int C8) {
+  int g = ew_grid(n8);
+  if (C8 > 256) {
+    int m = C8 / 256;
+    g = (g + m - 1) / m * m;
+  }
+  return g;
+}
 
 extern "C" int msml_bn_act_fwd(const void* x, const float* scale, const float* shift,
                                const float* alpha, const void* residual, int res_first, void* y,
                                long M, int C, int dtype, void* stream) {
   MSML_CHECK(x && y && scale && shift && M > 0 && C > 0 && C % 8 == 0, MSML_ERR_SHAPE,
              "bn_act_fwd: bad shape M=%ld C=%d", M, C);
+  MSML_CHECK(256 % (C / 8) == 0 || (C / 8) % 256 == 0, MSML_ERR_UNSUPPORTED,
+             "bn_act_fwd: C/8 = %d must divide 256 or be a multiple of it", C / 8);
   long n8 = M * (C / 8);
   MSML_DISPATCH_DTYPE(dtype, "bn_act_fwd",
-                      k_bn_act_fwd<DT><<<ew_grid(n8), 256, 0, (hipStream_t)stream>>>(
+                      k_bn_act_fwd<DT><<<ew_grid_c(n8, C / 8), 256, 0, (hipStream_t)stream>>>(
                           (const DT*)x, scale, shift, alpha, (const DT*)residual, res_first, (DT*)y, n8,
                           C / 8);)
   MSML_LAUNCH_OK("bn_act_fwd");
@@ -201,6 +258,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy,
                                                        const float* __restrict__ invstd,
                                                        const T* __restrict__ res, long M, int C,
                                                        float* __restrict__ partial) {
+  const int c0h = (threadIdx.x % (C / 8)) * 8;
+  const Coef8 sc = ldc8(scale, c0h, 1.f), sh = ldc8(shift, c0h, 0.f), al = ldc8(alpha, c0h, 1.f);
+  const Coef8 mu = ldc8(mean, c0h, 0.f), is = ldc8(invstd, c0h, 1.f);
   slab_reduce<3>(M, C, partial, [&](long pix, int c8, float(&q)[3][8]) {
     Vec8 g = load8<T>(dy + pix * C + c8 * 8);
     Vec8 v = load8<T>(x + pix * C + c8 * 8);
@@ -208,39 +268,35 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy,
     if (res) rr = load8<T>(res + pix * C + c8 * 8);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      int c = c8 * 8 + j;
       float gg = g.v[j];
       if (alpha) {
-        float z = v.v[j] * scale[c] + shift[c];
+        float z = v.v[j] * sc.v[j] + sh.v[j];
         if (res) z += rr.v[j];
         if (z <= 0.f) {
           q[2][j] += gg * z;
-          gg *= alpha[c];
+          gg *= al.v[j];
         }
       }
-      float xh = (v.v[j] - mean[c]) * invstd[c];
+      float xh = (v.v[j] - mu.v[j]) * is.v[j];
       q[0][j] += gg;
       q[1][j] += gg * xh;
     }
   });
 }
 
-__global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int rows, int C, double count,
+__global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restrict__ partial, int rows, int C, double count,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   float* __restrict__ dalpha, float* __restrict__ coef) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  for (int r = 0; r < rows; r++) {
-    s1 += (double)partial[((long)r * 3 + 0) * C + c];
-    s2 += (double)partial[((long)r * 3 + 1) * C + c];
-    s3 += (double)partial[((long)r * 3 + 2) * C + c];
-  }
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  if (dalpha) dalpha[c] = (float)s3;
-  coef[c] = (float)(s1 / count);
-  coef[C + c] = (float)(s2 / count);
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool cok = c < C;
+  double s[3];
+  fin_reduce<3>(partial, rows, C, c, cok, s);
+  if (threadIdx.x >= 32 || !cok) return;
+  if (dbeta) dbeta[c] = (float)s[0];
+  if (dgamma) dgamma[c] = (float)s[1];
+  if (dalpha) dalpha[c] = (float)s[2];
+  coef[c] = (float)(s[0] / count);
+  coef[C + c] = (float)(s[1] / count);
 }
 
 template <typename T>
@@ -254,25 +310,27 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
                                                       const T* __restrict__ res, T* __restrict__ dx,
                                                       T* __restrict__ dres, long n8, int C8) {
   const int C = C8 * 8;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % C8) * 8;
+  const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int c0 = (int)(tid % C8) * 8;
+  const Coef8 sc = ldc8(scale, c0, 1.f), sh = ldc8(shift, c0, 0.f), al = ldc8(alpha, c0, 1.f);
+  const Coef8 mu = ldc8(mean, c0, 0.f), is = ldc8(invstd, c0, 1.f);
+  const Coef8 k1 = ldc8(coef, c0, 0.f), k2 = ldc8(coef + C, c0, 0.f);
+  for (long i = tid; i < n8; i += (long)gridDim.x * blockDim.x) {
     Vec8 g = load8<T>(dy + i * 8);
     Vec8 v = load8<T>(x + i * 8);
     Vec8 rr;
     if (res) rr = load8<T>(res + i * 8);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      int c = c0 + j;
       float gg = g.v[j];
       if (alpha) {
-        float z = v.v[j] * scale[c] + shift[c];
+        float z = v.v[j] * sc.v[j] + sh.v[j];
         if (res) z += rr.v[j];
-        if (z <= 0.f) gg *= alpha[c];
+        if (z <= 0.f) gg *= al.v[j];
       }
-      float xh = (v.v[j] - mean[c]) * invstd[c];
+      float xh = (v.v[j] - mu.v[j]) * is.v[j];
       // scale[c] == gamma * invstd
-      v.v[j] = scale[c] * (gg - coef[c] - xh * coef[C + c]);
+      v.v[j] = sc.v[j] * (gg - k1.v[j] - xh * k2.v[j]);
       g.v[j] = gg;
     }
     store8<T>(dx + i * 8, v);
@@ -301,9 +359,9 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
                                                             alpha, save_mean, save_invstd,
                                                             (const DT*)residual_first, M, C, partial);
       MSML_LAUNCH_OK("bn_bwd_reduce");
-      k_bn_bwd_finalize<<<cdiv(C, 128), 128, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef);
+      k_bn_bwd_finalize<<<cdiv(C, 32), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef);
       MSML_LAUNCH_OK("bn_bwd_finalize");
-      k_bn_bwd_apply<DT><<<ew_grid(n8), 256, 0, st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
+      k_bn_bwd_apply<DT><<<ew_grid_c(n8, C / 8), 256, 0, st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
                                                      save_mean, save_invstd, coef, (const DT*)residual_first,
                                                      (DT*)dx, (DT*)dres, n8, C / 8);)
   MSML_LAUNCH_OK("bn_bwd_apply");
