@@ -18,6 +18,8 @@
 // both the ds_write_b128 staging and the ds_read_b128 fragment reads are conflict-free).
 // Pixels are the MFMA row dimension, so an accumulator register's 32 lanes hold 32 consecutive
 // output channels of one pixel: stores are 64-128 B contiguous per pixel row.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct ConvArgs {
@@ -304,6 +306,12 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
   return 0;
 }
 
+bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp,
+                             const float* bias, void* out, int coutp, float* stats, int N, int H,
+                             int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
+                             int transposed, int in_dtype, int out_dtype, int bm, int bn,
+                             hipStream_t st);
+
 extern "C" int msml_conv_tile_m(int coutp) { return coutp <= 64 ? 256 : 128; }
 extern "C" int msml_conv_tile_n(int coutp) { return coutp <= 32 ? 32 : (coutp <= 64 ? 64 : 128); }
 
@@ -345,6 +353,13 @@ extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, c
   MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE,
              "conv2d: packed weight has %d rows, need %d", kop, cdiv(coutp, bn) * bn);
   hipStream_t st = (hipStream_t)stream;
+  if ((out_dtype == MSML_BF16 || out_dtype == MSML_F32) && !getenv("MSML_NO_FAST_CONV") &&
+      msml_conv_fast_dispatch(in0, c0p, in1, c1p, wp, bias, out, coutp, stats, N, H, W, P, Q, R, S,
+                              stride, pad_h, pad_w, transposed, in_dtype, out_dtype,
+                              msml_conv_tile_m(coutp), bn, st)) {
+    MSML_LAUNCH_OK("conv2d(fast)");
+    return MSML_OK;
+  }
 #define CONV_CASE(TI, TO)                                                          \
   if (bn == 128) launch<TI, TO, 128, 128, 2, 2>(a, st);                            \
   else if (bn == 64) launch<TI, TO, 256, 64, 4, 1>(a, st);                         \

@@ -109,6 +109,26 @@ def test_deconv_fwd(shape, dtype, tol):
 
 
 @pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("shape", [(64, 128, 14), (128, 64, 9), (256, 256, 7), (32, 32, 12)])
+def test_conv_dgrad_bf16(stride, shape):
+    """bf16 backward-data (fast path, transposed gather) against f64 autograd on the same
+    bf16-rounded operands."""
+    cin, cout, h = shape
+    g = torch.Generator().manual_seed(11)
+    n = 3
+    x = torch.randn(n, cin, h, h, generator=g, dtype=torch.double, requires_grad=True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).bfloat16().double()
+    y = F.conv2d(x, w, None, stride, 1)
+    dy = torch.randn(y.shape, generator=g).bfloat16().double()
+    y.backward(dy)
+    wp = ops.pack_weight(w.float().cuda(), True, cout, 0, _lib.BF16)
+    dyd = ops.to_nhwc(dy.float().cuda(), _lib.BF16)
+    dx, _ = ops.conv2d(dyd, None, wp, None, cin, 3, 3, stride, 1, 1, True, p=h, q=h)
+    got = ops.to_nchw(dx, cin).cpu().double()
+    assert (got - x.grad).abs().max().item() <= 1e-2 * x.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("stride", [1, 2])
 def test_conv_dgrad_matches_autograd(stride):
     """conv backward-data == transposed gather with the (ko=cin, ci=cout) packing."""
     g = torch.Generator().manual_seed(9)
