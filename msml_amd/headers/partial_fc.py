@@ -153,9 +153,11 @@ class PartialFC(Module):
 
     @torch.no_grad()
     def sample(self, total_label):
+        # in place like the reference (partial_fc.py:78-81) but without boolean-mask indexing,
+        # which would synchronise with the host (and cannot be captured into a hipGraph)
         index_positive = (self.class_start <= total_label) & (total_label < self.class_start + self.num_local)
-        total_label[~index_positive] = -1
-        total_label[index_positive] -= self.class_start
+        total_label.copy_(torch.where(index_positive, total_label - self.class_start,
+                                      torch.full_like(total_label, -1)))
 
     def _all_gather(self, x):
         if self.world_size == 1:
