@@ -12,7 +12,8 @@
  *     immediately: 0 on success, a negative MSML_ERR_* otherwise; the message is available
  *     from msml_last_error() (thread-local).  No C++ exception crosses the ABI.
  *   - activations are NHWC ("pixel-major"): [N][H][W][Cp], Cp = channel count rounded up to a
- *     multiple of 8; pad channels hold exact zeros.  `dtype` selects the STORAGE type of
+ *     multiple of 8 (the Python host uses 8 or a multiple of 32, which selects the LDS-DMA
+ *     fast conv path); pad channels hold exact zeros.  `dtype` selects the STORAGE type of
  *     activations / packed weights: MSML_F32 (exact-f32 MFMA path, parity mode) or MSML_BF16
  *     (bf16 operands, f32 accumulate).  Parameters, statistics and gradients of parameters
  *     are always f32 in the reference's own layouts (OIHW etc.).

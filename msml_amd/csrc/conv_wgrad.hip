@@ -18,6 +18,8 @@
 // from LDS with the gfx950 transposing read ds_read_b64_tr_b16 (rows = pixels, 16-channel
 // blocks); LDS rows are padded to a pitch == 64 (mod 256) bytes so the four pixel rows of a
 // block fall in disjoint bank windows.  f32 fragments are plain ds_read_b32 (one k per lane).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -237,8 +239,10 @@ static int pick_tile(int c) { return c > 64 ? 128 : 64; }
 
 // number of pixel splits: enough workgroups to fill 256 CUs a few times over, chunks >= 256 px
 static int pick_splits(long mpix, int out_tiles) {
-  long want = (1024 + out_tiles - 1) / out_tiles;
-  long max_by_chunk = (mpix + 255) / 256;
+  static const long target = getenv("MSML_WGRAD_WGS") ? atol(getenv("MSML_WGRAD_WGS")) : 1024;
+  static const long minchunk = getenv("MSML_WGRAD_MINCHUNK") ? atol(getenv("MSML_WGRAD_MINCHUNK")) : 256;
+  long want = (target + out_tiles - 1) / out_tiles;
+  long max_by_chunk = (mpix + minchunk - 1) / minchunk;
   long s = want < max_by_chunk ? want : max_by_chunk;
   if (s < 1) s = 1;
   if (s > 512) s = 512;
@@ -282,6 +286,7 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   a.chunk = (int)(((a.Mpix + splits - 1) / splits + 31) / 32 * 32);
   dim3 grid(atiles, btiles * taps, splits);
   hipStream_t st = (hipStream_t)stream;
+
 #define WG_LAUNCH(T, BA_, BB_)                                                    \
   {                                                                               \
     typedef WTile<T, BA_, BB_> WT_;                                               \

@@ -57,7 +57,10 @@ PROFILE = _Profile()
 
 
 def cpad(c):
-    return (c + 7) // 8 * 8
+    """Storage channel count: 8 for tiny tensors (RGB input, gcm1's 8 maps), otherwise a
+    multiple of 32 so that every conv over the tensor takes the LDS-DMA fast path
+    (conv_fast.hip needs Cp % 32 == 0); pad channels hold exact zeros."""
+    return 8 if c <= 8 else (c + 31) // 32 * 32
 
 
 def kpad(k):
