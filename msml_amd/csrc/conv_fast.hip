@@ -1,29 +1,35 @@
 // Fast path of the implicit-GEMM convolution for bf16 tensors whose input segments all have
-// Cp % 32 == 0 (every 3x3 / 1x1 conv of the FRB, OSB encoder and FM operators except the
-// 3-channel stems and the 18-channel seg segments).  Same math and ABI as conv_igemm.hip
-// (k_conv_igemm is the general kernel and the f32 parity path); differences:
-//   * K-stage of 64 (two 32-channel sub-steps) per barrier: 16 MFMAs per wave per barrier,
-//   * a sub-step is (tap, 32-channel block), so a thread's gather address is
-//     pixel_base(tap) + const: no per-chunk div/mod and no tap crossing inside a chunk row,
+// Cp % 32 == 0 (every conv of the FRB, OSB and FM operators except the 3-channel stems and
+// gcm1's 8-channel maps).  Same math and ABI as conv_igemm.hip (k_conv_igemm stays the general
+// kernel and the exact-f32 parity path).  What makes it fast on gfx950:
+//   * tiles go HBM/L2 -> LDS directly by LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B per lane):
+//     no VGPR staging and no ds_write pass (the LDS store path, ~79 B/clk/CU, was the
+//     co-bottleneck of the register-staged version).  A DMA wave-instruction writes 64 x 16 B
+//     linearly, so the XOR swizzle is applied to the per-lane SOURCE chunk and again on the
+//     ds_read_b128 fragment read (cdna_hip_programming.md rule 21),
+//   * buffer addressing: 32-bit offsets against a wave-uniform descriptor, and an out-of-range
+//     offset makes the DMA write ZEROS (verified on MI355X) -- conv padding, the zero-dilated
+//     taps of a transposed gather and dead lanes cost one v_cndmask, no zero page, no 64-bit math,
+//   * a K stage is 64 = two (tap, 32-channel) sub-steps, so a lane's gather offset is
+//     (row_pixel + tap_delta) * Cp + const,
+//   * fragment addresses are four per-lane LDS offsets + immediates (PMC: the first LDS-DMA
+//     version issued 9.4 VALU per MFMA, mostly address arithmetic),
 //   * XCD-aware tile order (neighbouring pixel tiles share halo rows in one XCD's L2),
-//   * tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 16 B per lane): no VGPR staging
-//     and no ds_write pass (the LDS store path, ~79 B/clk/CU, was the co-bottleneck of the
-//     register-staged version).  An LDS-DMA wave-instruction writes 64 x 16 B linearly, so
-//     the XOR swizzle is applied to the per-lane SOURCE chunk and again on the fragment read
-//     (cdna_hip_programming.md rule 21); out-of-image taps read a zero page,
-//   * bf16 results are transposed through LDS and stored as 16-B rows (not 2-B scalars).
-#include "common.h"
+//   * bf16 results are transposed through LDS and stored as 16-B row chunks.
+#include <stdlib.h>
 
-__device__ unsigned int g_zero_page[64];     // 256 B of zeros: source of padded / dead lanes
+#include "common.h"
 
 struct ConvFastArgs {
   const unsigned short* in[2];
+  unsigned int in_bytes[2];
   int cp[2];          // channels per segment (multiple of 32)
-  int nsub[2];        // sub-steps per segment = R*S*cp/32
+  int nsub[2];        // sub-steps per segment = R*S*cp/32 (nsub[0] even when nseg == 2)
   int nseg;
   int N, H, W, P, Q;
   int R, S, stride_shift, stride, pad_h, pad_w, transposed;
   const unsigned short* wp;
+  unsigned int w_bytes;
   int Ktot;
   void* out;
   int coutp;
@@ -33,20 +39,31 @@ struct ConvFastArgs {
   int tiles_m;
 };
 
+#define OOB_OFFSET 0x7ffffff0u      // beyond any descriptor range: the DMA writes zeros
+
 __device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }   // 128-B rows
 
-template <typename TOUT, int BM, int BN, int WGM, int WGN>
-__global__ void __launch_bounds__(256) k_conv_fast(const ConvFastArgs p) {
-  constexpr int NA = BM / 32, NB = BN >= 32 ? BN / 32 : 1;     // rows per thread (8 chunks/row)
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// NST = 2: double buffer, loads of stage s+1 overlap the MFMAs of stage s, __syncthreads().
+// NST = 3: ring with TWO stages in flight across the barrier: counted `s_waitcnt vmcnt(L)` (L =
+//          DMA instructions per thread per stage) + raw s_barrier, never vmcnt(0) in the loop
+//          (cdna_hip_programming.md "Pipelining across barriers").
+template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST>
+__global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in the device pass only
+  constexpr int NW = WGM * WGN, NT = NW * 64, RPP = NW * 8;    // waves, threads, rows per pass
+  constexpr int NA = BM / RPP, NB = BN / RPP;                  // DMA instructions per thread
   constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 32, TN = WTN / 32;
-  static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "tile config");
+  static_assert(NA >= 1 && NB >= 1 && TM >= 1 && TN >= 1 && (NST == 2 || NST == 3), "tile config");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  u32x4* As = reinterpret_cast<u32x4*>(smem);          // [2][BM][8]
-  u32x4* Bs = As + 2 * BM * 8;                         // [2][BN][8]
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128;  // one stage of A / of B
+  char* As = smem;                                     // [NST][BM][128 B]
+  char* Bs = smem + NST * ABYTES;                      // [NST][BN][128 B]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int row0 = t >> 3;                             // 32 rows per pass, lane l -> LDS slot l
+  const int row0 = t >> 3;                             // RPP rows per pass, lane l -> LDS slot l
   const int chunk = (t & 7) ^ swz128(row0);            // logical 16-B chunk this lane fetches
   const int sub = chunk >> 2, cc = chunk & 3;
 
@@ -58,105 +75,105 @@ __global__ void __launch_bounds__(256) k_conv_fast(const ConvFastArgs p) {
   }
   const long m0 = (long)bid * BM;
   const int n0 = blockIdx.y * BN;
+  const int taps = p.R * p.S;
 
-  int pb[NA], y0[NA], x0[NA];
+  // per staged row: pixel index of the window origin and the origin coordinates
+  int rowpix[NA], y0[NA], x0[NA];
   const int PQ = p.P * p.Q;
 #pragma unroll
   for (int i = 0; i < NA; i++) {
-    long m = m0 + row0 + i * 32;
-    bool ok = m < p.M;
+    long m = m0 + row0 + i * RPP;
+    const bool ok = m < p.M;
     int mm = ok ? (int)m : 0;
     int n = mm / PQ;
     int rem = mm - n * PQ;
     int oy = rem / p.Q, ox = rem - oy * p.Q;
-    pb[i] = n * p.H * p.W;
+    const int pb = n * p.H * p.W;
     if (p.transposed) {
       y0[i] = oy + p.pad_h;
       x0[i] = ox + p.pad_w;
+      rowpix[i] = pb;
     } else {
       y0[i] = oy * p.stride - p.pad_h;
       x0[i] = ox * p.stride - p.pad_w;
+      rowpix[i] = pb + y0[i] * p.W + x0[i];
     }
     if (!ok) y0[i] = -(1 << 20);                       // forces every tap out of range
   }
-  const unsigned short* wrow = p.wp + (long)(n0 + row0) * p.Ktot + cc * 8;
 
-  // this thread's sub-step stream: q = sub, sub + 2, ...
-  int seg = 0, r = 0, s = 0, c32 = sub, qglob = sub;
-  int nc32 = p.cp[0] >> 5;
-  int seg_left = p.nsub[0];                            // sub-steps left in the current segment
-  bool alive = true;
-  const unsigned short* inp = p.in[0];
-  int cpseg = p.cp[0];
-  auto settle = [&]() {                                // normalise (c32, s, r, seg) after a jump
-    while (alive) {
-      while (c32 >= nc32 && r < p.R) {
-        c32 -= nc32;
-        if (++s == p.S) { s = 0; ++r; }
-      }
-      if (r < p.R) break;
-      if (seg + 1 < p.nseg) {                          // carry the overshoot into the next segment
-        seg++;
-        r = 0; s = 0;
-        nc32 = p.cp[seg] >> 5;
-        cpseg = p.cp[seg];
-        inp = p.in[seg];
-      } else {
-        alive = false;
-      }
-    }
-  };
-  (void)seg_left;
-  settle();
+  __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in[0], 0, (int)p.in_bytes[0], 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.nseg > 1 ? p.in[1] : p.in[0]), 0,
+                                                                    (int)(p.nseg > 1 ? p.in_bytes[1] : p.in_bytes[0]), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.w_bytes, 0x00020000);
+  // byte offset of this lane's weight row / chunk
+  const unsigned int wbase = (unsigned int)((n0 + row0) * p.Ktot + cc * 8) * 2u;
+  const unsigned int wstep = (unsigned int)(RPP * p.Ktot) * 2u;
+
+  // this thread's sub-step stream inside the current segment: q = sub, sub + 2, ...
+  int r = 0, s = 0, tap = 0, c32 = sub;
+  int nc32 = p.cp[0] >> 5, cp2 = p.cp[0] * 2;          // channel blocks, bytes per pixel
   const int qtot = p.nsub[0] + (p.nseg > 1 ? p.nsub[1] : 0);
   const int stages = (qtot + 1) >> 1;
+  const int seg0_stages = p.nseg > 1 ? (p.nsub[0] >> 1) : stages;   // uniform segment switch
+  auto settle = [&]() {
+    while (c32 >= nc32) {
+      c32 -= nc32;
+      ++tap;
+      if (++s == p.S) { s = 0; ++r; }
+    }
+  };
+  settle();
 
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page);
-  // issue the LDS-DMA loads of the current sub-step state into stage buffer `buf`
-  auto gissue = [&](int buf) {
-    char* a = reinterpret_cast<char*>(As + buf * BM * 8) + wave * 1024;
-    char* b = reinterpret_cast<char*>(Bs + buf * BN * 8) + wave * 1024;
-    // all source addresses first (distinct registers), then the DMA issues back to back:
-    // hipcc waits vmcnt(0) before it overwrites the address VGPRs of an in-flight LDS-DMA
-    const unsigned short* sa[NA];
-    const unsigned short* sb[NB];
-    const long coff = (long)(c32 << 5) + cc * 8;
+  // issue the LDS-DMA loads of stage `st` (this thread's current sub-step state) into `buf`
+  auto gissue = [&](int st, int buf) {
+    char* a = As + buf * ABYTES + wave * 1024;
+    char* b = Bs + buf * BBYTES + wave * 1024;
+    const bool alive = 2 * st + sub < qtot && tap < taps;
+    const unsigned int coff = (unsigned int)((c32 << 5) + cc * 8) * 2u;
+    unsigned int oa[NA], ob[NB];
+    if (p.transposed) {
 #pragma unroll
-    for (int i = 0; i < NA; i++) {
-      int iy, ix;
-      bool ok = alive;
-      if (p.transposed) {
-        int ty = y0[i] - r, tx = x0[i] - s;
-        ok = ok & (ty >= 0) & (tx >= 0) & (((ty | tx) & (p.stride - 1)) == 0);
-        iy = ty >> p.stride_shift;
-        ix = tx >> p.stride_shift;
-        ok = ok & (iy < p.H) & (ix < p.W);
-      } else {
-        iy = y0[i] + r;
-        ix = x0[i] + s;
-        ok = ok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      for (int i = 0; i < NA; i++) {
+        const int ty = y0[i] - r, tx = x0[i] - s;
+        const int iy = ty >> p.stride_shift, ix = tx >> p.stride_shift;
+        const bool v = alive & ((ty | tx) >= 0) & (((ty | tx) & (p.stride - 1)) == 0) & (iy < p.H) & (ix < p.W);
+        const unsigned int off = (unsigned int)(rowpix[i] + iy * p.W + ix) * (unsigned int)cp2 + coff;
+        oa[i] = v ? off : OOB_OFFSET;
       }
-      const unsigned short* src = inp + ((long)(pb[i] + iy * p.W + ix) * cpseg + coff);
-      sa[i] = ok ? src : zero;
-    }
+    } else {
+      const int dpix = r * p.W + s;
 #pragma unroll
-    for (int i = 0; i < NB; i++) {
-      const unsigned short* src = wrow + (long)i * 32 * p.Ktot + (long)qglob * 32;
-      sb[i] = alive ? src : zero;
+      for (int i = 0; i < NA; i++) {
+        const bool v = alive & ((unsigned)(y0[i] + r) < (unsigned)p.H) & ((unsigned)(x0[i] + s) < (unsigned)p.W);
+        const unsigned int off = (unsigned int)(rowpix[i] + dpix) * (unsigned int)cp2 + coff;
+        oa[i] = v ? off : OOB_OFFSET;
+      }
     }
+    const unsigned int wq = wbase + (unsigned int)(2 * st + sub) * 64u;
 #pragma unroll
-    for (int i = 0; i < NA; i++)
-      __builtin_amdgcn_global_load_lds((gptr_t)sa[i], (lptr_t)(a + i * 4096), 16, 0, 0);
+    for (int i = 0; i < NB; i++) ob[i] = alive ? wq + i * wstep : OOB_OFFSET;
+    if (st < seg0_stages) {
+#pragma unroll
+      for (int i = 0; i < NA; i++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in0, (lptr_t)(a + i * NW * 1024), 16, oa[i], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; i++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in1, (lptr_t)(a + i * NW * 1024), 16, oa[i], 0, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < NB; i++)
-      __builtin_amdgcn_global_load_lds((gptr_t)sb[i], (lptr_t)(b + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(b + i * NW * 1024), 16, ob[i], 0, 0, 0);
   };
-  auto advance = [&]() {
-    c32 += 2;
-    qglob += 2;
-    if (qglob >= qtot) alive = false;
+  // move this thread's state from stage st to stage st + 1
+  auto advance = [&](int st) {
+    if (st + 1 == seg0_stages && p.nseg > 1) {         // (uniform) first stage of segment 1
+      r = 0; s = 0; tap = 0; c32 = sub;
+      nc32 = p.cp[1] >> 5;
+      cp2 = p.cp[1] * 2;
+    } else {
+      c32 += 2;
+    }
     settle();
   };
 
@@ -171,32 +188,25 @@ __global__ void __launch_bounds__(256) k_conv_fast(const ConvFastArgs p) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int arow0 = wm * WTM, brow0 = wn * WTN;
   const int r32 = lane & 31, h = lane >> 5;
+  // fragment offsets: row (arow0 + r32), 16-B chunk ((2 kk + h) ^ swz); rows + 32 i keep the same
+  // swizzle (32 >> 1 == 0 mod 8), so tiles i / j and the stage buffer are immediates
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    aoff[kk] = (arow0 + r32) * 128 + (((kk * 2 + h) ^ swz128(arow0 + r32)) << 4);
+    boff[kk] = (brow0 + r32) * 128 + (((kk * 2 + h) ^ swz128(brow0 + r32)) << 4);
+  }
 
-  if (qglob >= qtot) alive = false;
-  gissue(0);
-  __syncthreads();                                     // (hipcc drains vmcnt before the barrier)
-  int cur = 0;
-  for (int st = 0; st < stages; st++) {
-    const bool more = st + 1 < stages;
-    if (more) {
-      advance();
-      gissue(cur ^ 1);
-    }
-    const u32x4* A = As + cur * BM * 8;
-    const u32x4* B = Bs + cur * BN * 8;
+  auto compute = [&](int buf) {
+    const char* A = As + buf * ABYTES;
+    const char* B = Bs + buf * BBYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {                   // 4 x 16 k per 64-wide stage
       u32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; i++) {
-        int row = arow0 + i * 32 + r32;
-        a[i] = A[row * 8 + ((kk * 2 + h) ^ swz128(row))];
-      }
+      for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const u32x4*>(A + aoff[kk] + i * 4096);
 #pragma unroll
-      for (int j = 0; j < TN; j++) {
-        int row = brow0 + j * 32 + r32;
-        b[j] = B[row * 8 + ((kk * 2 + h) ^ swz128(row))];
-      }
+      for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const u32x4*>(B + boff[kk] + j * 4096);
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -204,8 +214,42 @@ __global__ void __launch_bounds__(256) k_conv_fast(const ConvFastArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
               __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
     }
+  };
+
+  if constexpr (NST == 2) {
+    gissue(0, 0);
+    __syncthreads();                                   // (hipcc drains vmcnt before the barrier)
+    int cur = 0;
+    for (int st = 0; st < stages; st++) {
+      if (st + 1 < stages) {
+        advance(st);
+        gissue(st + 1, cur ^ 1);
+      }
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    constexpr int L = NA + NB;                         // DMA instructions per thread per stage
+    gissue(0, 0);
+    if (stages > 1) {
+      advance(0);
+      gissue(1, 1);
+    }
+    int cur = 0, nxt = 2;                              // buffer of stage st, of stage st + 2
+    for (int st = 0; st < stages; st++) {
+      if (st + 1 < stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // stage st landed for all waves; buffer
+      if (st + 2 < stages) {                           // `nxt` (read in st-1) is free again
+        advance(st + 1);
+        gissue(st + 2, nxt);
+      }
+      compute(cur);
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt = nxt == 2 ? 0 : nxt + 1;
+    }
     __syncthreads();
-    cur ^= 1;
   }
 
   // ---------------- epilogue (same contract as k_conv_igemm) -----------------------------------
@@ -244,7 +288,7 @@ __global__ void __launch_bounds__(256) k_conv_fast(const ConvFastArgs p) {
   if (VIA_LDS) {
     __syncthreads();
     constexpr int C8 = BN / 8;
-    for (int idx = t; idx < BM * C8; idx += 256) {
+    for (int idx = t; idx < BM * C8; idx += NT) {
       int row = idx / C8, c8 = idx % C8;
       long m = m0 + row;
       int col = n0 + c8 * 8;
@@ -267,32 +311,39 @@ __global__ void __launch_bounds__(256) k_conv_fast(const ConvFastArgs p) {
       }
     }
     __syncthreads();
-    for (int i = t; i < 2 * BN; i += 256) {
-      int which = i / BN, c = i % BN;
+    // one (sum, sumsq) row pair per SROWS pixel rows: 128 when BN >= 128 (so the row count does
+    // not depend on BM = 128 / 256), the whole tile otherwise
+    constexpr int SROWS = BN >= 128 ? 128 : BM;
+    constexpr int NH = BM / SROWS, WPH = WGM / NH;     // halves per tile, wave rows per half
+    for (int i = t; i < NH * 2 * BN; i += NT) {
+      int hf = i / (2 * BN), which = (i / BN) & 1, c = i % BN;
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < WGM; w++) v += red[(w * 2 + which) * BN + c];
+      for (int w = 0; w < WPH; w++) v += red[((hf * WPH + w) * 2 + which) * BN + c];
       int col = n0 + c;
-      if (col < p.coutp) p.stats[((long)bid * 2 + which) * p.coutp + col] = v;
+      long srow = (long)bid * NH + hf;
+      if (col < p.coutp && srow * SROWS < p.M) p.stats[(srow * 2 + which) * p.coutp + col] = v;
     }
   }
+#endif
 }
 
-template <typename TOUT, int BM, int BN, int WGM, int WGN>
+template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST>
 static void launch_fast(ConvFastArgs& a, hipStream_t st) {
   a.tiles_m = cdiv(a.M, BM);
   dim3 grid(a.tiles_m, cdiv(a.coutp, BN));
-  size_t lds = (size_t)2 * (BM + BN) * 8 * 16;
-  k_conv_fast<TOUT, BM, BN, WGM, WGN><<<grid, dim3(256), lds, st>>>(a);
+  size_t lds = (size_t)NST * (BM + BN) * 128;
+  size_t olds = sizeof(TOUT) == 2 ? (size_t)BM * (BN + 8) * 2 : 0;
+  if (olds > lds) lds = olds;
+  k_conv_fast<TOUT, BM, BN, WGM, WGN, NST><<<grid, dim3(WGM * WGN * 64), lds, st>>>(a);
 }
 
 // Called by msml_conv2d (conv_igemm.hip) when the fast-path conditions hold.  Returns false if
 // this kernel does not apply.
-bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp,
+bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
-                             int transposed, int in_dtype, int out_dtype, int bm, int bn,
-                             hipStream_t st) {
+                             int transposed, int in_dtype, int out_dtype, int bn, hipStream_t st) {
   if (in_dtype != MSML_BF16) return false;
   if (c0p % 32 != 0 || (in1 && c1p % 32 != 0)) return false;
   ConvFastArgs a;
@@ -302,20 +353,30 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   a.nseg = in1 ? 2 : 1;
   a.nsub[0] = R * S * (c0p / 32);
   a.nsub[1] = in1 ? R * S * (c1p / 32) : 0;
+  if (a.nseg == 2 && (a.nsub[0] & 1)) return false;    // segment switch must be stage-aligned
   a.Ktot = 32 * (a.nsub[0] + a.nsub[1]);
+  const long in0_bytes = (long)N * H * W * c0p * 2, in1_bytes = (long)N * H * W * c1p * 2;
+  const long w_bytes = (long)kop * a.Ktot * 2;
+  if (in0_bytes >= 0x7fffff00L || in1_bytes >= 0x7fffff00L || w_bytes >= 0x7fffff00L) return false;
+  a.in_bytes[0] = (unsigned int)in0_bytes;
+  a.in_bytes[1] = (unsigned int)in1_bytes;
+  a.w_bytes = (unsigned int)w_bytes;
   a.N = N; a.H = H; a.W = W; a.P = P; a.Q = Q; a.R = R; a.S = S;
   a.stride = stride;
   a.stride_shift = stride == 1 ? 0 : (stride == 2 ? 1 : 2);
   a.pad_h = pad_h; a.pad_w = pad_w; a.transposed = transposed;
   a.wp = (const unsigned short*)wp; a.out = out; a.coutp = coutp; a.bias = bias; a.stats = stats;
   a.M = (long)N * P * Q;
-#define FAST_CASE(TO)                                          \
-  if (bn == 128) launch_fast<TO, 128, 128, 2, 2>(a, st);       \
-  else if (bn == 64) launch_fast<TO, 256, 64, 4, 1>(a, st);    \
-  else launch_fast<TO, 256, 32, 4, 1>(a, st);
+  // big tile only when it still fills the 256 CUs
+  static const bool use_big = getenv("MSML_CONV_BIG_TILE") != nullptr;
+  const bool big = use_big && bn == 128 && (long)cdiv(a.M, 256) * cdiv(coutp, 128) >= 256;
+#define FAST_CASE(TO)                                                   \
+  if (big) launch_fast<TO, 256, 128, 4, 2, 3>(a, st);                   \
+  else if (bn == 128) launch_fast<TO, 128, 128, 2, 2, 2>(a, st);        \
+  else if (bn == 64) launch_fast<TO, 256, 64, 4, 1, 2>(a, st);          \
+  else launch_fast<TO, 256, 32, 4, 1, 2>(a, st);
   if (out_dtype == MSML_BF16) { FAST_CASE(unsigned short) }
   else { FAST_CASE(float) }
 #undef FAST_CASE
-  (void)bm;
   return true;
 }

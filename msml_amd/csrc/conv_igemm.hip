@@ -306,11 +306,10 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
   return 0;
 }
 
-bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp,
+bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
-                             int transposed, int in_dtype, int out_dtype, int bm, int bn,
-                             hipStream_t st);
+                             int transposed, int in_dtype, int out_dtype, int bn, hipStream_t st);
 
 extern "C" int msml_conv_tile_m(int coutp) { return coutp <= 64 ? 256 : 128; }
 extern "C" int msml_conv_tile_n(int coutp) { return coutp <= 32 ? 32 : (coutp <= 64 ? 64 : 128); }
@@ -354,9 +353,8 @@ extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, c
              "conv2d: packed weight has %d rows, need %d", kop, cdiv(coutp, bn) * bn);
   hipStream_t st = (hipStream_t)stream;
   if ((out_dtype == MSML_BF16 || out_dtype == MSML_F32) && !getenv("MSML_NO_FAST_CONV") &&
-      msml_conv_fast_dispatch(in0, c0p, in1, c1p, wp, bias, out, coutp, stats, N, H, W, P, Q, R, S,
-                              stride, pad_h, pad_w, transposed, in_dtype, out_dtype,
-                              msml_conv_tile_m(coutp), bn, st)) {
+      msml_conv_fast_dispatch(in0, c0p, in1, c1p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R,
+                              S, stride, pad_h, pad_w, transposed, in_dtype, out_dtype, bn, st)) {
     MSML_LAUNCH_OK("conv2d(fast)");
     return MSML_OK;
   }

@@ -38,13 +38,16 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
+    ap.add_argument("--shapes", default="", help="comma-separated indices into SHAPES")
+    ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
     dt = _lib.BF16 if args.dtype == "bf16" else _lib.F32
     tdt = _lib.TORCH_DTYPE[dt]
     only = args.only.split(",")
     tot = {k: [0.0, 0.0] for k in only}
     print("%-28s %s" % ("shape", "  ".join("%12s" % k for k in only)))
-    for cin, cout, h, r, stride, cnt in SHAPES:
+    shapes = SHAPES if not args.shapes else [SHAPES[int(i)] for i in args.shapes.split(",")]
+    for cin, cout, h, r, stride, cnt in shapes:
         n = args.batch
         pad = r // 2
         p = (h + 2 * pad - r) // stride + 1
@@ -62,7 +65,7 @@ def main():
         }
         res = []
         for k in only:
-            t = timeit(fns[k])
+            t = timeit(fns[k], args.iters)
             res.append("%7.1f TF %5.0fus" % (flops / t / 1e12, t * 1e6))
             tot[k][0] += flops * cnt
             tot[k][1] += t * cnt
