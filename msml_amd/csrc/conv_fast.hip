@@ -37,6 +37,8 @@ struct ConvFastArgs {
   float* stats;
   long M;
   int tiles_m;
+  int parity;         // transposed gather with stride 2: one launch slice (blockIdx.z) per output
+                      // parity class, visiting only the taps that hit real input pixels
 };
 
 #define OOB_OFFSET 0x7ffffff0u      // beyond any descriptor range: the DMA writes zeros
@@ -75,19 +77,44 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   }
   const long m0 = (long)bid * BM;
   const int n0 = blockIdx.y * BN;
-  const int taps = p.R * p.S;
+
+  // tap walk: r = r0 + rstep * ri (ri < nr), s = s0 + rstep * si (si < ns).  Parity mode
+  // (stride-2 transposed gather) keeps only the taps congruent to the class of the output
+  // pixel: a 3x3 has 1 / 2 / 2 / 4 of 9 taps per class, a 4x4 has 4 of 16 -- no zero work.
+  int cy = 0, cx = 0, r0 = 0, s0 = 0, rstep = 1, nr = p.R, ns = p.S;
+  int Pc = p.P, Qc = p.Q;                              // output grid walked by this launch slice
+  if (p.parity) {
+    cy = blockIdx.z >> 1; cx = blockIdx.z & 1;
+    r0 = (cy + p.pad_h) & 1; s0 = (cx + p.pad_w) & 1;
+    rstep = 2;
+    nr = p.R > r0 ? (p.R - r0 + 1) >> 1 : 0;
+    ns = p.S > s0 ? (p.S - s0 + 1) >> 1 : 0;
+    Pc = (p.P - cy + 1) >> 1; Qc = (p.Q - cx + 1) >> 1;
+  }
+  const long Mc = p.parity ? (long)p.N * Pc * Qc : p.M;
+  if (m0 >= Mc) return;
+  const int taps = nr * ns;
+  // output row index (pixel in the full P x Q grid) of class-local row m
+  auto out_pixel = [&](long m) -> long {
+    if (!p.parity) return m;
+    int n = (int)(m / (Pc * Qc));
+    int rem = (int)(m - (long)n * (Pc * Qc));
+    int oyc = rem / Qc, oxc = rem - oyc * Qc;
+    return ((long)n * p.P + 2 * oyc + cy) * p.Q + 2 * oxc + cx;
+  };
 
   // per staged row: pixel index of the window origin and the origin coordinates
   int rowpix[NA], y0[NA], x0[NA];
-  const int PQ = p.P * p.Q;
+  const int PQ = Pc * Qc;
 #pragma unroll
   for (int i = 0; i < NA; i++) {
     long m = m0 + row0 + i * RPP;
-    const bool ok = m < p.M;
+    const bool ok = m < Mc;
     int mm = ok ? (int)m : 0;
     int n = mm / PQ;
     int rem = mm - n * PQ;
-    int oy = rem / p.Q, ox = rem - oy * p.Q;
+    int oy = rem / Qc, ox = rem - oy * Qc;
+    if (p.parity) { oy = 2 * oy + cy; ox = 2 * ox + cx; }
     const int pb = n * p.H * p.W;
     if (p.transposed) {
       y0[i] = oy + p.pad_h;
@@ -110,16 +137,17 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   const unsigned int wstep = (unsigned int)(RPP * p.Ktot) * 2u;
 
   // this thread's sub-step stream inside the current segment: q = sub, sub + 2, ...
-  int r = 0, s = 0, tap = 0, c32 = sub;
+  int ri = 0, si = 0, c32 = sub;
   int nc32 = p.cp[0] >> 5, cp2 = p.cp[0] * 2;          // channel blocks, bytes per pixel
-  const int qtot = p.nsub[0] + (p.nseg > 1 ? p.nsub[1] : 0);
+  int wseg = 0;                                        // weight sub-step index of the segment start
+  const int nsub0 = taps * (p.cp[0] >> 5), nsub1 = p.nseg > 1 ? taps * (p.cp[1] >> 5) : 0;
+  const int qtot = nsub0 + nsub1;
   const int stages = (qtot + 1) >> 1;
-  const int seg0_stages = p.nseg > 1 ? (p.nsub[0] >> 1) : stages;   // uniform segment switch
+  const int seg0_stages = p.nseg > 1 ? (nsub0 >> 1) : stages;       // uniform segment switch
   auto settle = [&]() {
     while (c32 >= nc32) {
       c32 -= nc32;
-      ++tap;
-      if (++s == p.S) { s = 0; ++r; }
+      if (++si == ns) { si = 0; ++ri; }
     }
   };
   settle();
@@ -128,7 +156,8 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   auto gissue = [&](int st, int buf) {
     char* a = As + buf * ABYTES + wave * 1024;
     char* b = Bs + buf * BBYTES + wave * 1024;
-    const bool alive = 2 * st + sub < qtot && tap < taps;
+    const bool alive = (2 * st + sub < qtot) & (ri < nr);
+    const int r = r0 + rstep * ri, s = s0 + rstep * si;
     const unsigned int coff = (unsigned int)((c32 << 5) + cc * 8) * 2u;
     unsigned int oa[NA], ob[NB];
     if (p.transposed) {
@@ -149,7 +178,8 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
         oa[i] = v ? off : OOB_OFFSET;
       }
     }
-    const unsigned int wq = wbase + (unsigned int)(2 * st + sub) * 64u;
+    // packed-weight column of this sub-step: [segment][r][s][c32] blocks of 32 (64 B)
+    const unsigned int wq = wbase + (unsigned int)(wseg + (r * p.S + s) * nc32 + c32) * 64u;
 #pragma unroll
     for (int i = 0; i < NB; i++) ob[i] = alive ? wq + i * wstep : OOB_OFFSET;
     if (st < seg0_stages) {
@@ -168,7 +198,8 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   // move this thread's state from stage st to stage st + 1
   auto advance = [&](int st) {
     if (st + 1 == seg0_stages && p.nseg > 1) {         // (uniform) first stage of segment 1
-      r = 0; s = 0; tap = 0; c32 = sub;
+      ri = 0; si = 0; c32 = sub;
+      wseg = p.R * p.S * (p.cp[0] >> 5);
       nc32 = p.cp[1] >> 5;
       cp2 = p.cp[1] * 2;
     } else {
@@ -275,8 +306,8 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
         long m = m0 + row;
         float v = acc[i][j][e] + bv;
         if (VIA_LDS) otile[row * OP + lcol] = f2bf(v);
-        if (m < p.M && cok) {
-          if (!VIA_LDS) store1<TOUT>(outp + m * p.coutp + col, v);
+        if (m < Mc && cok) {
+          if (!VIA_LDS) store1<TOUT>(outp + out_pixel(m) * p.coutp + col, v);
           s1 += v;
           s2 += v * v;
         }
@@ -292,9 +323,9 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
       int row = idx / C8, c8 = idx % C8;
       long m = m0 + row;
       int col = n0 + c8 * 8;
-      if (m < p.M && col < p.coutp) {
+      if (m < Mc && col < p.coutp) {
         u32x4 v = *reinterpret_cast<const u32x4*>(otile + row * OP + c8 * 8);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + m * p.coutp + col) = v;
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + out_pixel(m) * p.coutp + col) = v;
       }
     }
   }
@@ -322,7 +353,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
       for (int w = 0; w < WPH; w++) v += red[((hf * WPH + w) * 2 + which) * BN + c];
       int col = n0 + c;
       long srow = (long)bid * NH + hf;
-      if (col < p.coutp && srow * SROWS < p.M) p.stats[(srow * 2 + which) * p.coutp + col] = v;
+      if (col < p.coutp && srow * SROWS < Mc) p.stats[(srow * 2 + which) * p.coutp + col] = v;
     }
   }
 #endif
@@ -330,8 +361,10 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
 
 template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST>
 static void launch_fast(ConvFastArgs& a, hipStream_t st) {
-  a.tiles_m = cdiv(a.M, BM);
-  dim3 grid(a.tiles_m, cdiv(a.coutp, BN));
+  // parity mode: tiles sized for the largest class (cy = cx = 0); smaller classes exit early
+  const long mtile = a.parity ? (long)a.N * ((a.P + 1) / 2) * ((a.Q + 1) / 2) : a.M;
+  a.tiles_m = cdiv(mtile, BM);
+  dim3 grid(a.tiles_m, cdiv(a.coutp, BN), a.parity ? 4 : 1);
   size_t lds = (size_t)NST * (BM + BN) * 128;
   size_t olds = sizeof(TOUT) == 2 ? (size_t)BM * (BN + 8) * 2 : 0;
   if (olds > lds) lds = olds;
@@ -367,6 +400,18 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   a.pad_h = pad_h; a.pad_w = pad_w; a.transposed = transposed;
   a.wp = (const unsigned short*)wp; a.out = out; a.coutp = coutp; a.bias = bias; a.stats = stats;
   a.M = (long)N * P * Q;
+  // stride-2 transposed gather by output parity class (needs stage-aligned segment switches)
+  a.parity = 0;
+  if (transposed && stride == 2 && !getenv("MSML_CONV_NO_PARITY") && stats == nullptr) {
+    bool ok = true;
+    if (a.nseg == 2)
+      for (int c = 0; c < 4 && ok; c++) {
+        int r0 = ((c >> 1) + pad_h) & 1, s0 = ((c & 1) + pad_w) & 1;
+        int nr = R > r0 ? (R - r0 + 1) / 2 : 0, ns = S > s0 ? (S - s0 + 1) / 2 : 0;
+        ok = ((nr * ns * (c0p / 32)) & 1) == 0;
+      }
+    a.parity = ok ? 1 : 0;
+  }
   // big tile only when it still fills the 256 CUs
   static const bool use_big = getenv("MSML_CONV_BIG_TILE") != nullptr;
   const bool big = use_big && bn == 128 && (long)cdiv(a.M, 256) * cdiv(coutp, 128) >= 256;

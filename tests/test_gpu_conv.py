@@ -198,3 +198,22 @@ def test_deconv_wgrad():
     xd = ops.to_nhwc(x.cuda(), _lib.F32)
     ops.conv_wgrad(xd, ops.to_nhwc(dy.cuda(), _lib.F32), dw, cin, cout, cout, 0, k, k, 2, 1, 1)
     assert (dw.cpu() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("h", [14, 9])
+def test_conv1x1_s2_dgrad_bf16(h):
+    """Downsample 1x1 stride-2 backward-data: three of the four output parity classes receive
+    no tap at all and must come out as exact zeros."""
+    g = torch.Generator().manual_seed(13)
+    n, cin, cout = 2, 64, 128
+    x = torch.randn(n, cin, h, h, generator=g, dtype=torch.double, requires_grad=True)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.1).bfloat16().double()
+    y = F.conv2d(x, w, None, 2, 0)
+    dy = torch.randn(y.shape, generator=g).bfloat16().double()
+    y.backward(dy)
+    wp = ops.pack_weight(w.float().cuda(), True, cout, 0, _lib.BF16)
+    dyd = ops.to_nhwc(dy.float().cuda(), _lib.BF16)
+    dx, _ = ops.conv2d(dyd, None, wp, None, cin, 1, 1, 2, 0, 0, True, p=h, q=h)
+    got = ops.to_nchw(dx, cin).cpu().double()
+    assert (got - x.grad).abs().max().item() <= 1e-2 * x.grad.abs().max().item()
+    assert (got[:, :, 1::2, :] == 0).all() and (got[:, :, :, 1::2] == 0).all()
