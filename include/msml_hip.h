@@ -134,7 +134,8 @@ int msml_conv_wgrad(const void* u, int up, const void* v, int vp, float* dw, int
  *   (resblock_bottle, fmoperator.py:65-67).  alpha / residual optional.
  * msml_bn_act_bwd (training statistics): dx, dgamma, dbeta, dalpha from dy and the saved x;
  *   residual_first (the saved residual, only for res_first == 1) and dres (gradient flowing
- *   to that residual) optional; workspace >= rows*3*C + 2*C floats. */
+ *   to that residual) optional; accumulate != 0 adds the parameter gradients into dgamma / dbeta /
+ *   dalpha (the flat gradient arena) instead of overwriting; workspace >= rows*3*C + 2*C floats. */
 int msml_bn_stats_rows(long M, int C);
 int msml_bn_stats(const void* x, long M, int C, float* partial, int dtype, void* stream);
 int msml_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma,
@@ -147,12 +148,12 @@ int msml_bn_act_fwd(const void* x, const float* scale, const float* shift, const
 int msml_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
                     const float* alpha, const float* save_mean, const float* save_invstd,
                     const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,
-                    float* dalpha, long M, int C, float* workspace, long ws_floats, int dtype,
-                    void* stream);
+                    float* dalpha, int accumulate, long M, int C, float* workspace, long ws_floats,
+                    int dtype, void* stream);
 /* db[c] = sum over pixels of dy (biased GCM convs, backbones/osb/unet.py:23-30);
  * workspace >= msml_bn_stats_rows(M,Cp)*2*Cp floats. */
-int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* db, float* workspace,
-                   long ws_floats, int dtype, void* stream);
+int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* db, int accumulate,
+                   float* workspace, long ws_floats, int dtype, void* stream);
 /* out = a + b (GCM branch sum unet.py:37; gradient joins) */
 int msml_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);
 

@@ -115,7 +115,8 @@ class IResNet(nn.Module):
         n, h, w, c = x.shape
         wview = self.fc.weight.view(self.fc.out_features, c, h, w)
         cfg = {"deconv": False, "c0": c, "c1": 0, "cout": self.fc.out_features, "stride": 1,
-               "pad_h": 0, "pad_w": 0, "want_stats": self.features.training}
+               "pad_h": 0, "pad_w": 0, "want_stats": self.features.training,
+               "grad_param": self.fc.weight}
         y, stats = Fh.conv(x, None, wview, self.fc.bias, cfg)
         y = Fh.bn_act(y, stats, self.features)
         return Fh.to_vec(y, self.fc.out_features), 0.0

@@ -286,15 +286,15 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy,
 
 __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restrict__ partial, int rows, int C, double count,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                  float* __restrict__ dalpha, float* __restrict__ coef) {
+                                  float* __restrict__ dalpha, float* __restrict__ coef, int accumulate) {
   const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   const bool cok = c < C;
   double s[3];
   fin_reduce<3>(partial, rows, C, c, cok, s);
   if (threadIdx.x >= 32 || !cok) return;
-  if (dbeta) dbeta[c] = (float)s[0];
-  if (dgamma) dgamma[c] = (float)s[1];
-  if (dalpha) dalpha[c] = (float)s[2];
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s[0];
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s[1];
+  if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + (float)s[2];
   coef[c] = (float)(s[0] / count);
   coef[C + c] = (float)(s[1] / count);
 }
@@ -341,8 +341,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
 extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
                                const float* alpha, const float* save_mean, const float* save_invstd,
                                const void* residual_first, void* dx, void* dres, float* dgamma,
-                               float* dbeta, float* dalpha, long M, int C, float* workspace,
-                               long ws_floats, int dtype, void* stream) {
+                               float* dbeta, float* dalpha, int accumulate, long M, int C,
+                               float* workspace, long ws_floats, int dtype, void* stream) {
   MSML_CHECK(dy && x && dx && scale && shift && save_mean && save_invstd && workspace && M > 0 &&
                  C > 0 && C % 8 == 0 && C <= 2048,
              MSML_ERR_SHAPE, "bn_act_bwd: bad args M=%ld C=%d", M, C);
@@ -359,7 +359,7 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
                                                             alpha, save_mean, save_invstd,
                                                             (const DT*)residual_first, M, C, partial);
       MSML_LAUNCH_OK("bn_bwd_reduce");
-      k_bn_bwd_finalize<<<cdiv(C, 32), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef);
+      k_bn_bwd_finalize<<<cdiv(C, 32), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef, accumulate);
       MSML_LAUNCH_OK("bn_bwd_finalize");
       k_bn_bwd_apply<DT><<<ew_grid_c(n8, C / 8), 256, 0, st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
                                                      save_mean, save_invstd, coef, (const DT*)residual_first,
@@ -371,16 +371,16 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
 // ------------------------------------------------------------------ bias gradient ------------
 // db[c] = sum over pixels of dy[.., c]  (GCM convs carry a bias: backbones/osb/unet.py:23-30)
 __global__ void k_colsum_finalize(const float* __restrict__ partial, int rows, int C, int stride_q,
-                                  float* __restrict__ out, int Creal) {
+                                  float* __restrict__ out, int Creal, int accumulate) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Creal) return;
   double s = 0.0;
   for (int r = 0; r < rows; r++) s += (double)partial[(long)r * stride_q * C + c];
-  out[c] = (float)s;
+  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
 }
 
-extern "C" int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* db, float* workspace,
-                              long ws_floats, int dtype, void* stream) {
+extern "C" int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* db, int accumulate,
+                              float* workspace, long ws_floats, int dtype, void* stream) {
   MSML_CHECK(dy && db && workspace && M > 0 && Cp > 0 && Cp % 8 == 0 && Creal <= Cp, MSML_ERR_SHAPE,
              "bias_grad: bad args");
   int rows = red_rows(M, Cp);
@@ -389,7 +389,7 @@ extern "C" int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* 
   MSML_DISPATCH_DTYPE(dtype, "bias_grad",
                       k_bn_stats<DT><<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace);)
   MSML_LAUNCH_OK("bias_grad");
-  k_colsum_finalize<<<cdiv(Creal, 128), 128, 0, st>>>(workspace, rows, Cp, 2, db, Creal);
+  k_colsum_finalize<<<cdiv(Creal, 128), 128, 0, st>>>(workspace, rows, Cp, 2, db, Creal, accumulate);
   MSML_LAUNCH_OK("bias_grad_finalize");
   return MSML_OK;
 }

@@ -56,6 +56,8 @@ class _Conv(torch.autograd.Function):
                               want_stats=cfg.get("want_stats", False), real=(c0 + c1, cout))
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
+        ctx.wparam = cfg.get("grad_param", weight)      # the leaf whose .grad receives dW
+        ctx.bparam = bias
         ctx.save_for_backward(x0, x1, weight)
         if stats is None:
             stats = x0.new_empty(0)
@@ -90,22 +92,30 @@ class _Conv(torch.autograd.Function):
                                          p=h, q=wd, real=(cout, ci))
         dw = None
         if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(w)
+            inplace = ops.INPLACE_GRADS and ctx.wparam.grad is not None
+            dw = ctx.wparam.grad.view(w.shape) if inplace else torch.empty_like(w)
             for x, off, ci in ((x0, 0, c0), (x1, c0, c1)):
                 if x is None:
                     continue
                 if deconv:
-                    ops.conv_wgrad(x, dy, dw[off:off + ci], ci, cout, cout, 0, r, s, stride, ph, pw)
+                    ops.conv_wgrad(x, dy, dw[off:off + ci], ci, cout, cout, 0, r, s, stride, ph, pw,
+                                   accumulate=inplace)
                 else:
-                    ops.conv_wgrad(dy, x, dw, cout, ci, c0 + c1, off, r, s, stride, ph, pw)
+                    ops.conv_wgrad(dy, x, dw, cout, ci, c0 + c1, off, r, s, stride, ph, pw,
+                                   accumulate=inplace)
+            if inplace:
+                dw = None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[3]:
             m = dy.numel() // dy.shape[-1]
             cp = dy.shape[-1]
             rows = ops.bn_stats_rows(m, cp)
             wsb = ops.workspace(rows * 2 * cp * 4, dy.device)
-            db = torch.empty(cout, dtype=torch.float32, device=dy.device)
-            call("msml_bias_grad", dy, m, cp, cout, db, wsb, wsb.numel() // 4, dtype)
+            binplace = ops.INPLACE_GRADS and ctx.bparam.grad is not None
+            db = ctx.bparam.grad if binplace else torch.empty(cout, dtype=torch.float32, device=dy.device)
+            call("msml_bias_grad", dy, m, cp, cout, db, int(binplace), wsb, wsb.numel() // 4, dtype)
+            if binplace:
+                db = None
         return grads[0], grads[1], dw, db, None, None
 
 
@@ -142,6 +152,7 @@ class _BnAct(torch.autograd.Function):
         ctx.training = training
         ctx.has = (gamma is not None, beta is not None, alpha is not None, residual is not None)
         ctx.res_first = bool(res_first) and residual is not None and alpha is not None
+        ctx.params = (gamma, beta, alpha)
         ctx.save_for_backward(x, coef, alpha, residual if ctx.res_first else None)
         return y
 
@@ -160,16 +171,26 @@ class _BnAct(torch.autograd.Function):
         need = (rows * 3 * c + 2 * c) * 4
         ws = ops.workspace(need, x.device)
         dres = torch.empty_like(x) if ctx.res_first else None
+        has_g, has_b, has_a, has_r = ctx.has
+        gamma, beta, alpha_p = ctx.params
+        want = (has_g and ctx.needs_input_grad[2], has_b and ctx.needs_input_grad[3],
+                has_a and ctx.needs_input_grad[4])
+        # parameter gradients go straight into the flat arena when FlatSGD owns the .grad views
+        inplace = ops.INPLACE_GRADS and all(
+            (not w) or prm.grad is not None for w, prm in zip(want, (gamma, beta, alpha_p)))
+        if inplace:
+            tg = [prm.grad if w else None for w, prm in zip(want, (gamma, beta, alpha_p))]
+        else:
+            tg = [pg[0], pg[1], pg[2] if alpha is not None else None]
         with ops.PROFILE.rec("bn_act_bwd", 0.0, x.numel() * x.element_size() * (5 + (3 if ctx.res_first else 0))):
             call("msml_bn_act_bwd", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, dx, dres,
-                 pg[0], pg[1], pg[2] if alpha is not None else None, m, c, ws, ws.numel() // 4, dtype)
-        has_g, has_b, has_a, has_r = ctx.has
+                 tg[0], tg[1], tg[2], int(inplace), m, c, ws, ws.numel() // 4, dtype)
         if ctx.res_first:
             dy = dres
         return (dx, None,
-                pg[0] if has_g and ctx.needs_input_grad[2] else None,
-                pg[1] if has_b and ctx.needs_input_grad[3] else None,
-                pg[2] if has_a and ctx.needs_input_grad[4] else None,
+                pg[0] if want[0] and not inplace else None,
+                pg[1] if want[1] and not inplace else None,
+                pg[2] if want[2] and not inplace else None,
                 dy if has_r else None, None, None, None, None, None, None)
 
 

@@ -55,6 +55,12 @@ class _Rec:
 
 PROFILE = _Profile()
 
+# When True (set by msml_amd.optim.FlatSGD) the backward kernels add parameter gradients
+# straight into the pre-zeroed param.grad views of the flat arena and autograd gets None for
+# them: no temporary gradient tensors and no AccumulateGrad add kernels (~470 tiny launches per
+# ires50 step).  Requires grads to be zeroed by FlatSGD.zero_grad() before every backward.
+INPLACE_GRADS = False
+
 
 def cpad(c):
     """Storage channel count: 8 for tiny tensors (RGB input, gcm1's 8 maps), otherwise a

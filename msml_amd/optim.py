@@ -51,6 +51,8 @@ class FlatSGD:
             self.groups.append({"start": start, "end": off, "lr": g["lr"], "base_lr": g["lr"]})
         self.params = params
         self.steps = 0
+        from . import ops
+        ops.INPLACE_GRADS = True      # backward kernels accumulate into the arena views directly
         self.norm_coef = torch.ones(2, dtype=torch.float32, device=dev)
         self.ws = torch.empty(1024, dtype=torch.float32, device=dev)
 

@@ -205,3 +205,31 @@ def test_flat_sgd_matches_torch():
         to.step()
         for p, q in zip(ps, qs):
             assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), step
+
+
+def test_inplace_grads_match_autograd():
+    """FlatSGD's in-place gradient accumulation (kernels write into the arena views, autograd
+    gets None) gives the same gradients as the standard autograd path."""
+    from msml_amd import ops
+    from msml_amd.optim import FlatSGD, reference_param_groups
+    x, msk = eval_inputs(2)
+    label = synthetic.labels(2, 50, seed=1)
+
+    def grads(inplace):
+        m = hip_msml("iresnet18", 50).train()
+        opt = None
+        if inplace:
+            opt = FlatSGD(reference_param_groups(m, 2, 1), 0.9, 5e-4, 5.0)
+            opt.zero_grad()
+        else:
+            ops.INPLACE_GRADS = False
+        cls, seg, _ = m(x.cuda(), label.cuda())
+        loss = torch.nn.functional.cross_entropy(cls, label.cuda()) + \
+            StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
+        loss.backward()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    a = grads(False)
+    b = grads(True)
+    assert set(a) == set(b)
+    for n in a:
+        assert torch.allclose(a[n], b[n], rtol=1e-5, atol=1e-7), n
