@@ -276,6 +276,10 @@ def main():
     }
     if args.mode == "train" and out[0] is not None:
         rec["loss"] = round(float(out[0]), 4)
+    if os.environ.get("MSML_PROFILE_DETAIL"):
+        for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:45]:
+            print("%-52s n=%3d ms/step=%7.3f TF/s=%6.1f" % (name, v["n"] // prof_steps, v["ms"] / prof_steps,
+                  v["flops"] / max(v["ms"], 1e-9) / 1e9), file=sys.stderr)
     k = prof.get("conv_igemm")
     if k:
         peak = PEAK_TFLOPS[args.dtype]

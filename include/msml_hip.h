@@ -207,6 +207,13 @@ int msml_sgd_momentum(float* w, const float* grad, float* mom, long n, float lr,
 int msml_grad_norm_clip(const float* grad, long n, float max_norm, float* out2, float* workspace,
                         long ws_floats, void* stream);
 
+/* Skinny GEMM with a huge K, split over K with deterministic slab reduction: out[M][coutp] (f32)
+ * = a[M][K] (bf16, K % 32 == 0) . wp[kop][K]^T.  PartialFC dX = dcos . Wn (K = local classes,
+ * headers/partial_fc.py:169 total_features.grad). */
+long msml_gemm_splitk_workspace(int M, int coutp, int K);
+int msml_gemm_splitk(const void* a, int M, int K, const void* wp, int kop, float* out, int coutp,
+                     void* workspace, long ws_bytes, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,8 @@ struct ConvFastArgs {
   int tiles_m;
   int parity;         // transposed gather with stride 2: one launch slice (blockIdx.z) per output
                       // parity class, visiting only the taps that hit real input pixels
+  int ksplits;        // > 1: split-K over stages, slice z writes f32 partials to out + z*split_stride
+  long split_stride;
 };
 
 #define OOB_OFFSET 0x7ffffff0u      // beyond any descriptor range: the DMA writes zeros
@@ -142,8 +144,17 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   int wseg = 0;                                        // weight sub-step index of the segment start
   const int nsub0 = taps * (p.cp[0] >> 5), nsub1 = p.nseg > 1 ? taps * (p.cp[1] >> 5) : 0;
   const int qtot = nsub0 + nsub1;
-  const int stages = (qtot + 1) >> 1;
-  const int seg0_stages = p.nseg > 1 ? (nsub0 >> 1) : stages;       // uniform segment switch
+  const int all_stages = (qtot + 1) >> 1;
+  // split-K: this launch slice owns stages [st0, stages)
+  int st0 = 0, stages = all_stages;
+  if (p.ksplits > 1) {
+    const int per = (all_stages + p.ksplits - 1) / p.ksplits;
+    st0 = blockIdx.z * per;
+    stages = st0 + per < all_stages ? st0 + per : all_stages;
+    if (st0 > stages) st0 = stages;
+    c32 = sub + 2 * st0;
+  }
+  const int seg0_stages = p.nseg > 1 ? (nsub0 >> 1) : all_stages;   // uniform segment switch
   auto settle = [&]() {
     while (c32 >= nc32) {
       c32 -= nc32;
@@ -248,10 +259,10 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   };
 
   if constexpr (NST == 2) {
-    gissue(0, 0);
+    gissue(st0, 0);
     __syncthreads();                                   // (hipcc drains vmcnt before the barrier)
     int cur = 0;
-    for (int st = 0; st < stages; st++) {
+    for (int st = st0; st < stages; st++) {
       if (st + 1 < stages) {
         advance(st);
         gissue(st + 1, cur ^ 1);
@@ -286,7 +297,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   // ---------------- epilogue (same contract as k_conv_igemm) -----------------------------------
   // bf16 results go through an LDS transpose tile [BM][BN + 8] and leave as 16-B row chunks;
   // f32 results (head logits) are stored directly.
-  TOUT* outp = reinterpret_cast<TOUT*>(p.out);
+  TOUT* outp = reinterpret_cast<TOUT*>(p.out) + (p.ksplits > 1 ? blockIdx.z * p.split_stride : 0);
   constexpr bool VIA_LDS = sizeof(TOUT) == 2;
   constexpr int OP = BN + 8;                           // tile pitch in elements
   unsigned short* otile = reinterpret_cast<unsigned short*>(smem);
@@ -364,7 +375,7 @@ static void launch_fast(ConvFastArgs& a, hipStream_t st) {
   // parity mode: tiles sized for the largest class (cy = cx = 0); smaller classes exit early
   const long mtile = a.parity ? (long)a.N * ((a.P + 1) / 2) * ((a.Q + 1) / 2) : a.M;
   a.tiles_m = cdiv(mtile, BM);
-  dim3 grid(a.tiles_m, cdiv(a.coutp, BN), a.parity ? 4 : 1);
+  dim3 grid(a.tiles_m, cdiv(a.coutp, BN), a.parity ? 4 : (a.ksplits > 1 ? a.ksplits : 1));
   size_t lds = (size_t)NST * (BM + BN) * 128;
   size_t olds = sizeof(TOUT) == 2 ? (size_t)BM * (BN + 8) * 2 : 0;
   if (olds > lds) lds = olds;
@@ -400,6 +411,8 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   a.pad_h = pad_h; a.pad_w = pad_w; a.transposed = transposed;
   a.wp = (const unsigned short*)wp; a.out = out; a.coutp = coutp; a.bias = bias; a.stats = stats;
   a.M = (long)N * P * Q;
+  a.ksplits = 1;
+  a.split_stride = 0;
   // stride-2 transposed gather by output parity class (needs stage-aligned segment switches)
   a.parity = 0;
   if (transposed && stride == 2 && !getenv("MSML_CONV_NO_PARITY") && stats == nullptr) {
@@ -423,5 +436,33 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   if (out_dtype == MSML_BF16) { FAST_CASE(unsigned short) }
   else { FAST_CASE(float) }
 #undef FAST_CASE
+  return true;
+}
+
+
+// Split-K variant for skinny GEMMs with a huge K (PartialFC dX = dcos[N x C] . Wn[C x E]:
+// K = classes, only a handful of output tiles): `ksplits` launch slices each accumulate a K
+// range into an f32 slab (ws[z][M][coutp]); the caller sums the slabs in a fixed order.
+bool msml_conv_fast_splitk(const void* in0, int c0p, const void* wp, int kop, float* ws, int coutp, int N,
+                           int ksplits, hipStream_t st) {
+  if (c0p % 32 != 0) return false;
+  ConvFastArgs a;
+  a.in[0] = (const unsigned short*)in0; a.in[1] = nullptr;
+  a.cp[0] = c0p; a.cp[1] = 0;
+  a.nseg = 1;
+  a.nsub[0] = c0p / 32; a.nsub[1] = 0;
+  a.Ktot = c0p;
+  const long in_bytes = (long)N * c0p * 2, w_bytes = (long)kop * a.Ktot * 2;
+  if (in_bytes >= 0x7fffff00L || w_bytes >= 0x7fffff00L) return false;
+  a.in_bytes[0] = (unsigned int)in_bytes; a.in_bytes[1] = 0;
+  a.w_bytes = (unsigned int)w_bytes;
+  a.N = N; a.H = 1; a.W = 1; a.P = 1; a.Q = 1; a.R = 1; a.S = 1;
+  a.stride = 1; a.stride_shift = 0; a.pad_h = 0; a.pad_w = 0; a.transposed = 0;
+  a.wp = (const unsigned short*)wp; a.out = ws; a.coutp = coutp; a.bias = nullptr; a.stats = nullptr;
+  a.M = N;
+  a.parity = 0;
+  a.ksplits = ksplits;
+  a.split_stride = (long)N * coutp;
+  launch_fast<float, 128, 128, 2, 2, 2>(a, st);
   return true;
 }

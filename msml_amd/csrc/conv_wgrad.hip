@@ -235,6 +235,10 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
+bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
+                            int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int ba, int bb,
+                            int splits, int chunk, hipStream_t st);
+
 static int pick_tile(int c) { return c > 64 ? 128 : 64; }
 
 // number of pixel splits: enough workgroups to fill 256 CUs a few times over, chunks >= 256 px
@@ -283,9 +287,19 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   const int ba = pick_tile(up), bb = pick_tile(vp);
   const int atiles = cdiv(up, ba), btiles = cdiv(vp, bb), taps = R * S;
   const int splits = pick_splits(a.Mpix, atiles * btiles * taps);
-  a.chunk = (int)(((a.Mpix + splits - 1) / splits + 31) / 32 * 32);
+  a.chunk = (int)(((a.Mpix + splits - 1) / splits + 63) / 64 * 64);
   dim3 grid(atiles, btiles * taps, splits);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == MSML_BF16 && !getenv("MSML_NO_FAST_WGRAD") &&
+      msml_wgrad_fast_launch(u, up, v, vp, a.ws, N, H, W, P, Q, R, S, stride, pad_h, pad_w, ba, bb, splits,
+                             a.chunk, st)) {
+    MSML_LAUNCH_OK("conv_wgrad(fast)");
+    long total = (long)A * taps * vp;
+    int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    k_wgrad_reduce<<<rgrid, 256, 0, st>>>(a.ws, dw, splits, up, taps, vp, A, Breal, Btot, boff, accumulate);
+    MSML_LAUNCH_OK("conv_wgrad_reduce");
+    return MSML_OK;
+  }
 
 #define WG_LAUNCH(T, BA_, BB_)                                                    \
   {                                                                               \
@@ -308,5 +322,38 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   k_wgrad_reduce<<<rgrid, 256, 0, st>>>(a.ws, dw, splits, up, taps, vp, A, Breal, Btot, boff, accumulate);
   MSML_LAUNCH_OK("conv_wgrad_reduce");
+  return MSML_OK;
+}
+
+
+// ---------------------------------------------------------------- split-K GEMM (head dX) -----
+bool msml_conv_fast_splitk(const void* in0, int c0p, const void* wp, int kop, float* ws, int coutp, int N,
+                           int ksplits, hipStream_t st);
+
+extern "C" long msml_gemm_splitk_workspace(int M, int coutp, int K) {
+  int stages = (K / 32 + 1) / 2;
+  int ks = stages / 16 > 0 ? stages / 16 : 1;          // >= 16 stages (1024 k) per slice
+  int tiles = cdiv(M, 128) * cdiv(coutp, 128);
+  int want = (768 + tiles - 1) / tiles;
+  if (ks > want) ks = want;
+  return (long)ks * M * coutp * (long)sizeof(float);
+}
+
+extern "C" int msml_gemm_splitk(const void* a, int M, int K, const void* wp, int kop, float* out, int coutp,
+                                void* workspace, long ws_bytes, int dtype, void* stream) {
+  MSML_CHECK(a && wp && out && workspace && M > 0 && K > 0 && K % 32 == 0 && coutp % 8 == 0, MSML_ERR_SHAPE,
+             "gemm_splitk: bad args M=%d K=%d coutp=%d", M, K, coutp);
+  MSML_CHECK(dtype == MSML_BF16, MSML_ERR_UNSUPPORTED, "gemm_splitk: bf16 only");
+  long need = msml_gemm_splitk_workspace(M, coutp, K);
+  MSML_CHECK(ws_bytes >= need, MSML_ERR_WORKSPACE, "gemm_splitk: workspace %ld < %ld", ws_bytes, need);
+  int ks = (int)(need / ((long)M * coutp * sizeof(float)));
+  hipStream_t st = (hipStream_t)stream;
+  MSML_CHECK(msml_conv_fast_splitk(a, K, wp, kop, (float*)workspace, coutp, M, ks, st), MSML_ERR_UNSUPPORTED,
+             "gemm_splitk: shape not supported by the fast kernel");
+  MSML_LAUNCH_OK("gemm_splitk");
+  long total = (long)M * coutp;
+  int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  k_wgrad_reduce<<<rgrid, 256, 0, st>>>((const float*)workspace, out, ks, M, 1, coutp, M, coutp, coutp, 0, 0);
+  MSML_LAUNCH_OK("gemm_splitk_reduce");
   return MSML_OK;
 }

@@ -91,7 +91,10 @@ class HipBackend:
         call("msml_pfc_grad", cosm, cp, n, c, labels, kind, margin.s, margin.m, margin.a, margin.k,
              gmax, gsum, eps_ls, 1.0 / n_total, dcos, cp, ptarget, self.dtype)
         wnt = ops.pack_weight(wn[:c].float().reshape(c, e, 1, 1), True, c, 0, self.dtype)
-        dx, _ = ops.conv2d(dcos, None, wnt, None, e, 1, 1, 1, 0, 0, False, out_dtype=0)
+        if self.dtype == 1:        # bf16: K = classes is huge and there are only 8 output tiles
+            dx = ops.gemm_splitk(dcos.reshape(n, cp), wnt, e)
+        else:
+            dx, _ = ops.conv2d(dcos, None, wnt, None, e, 1, 1, 1, 0, 0, False, out_dtype=0)
         dwn = torch.empty(c, e, dtype=torch.float32, device=dev)
         ops.conv_wgrad(dcos, xs, dwn, c, e, e, 0, 1, 1, 1, 0, 0)
         dw = torch.empty(c, e, dtype=torch.float32, device=dev)

@@ -1,5 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (no autograd): allocate outputs with torch,
 pass raw pointers.  Everything here requires the HIP library and a GPU tensor."""
+import os
+
 import torch
 
 from . import _lib
@@ -54,6 +56,7 @@ class _Rec:
 
 
 PROFILE = _Profile()
+DETAIL = bool(os.environ.get("MSML_PROFILE_DETAIL"))   # per-shape names in the event profile
 
 # When True (set by msml_amd.optim.FlatSGD) the backward kernels add parameter gradients
 # straight into the pre-zeroed param.grad views of the flat arena and autograd gets None for
@@ -139,7 +142,10 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
     cin, cout = real if real is not None else (c0p + c1p, coutp)
     # algorithmic FLOP: 2*N*Cout*P*Q*Cin*R*S, deconv form 2*N*Cin*H*W*Cout*R*S
     pix = n * h * w if transposed else n * p * q
-    with PROFILE.rec("conv_igemm", 2.0 * pix * cin * cout * r * s):
+    name = "conv_igemm"
+    if DETAIL:
+        name = "conv %s c%d+%d->%d %dx%d k%dx%d s%d n%d" % ("T" if transposed else "N", c0p, c1p, coutp, h, w, r, s, stride, n)
+    with PROFILE.rec(name, 2.0 * pix * cin * cout * r * s):
         call("msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats, n, h, w, p,
              q, r, s, stride, pad_h, pad_w, int(transposed), in_dtype, out_dtype)
     return out, stats
@@ -163,7 +169,21 @@ def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accum
     _, h, w, vp = v.shape
     need = _lib.value("msml_conv_wgrad_workspace", up, vp, n, p, q, r, s)
     ws = workspace(need, u.device)
-    with PROFILE.rec("conv_wgrad", 2.0 * n * p * q * a * breal * r * s):
+    name = "conv_wgrad"
+    if DETAIL:
+        name = "wgrad u%d v%d %dx%d k%dx%d s%d n%d" % (up, vp, p, q, r, s, stride, n)
+    with PROFILE.rec(name, 2.0 * n * p * q * a * breal * r * s):
         call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
              pad_h, pad_w, int(accumulate), ws, ws.numel(), DTYPE_OF[u.dtype])
     return dw
+
+
+def gemm_splitk(a, wp, coutp):
+    """out[M][coutp] f32 = a[M][K] . wp[kop][K]^T with split-K (see msml_gemm_splitk)."""
+    m, k = a.shape
+    need = _lib.value("msml_gemm_splitk_workspace", m, coutp, k)
+    ws = workspace(need, a.device)
+    out = torch.empty(m, coutp, dtype=torch.float32, device=a.device)
+    with PROFILE.rec("gemm_splitk", 2.0 * m * k * coutp):
+        call("msml_gemm_splitk", a, m, k, wp, wp.shape[0], out, coutp, ws, ws.numel(), DTYPE_OF[a.dtype])
+    return out

@@ -233,3 +233,26 @@ def test_inplace_grads_match_autograd():
     assert set(a) == set(b)
     for n in a:
         assert torch.allclose(a[n], b[n], rtol=1e-5, atol=1e-7), n
+
+
+def test_partial_fc_bf16_vs_oracle():
+    """bf16 PartialFC (split-K dX GEMM, fused softmax passes) against the CPU oracle backend at a
+    shape with many classes; tolerance = bf16 operand rounding."""
+    from msml_amd.headers import ArcMargin, PartialFC
+    from tests.pfc_cpu_backend import OracleBackend
+    torch.manual_seed(0)
+    N, C, E = 32, 10000, 512
+    feat = torch.nn.functional.normalize(torch.randn(N, E))
+    label = torch.randint(0, C, (N,))
+    w = torch.randn(C, E) * 0.01
+    ref = PartialFC(0, 0, 1, N, False, ArcMargin(64.0, 0.48, 0, 0), C, backend=OracleBackend(),
+                    device=torch.device("cpu"))
+    ref.weight.copy_(w)
+    xg_r, loss_r = ref.forward_backward(label, feat, None)
+    p = PartialFC(0, 0, 1, N, False, ArcMargin(64.0, 0.48, 0, 0), C, fp16=True)
+    with torch.no_grad():
+        p.weight.copy_(w)
+    xg, loss = p.forward_backward(label.cuda(), feat.cuda(), None)
+    assert abs(loss.item() - loss_r.item()) < 1e-3 * abs(loss_r.item())
+    assert rel_err(xg.cpu().numpy(), xg_r.numpy()) < 1e-2
+    assert rel_err(p.sub_weight.grad.cpu().numpy(), ref.sub_weight.grad.numpy()) < 1e-2
