@@ -171,6 +171,8 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
 #endif
 }
 
+
+
 // Called from msml_conv_wgrad (conv_wgrad.hip) for bf16; chunk is a multiple of 64.
 // Returns false when the tensors are too large for 32-bit buffer offsets.
 bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
