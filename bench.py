@@ -187,7 +187,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = bool(os.environ.get("MSML_FORCE_DIST"))   # exercise the RCCL path at world == 1
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from msml_amd import ops
     runner = (Trainer if args.mode == "train" else Inferer)(args, rank, local_rank, world)
@@ -203,7 +206,7 @@ def main():
     # when issued from Python one by one.
     graph = None
     static = None
-    if not args.no_graph and world == 1:
+    if not args.no_graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -214,7 +217,10 @@ def main():
             torch.cuda.synchronize()
             static = tuple(t.clone() for t in runner.next_batch())
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # RCCL collectives are captured too (verified with a 1-rank communicator); the
+            # watchdog thread of ProcessGroupNCCL must not trip the capture -> thread_local mode
+            mode = "thread_local" if dist.is_initialized() else "global"
+            with torch.cuda.graph(graph, capture_error_mode=mode):
                 out = runner.step(static)
         except Exception as e:                              # pragma: no cover (diagnostic path)
             import traceback
@@ -256,7 +262,7 @@ def main():
         dist.all_reduce(tt, dist.ReduceOp.MAX)
         dt = tt.item()
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
     imgs = args.batch * world * args.steps
@@ -295,7 +301,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.mode == "train":
         rec["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -27,6 +27,9 @@ from torch.nn import Module
 from torch.nn.parameter import Parameter
 
 
+_FORCE = bool(os.environ.get("MSML_FORCE_DIST"))   # run the collectives even at world size 1
+
+
 class _Margin:
     kind = "arc"
 
@@ -163,7 +166,7 @@ class PartialFC(Module):
                                       torch.full_like(total_label, -1)))
 
     def _all_gather(self, x):
-        if self.world_size == 1:
+        if self.world_size == 1 and not _FORCE:
             return x.clone()
         out = torch.zeros((self.batch_size * self.world_size,) + tuple(x.shape[1:]), dtype=x.dtype,
                           device=x.device)
@@ -186,7 +189,7 @@ class PartialFC(Module):
         n_total = self.batch_size * self.world_size
         state, rowmax, rowsum = self.backend.local_stats(total_features, self.sub_weight, total_label,
                                                          self.margin_softmax)
-        if self.world_size > 1:
+        if self.world_size > 1 or _FORCE:
             gmax = rowmax.clone()
             dist.all_reduce(gmax, dist.ReduceOp.MAX)
             gsum = rowsum * torch.exp(rowmax - gmax)
@@ -196,11 +199,11 @@ class PartialFC(Module):
         ptarget, dx_total, dw = self.backend.local_grads(state, self.sub_weight, total_label,
                                                         self.margin_softmax, gmax, gsum, n_total,
                                                         self.eps_ls)
-        if self.world_size > 1:
+        if self.world_size > 1 or _FORCE:
             dist.all_reduce(ptarget, dist.ReduceOp.SUM)
         loss_v = ptarget.clamp_min(1e-30).log().mean() * (-1)
         self.sub_weight.grad = dw
-        if self.world_size > 1:
+        if self.world_size > 1 or _FORCE:
             x_grad = torch.zeros_like(features, dtype=torch.float32)
             dist.reduce_scatter(x_grad, list(dx_total.contiguous().chunk(self.world_size, dim=0)))
             x_grad = x_grad * self.world_size

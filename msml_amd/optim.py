@@ -14,6 +14,9 @@ import torch.distributed as dist
 from ._lib import call
 
 
+FORCE_COLLECTIVES = bool(__import__("os").environ.get("MSML_FORCE_DIST"))
+
+
 def reference_param_groups(model, batch_size, world_size, lr=0.1):
     """LR groups of the reference (train.py:153-178, conf.pretrained False): parameters whose
     name contains 'osb' train at 0.01/512*bs*W, everything else at lr/512*bs*W."""
@@ -70,7 +73,7 @@ class FlatSGD:
 
     def all_reduce_grads(self, world_size, bucket_bytes=64 << 20):
         """DDP gradient averaging on the flat arena: a few large all-reduces."""
-        if world_size == 1:
+        if world_size == 1 and not FORCE_COLLECTIVES:
             return
         n = self.flat_g.numel()
         step = bucket_bytes // 4
