@@ -214,6 +214,18 @@ long msml_gemm_splitk_workspace(int M, int coutp, int K);
 int msml_gemm_splitk(const void* a, int M, int K, const void* wp, int kop, float* out, int coutp,
                      void* workspace, long ws_bytes, int dtype, void* stream);
 
+/* Pack many weights (or sub-blocks of weights) in ONE launch.  table: device array of count x 16
+ * int64 {w, dst, Afull, Bfull, a_off, A, b_off, B, R, S, transpose, C1, C1p, C2, C2p, KOp}; every
+ * entry is packed as msml_pack_weight would pack the sub-block (a_off, A) x (b_off, B) of
+ * w[Afull][Bfull][R][S].  Used once per training step for the forward and backward-data operands
+ * of every conv / deconv / linear of the model. */
+int msml_pack_weights_batched(const long* table, int count, int dtype, void* stream);
+
+/* dst[c][r] = src[r][c] (storage dtype), dst rows ld_d long, zero-filled for r >= R.  Wn^T for the
+ * PartialFC dX GEMM (headers/partial_fc.py:169). */
+int msml_transpose(const void* src, int R, int C, int ld_s, void* dst, int ld_d, int dtype,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,8 +4,6 @@ The containers' own forward() is never called: all arithmetic goes through the C
 import torch.nn as nn
 
 from .. import functional as Fh
-from ..ops import pack_weight
-from .._lib import DTYPE_OF
 
 
 def conv(m, x0, x1=None, want_stats=False, c0=None, c1=0):
@@ -18,16 +16,8 @@ def conv(m, x0, x1=None, want_stats=False, c0=None, c1=0):
     assert m.groups == 1 and m.dilation == (1, 1) and m.stride[0] == m.stride[1]
     cfg = {"deconv": deconv, "c0": c0, "c1": c1, "cout": m.out_channels, "stride": m.stride[0],
            "pad_h": m.padding[0], "pad_w": m.padding[1], "want_stats": want_stats}
-    wp = None
-    if not m.weight.requires_grad or not m.training:
-        # inference: cache the packed weight until the parameter changes
-        key = (m.weight._version, m.weight.data_ptr(), x0.dtype)
-        cache = m.__dict__.get("_msml_wp")
-        if cache is None or cache[0] != key:
-            cache = (key, pack_weight(m.weight.detach(), deconv, c0, c1, DTYPE_OF[x0.dtype]))
-            m.__dict__["_msml_wp"] = cache
-        wp = cache[1]
-    return Fh.conv(x0, x1, m.weight, m.bias, cfg, wp)
+    # packed operands are cached / refreshed by ops.PACKS (keyed on parameter version)
+    return Fh.conv(x0, x1, m.weight, m.bias, cfg)
 
 
 def conv_bn(conv_m, bn_m, x0, x1=None, prelu=None, residual=None, c1=0, res_first=False):

@@ -85,6 +85,8 @@ class MSML(nn.Module):
             raise RuntimeError("msml_amd.MSML runs on an MI355X only (no CPU path); got a CPU tensor")
         if not self.use_osb:
             raise NotImplementedError("msml_amd: use_osb=False is not built")
+        from .. import ops
+        ops.PACKS.refresh_if_stale()      # one batched repack after a FlatSGD step
         xh = Fh.to_nhwc(x, BF16 if self.fp16 else F32)
         seg_list = self.osb(xh)                    # [seg0, seg1, seg2, seg3, seg5]
         final_seg = seg_list[4]

@@ -370,13 +370,23 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
 
 // ------------------------------------------------------------------ bias gradient ------------
 // db[c] = sum over pixels of dy[.., c]  (GCM convs carry a bias: backbones/osb/unet.py:23-30)
-__global__ void k_colsum_finalize(const float* __restrict__ partial, int rows, int C, int stride_q,
-                                  float* __restrict__ out, int Creal, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Creal) return;
-  double s = 0.0;
-  for (int r = 0; r < rows; r++) s += (double)partial[(long)r * stride_q * C + c];
-  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+__global__ void __launch_bounds__(1024) k_colsum_finalize(const float* __restrict__ partial, int rows, int C,
+                                                          int stride_q, float* __restrict__ out, int Creal,
+                                                          int accumulate) {
+  // rows of [stride_q][C]; quantity 0 is the column sum.  Same 32 x 32 layout as fin_reduce.
+  __shared__ double red[FIN_LANES][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double acc = 0.0;
+  if (c < Creal)
+    for (int r = ry; r < rows; r += FIN_LANES) acc += (double)partial[(long)r * stride_q * C + c];
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < Creal) {
+    double s = 0.0;
+    for (int y = 0; y < FIN_LANES; y++) s += red[y][cx];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+  }
 }
 
 extern "C" int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* db, int accumulate,
@@ -389,7 +399,7 @@ extern "C" int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* 
   MSML_DISPATCH_DTYPE(dtype, "bias_grad",
                       k_bn_stats<DT><<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace);)
   MSML_LAUNCH_OK("bias_grad");
-  k_colsum_finalize<<<cdiv(Creal, 128), 128, 0, st>>>(workspace, rows, Cp, 2, db, Creal, accumulate);
+  k_colsum_finalize<<<cdiv(Creal, 32), 1024, 0, st>>>(workspace, rows, Cp, 2, db, Creal, accumulate);
   MSML_LAUNCH_OK("bias_grad_finalize");
   return MSML_OK;
 }

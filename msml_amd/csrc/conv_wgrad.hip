@@ -217,21 +217,41 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(const WgradArgs p) {
 }
 
 // dst[a][boff + b][tap] = sum_split ws[split][a][tap][b]   (a < A, b < Breal)
+// 64 consecutive outputs x 4 split lanes per workgroup: coalesced 256-B reads, four independent
+// partial sums per output combined in a fixed order through LDS (deterministic).
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dst,
                                                       int splits, int arows, int taps, int vp, int A,
                                                       int Breal, int Btot, int boff, int accumulate) {
-  long total = (long)A * taps * vp;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    int b = (int)(i % vp);
-    long at = i / vp;
-    int tap = (int)(at % taps);
-    int a = (int)(at / taps);
-    if (b >= Breal) continue;
-    float sum = 0.f;
-    for (int sp = 0; sp < splits; sp++) sum += ws[(((long)sp * arows + a) * taps + tap) * vp + b];
-    long o = ((long)a * Btot + boff + b) * taps + tap;
-    dst[o] = accumulate ? dst[o] + sum : sum;
+  __shared__ float red[4][64];
+  const long total = (long)A * taps * vp;
+  const long slab = (long)arows * taps * vp;
+  const int ox = threadIdx.x & 63, sy = threadIdx.x >> 6;
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    const long i = base + ox;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < total) {
+      const float* p = ws + i;
+      int sp = sy;
+      for (; sp + 4 < splits; sp += 8) {
+        s0 += p[(long)sp * slab];
+        s1 += p[(long)(sp + 4) * slab];
+      }
+      if (sp < splits) s0 += p[(long)sp * slab];
+    }
+    red[sy][ox] = s0 + s1;
+    __syncthreads();
+    if (sy == 0 && i < total) {
+      const float sum = (red[0][ox] + red[1][ox]) + (red[2][ox] + red[3][ox]);
+      const int b = (int)(i % vp);
+      const long at = i / vp;
+      const int tap = (int)(at % taps);
+      const int a = (int)(at / taps);
+      if (b < Breal) {
+        const long o = ((long)a * Btot + boff + b) * taps + tap;
+        dst[o] = accumulate ? dst[o] + sum : sum;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -295,7 +315,7 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
                              a.chunk, st)) {
     MSML_LAUNCH_OK("conv_wgrad(fast)");
     long total = (long)A * taps * vp;
-    int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    int rgrid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
     k_wgrad_reduce<<<rgrid, 256, 0, st>>>(a.ws, dw, splits, up, taps, vp, A, Breal, Btot, boff, accumulate);
     MSML_LAUNCH_OK("conv_wgrad_reduce");
     return MSML_OK;
@@ -319,7 +339,7 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   }
   MSML_LAUNCH_OK("conv_wgrad");
   long total = (long)A * taps * vp;
-  int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  int rgrid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
   k_wgrad_reduce<<<rgrid, 256, 0, st>>>(a.ws, dw, splits, up, taps, vp, A, Breal, Btot, boff, accumulate);
   MSML_LAUNCH_OK("conv_wgrad_reduce");
   return MSML_OK;
@@ -352,7 +372,7 @@ extern "C" int msml_gemm_splitk(const void* a, int M, int K, const void* wp, int
              "gemm_splitk: shape not supported by the fast kernel");
   MSML_LAUNCH_OK("gemm_splitk");
   long total = (long)M * coutp;
-  int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  int rgrid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
   k_wgrad_reduce<<<rgrid, 256, 0, st>>>((const float*)workspace, out, ks, M, 1, coutp, M, coutp, coutp, 0, 0);
   MSML_LAUNCH_OK("gemm_splitk_reduce");
   return MSML_OK;

@@ -115,3 +115,86 @@ extern "C" int msml_pack_weight(const float* w, void* dst, int A, int B, int R, 
   MSML_LAUNCH_OK("pack_weight");
   return MSML_OK;
 }
+
+
+// ---------------------------------------------------------------- batched / sub-block packing -
+// One launch packs every weight of a model: desc[i] = 16 x int64
+//   {w, dst, Afull, Bfull, a_off, A, b_off, B, R, S, transpose, C1, C1p, C2, C2p, KOp}
+// (w, dst are device pointers).  The sub-block (a_off, A) x (b_off, B) of w[Afull][Bfull][R][S]
+// is packed exactly like msml_pack_weight packs a whole tensor, so backward-data packs of one
+// concat segment need no sliced copy of the parameter.
+template <typename T>
+__global__ void __launch_bounds__(256) k_pack_batched(const long* __restrict__ table, int count) {
+  const long* d = table + (long)blockIdx.y * 16;
+  const float* w = reinterpret_cast<const float*>(d[0]);
+  T* dst = reinterpret_cast<T*>(d[1]);
+  const int Bfull = (int)d[3], a_off = (int)d[4], A = (int)d[5], b_off = (int)d[6], B = (int)d[7];
+  const int R = (int)d[8], S = (int)d[9], transpose = (int)d[10];
+  const int C1 = (int)d[11], C1p = (int)d[12], C2 = (int)d[13], C2p = (int)d[14], KOp = (int)d[15];
+  const int K0 = (R * S * C1p + 31) / 32 * 32;
+  const int K1 = C2 > 0 ? (R * S * C2p + 31) / 32 * 32 : 0;
+  const int Ktot = K0 + K1;
+  const long total = (long)KOp * Ktot;
+  const int KO = transpose ? B : A;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int k = (int)(i % Ktot);
+    int ko = (int)(i / Ktot);
+    int seg = k >= K0;
+    int kk = seg ? k - K0 : k;
+    int cp = seg ? C2p : C1p;
+    int cn = seg ? C2 : C1;
+    int c = kk % cp;
+    int tap = kk / cp;
+    float v = 0.f;
+    if (ko < KO && tap < R * S && c < cn) {
+      int r = tap / S, s2 = tap % S;
+      int ci = c + (seg ? C1 : 0);
+      int a = (transpose ? ci : ko) + a_off;
+      int b = (transpose ? ko : ci) + b_off;
+      v = w[(((long)a * Bfull + b) * R + r) * S + s2];
+    }
+    store1<T>(dst + i, v);
+  }
+}
+
+extern "C" int msml_pack_weights_batched(const long* table, int count, int dtype, void* stream) {
+  MSML_CHECK(table && count > 0, MSML_ERR_SHAPE, "pack_weights_batched: bad args");
+  dim3 grid(192, count);
+  MSML_DISPATCH_DTYPE(dtype, "pack_weights_batched",
+                      k_pack_batched<DT><<<grid, 256, 0, (hipStream_t)stream>>>(table, count);)
+  MSML_LAUNCH_OK("pack_weights_batched");
+  return MSML_OK;
+}
+
+
+// ---------------------------------------------------------------- 2-D transpose ---------------
+// dst[c][r] = src[r][c] for r < R, c < C; dst rows are ld_d long and zero-filled for r in
+// [R, ld_d).  64 x 64 tiles through LDS (coalesced both ways).  Used for Wn^T of the PartialFC
+// dX GEMM (K = classes must be the contiguous dimension of the MFMA operand).
+template <typename T>
+__global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, int R, int C, int ld_s,
+                                                   T* __restrict__ dst, int ld_d) {
+  __shared__ T tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? src[(long)r * ld_s + c] : (T)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    int c = c0 + i, r = r0 + tx;
+    if (c < C && r < ld_d) dst[(long)c * ld_d + r] = tile[tx][i];
+  }
+}
+
+extern "C" int msml_transpose(const void* src, int R, int C, int ld_s, void* dst, int ld_d, int dtype,
+                              void* stream) {
+  MSML_CHECK(src && dst && R > 0 && C > 0 && ld_s >= C && ld_d >= R, MSML_ERR_SHAPE, "transpose: bad args");
+  dim3 grid(cdiv(ld_d, 64), cdiv(C, 64));
+  MSML_DISPATCH_DTYPE(dtype, "transpose",
+                      k_transpose<DT><<<grid, 256, 0, (hipStream_t)stream>>>((const DT*)src, R, C, ld_s, (DT*)dst,
+                                                                          ld_d);)
+  MSML_LAUNCH_OK("transpose");
+  return MSML_OK;
+}

@@ -46,7 +46,7 @@ class _Conv(torch.autograd.Function):
         r, s = weight.shape[2], weight.shape[3]
         dtype = DTYPE_OF[x0.dtype]
         if wp is None:
-            wp = ops.pack_weight(weight.detach(), deconv, c0, c1, dtype)
+            wp = ops.PACKS.get(weight, deconv, 0, weight.shape[0], 0, weight.shape[1], c0, c1, dtype)
         bp = None
         if bias is not None:
             bp = torch.zeros(cpad(cout), dtype=torch.float32, device=x0.device)
@@ -81,13 +81,12 @@ class _Conv(torch.autograd.Function):
         for i, (x, off, ci) in enumerate(((x0, 0, c0), (x1, c0, c1))):
             if x is None or not ctx.needs_input_grad[i]:
                 continue
-            ws = _slice_w(w, deconv, off, ci)
             if deconv:      # backward-data of a transposed conv = strided conv of dy
-                wp = ops.pack_weight(ws, False, cout, 0, dtype)
+                wp = ops.PACKS.get(w, False, off, ci, 0, cout, cout, 0, dtype)
                 grads[i], _ = ops.conv2d(dy, None, wp, None, cpad(ci), r, s, stride, ph, pw, False,
                                          p=h, q=wd, real=(cout, ci))
             else:           # backward-data of a conv = transposed gather of dy
-                wp = ops.pack_weight(ws, True, cout, 0, dtype)
+                wp = ops.PACKS.get(w, True, 0, cout, off, ci, cout, 0, dtype)
                 grads[i], _ = ops.conv2d(dy, None, wp, None, cpad(ci), r, s, stride, ph, pw, True,
                                          p=h, q=wd, real=(cout, ci))
         dw = None
@@ -376,7 +375,8 @@ class _CosMarginHead(torch.autograd.Function):
         demb = dw = None
         if ctx.needs_input_grad[0]:
             # dXn = dcos @ Wn : GEMM with K = classes -> weights packed transposed [E][Cp]
-            wnt = ops.pack_weight(wn[:c].float().reshape(c, e, 1, 1), True, c, 0, dtype)
+            wnt = torch.empty(e, ops.kpad(cp), dtype=tdt, device=dev)       # K padded to 32
+            call("msml_transpose", wn, c, e, e, wnt, ops.kpad(cp), dtype)
             dxn, _ = ops.conv2d(dcos, None, wnt, None, e, 1, 1, 1, 0, 0, False, out_dtype=F32)
             demb = torch.empty_like(emb)
             call("msml_rownorm_bwd", emb.detach().contiguous(), inv_x, dxn.reshape(b, e), e, b, e,

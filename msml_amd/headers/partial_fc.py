@@ -93,7 +93,9 @@ class HipBackend:
         ptarget = torch.empty(n, dtype=torch.float32, device=dev)
         call("msml_pfc_grad", cosm, cp, n, c, labels, kind, margin.s, margin.m, margin.a, margin.k,
              gmax, gsum, eps_ls, 1.0 / n_total, dcos, cp, ptarget, self.dtype)
-        wnt = ops.pack_weight(wn[:c].float().reshape(c, e, 1, 1), True, c, 0, self.dtype)
+        # Wn^T [E][Cp]: classes become the contiguous K of the dX GEMM
+        wnt = torch.empty(e, ops.kpad(cp), dtype=self.tdt, device=dev)     # K padded to 32
+        call("msml_transpose", wn, c, e, e, wnt, ops.kpad(cp), self.dtype)
         if self.dtype == 1:        # bf16: K = classes is huge and there are only 8 output tiles
             dx = ops.gemm_splitk(dcos.reshape(n, cp), wnt, e)
         else:

@@ -187,3 +187,77 @@ def gemm_splitk(a, wp, coutp):
     with PROFILE.rec("gemm_splitk", 2.0 * m * k * coutp):
         call("msml_gemm_splitk", a, m, k, wp, wp.shape[0], out, coutp, ws, ws.numel(), DTYPE_OF[a.dtype])
     return out
+
+
+class PackCache:
+    """Packed GEMM operands of every conv-like parameter, refreshed by ONE batched launch per
+    optimizer step instead of ~260 small pack kernels (and the sliced parameter copies the
+    backward-data packs needed).  Entries register themselves on first use; `refresh()` repacks
+    all of them; a use whose key (parameter version, WEIGHT_EPOCH, storage) is stale falls back
+    to an immediate single pack, so results never depend on refresh() having been called."""
+
+    def __init__(self):
+        self.entries = {}          # key -> dict(desc, dst, stamp)
+        self.table = None
+        self.order = []
+        self.last_epoch = -1
+
+    def clear(self):
+        self.__init__()
+
+    @staticmethod
+    def _stamp(w):
+        return (w._version, WEIGHT_EPOCH, w.data_ptr())
+
+    def get(self, w, transpose, a_off, a_n, b_off, b_n, c1, c2, dtype):
+        """Packed operand of the sub-block rows [a_off, a_off+a_n) x cols [b_off, b_off+b_n)."""
+        afull, bfull, r, s = w.shape
+        key = (w.data_ptr(), tuple(w.shape), transpose, a_off, a_n, b_off, b_n, c1, c2, dtype)
+        e = self.entries.get(key)
+        if e is None:
+            ko = b_n if transpose else a_n
+            kop = (cpad(ko) + tile_n(cpad(ko)) - 1) // tile_n(cpad(ko)) * tile_n(cpad(ko))
+            c1p, c2p = cpad(c1), cpad(c2) if c2 else 0
+            ktot = kpad(r * s * c1p) + (kpad(r * s * c2p) if c2 else 0)
+            dst = torch.empty(kop, ktot, dtype=TORCH_DTYPE[dtype], device=w.device)
+            desc = [0, dst.data_ptr(), afull, bfull, a_off, a_n, b_off, b_n, r, s, int(transpose), c1,
+                    c1p, c2, c2p, kop]
+            e = {"desc": desc, "dst": dst, "stamp": None, "w": w}
+            self.entries[key] = e
+            self.table = None
+        st = self._stamp(w)
+        if e["stamp"] != st:
+            e["desc"][0] = w.data_ptr()
+            t = torch.tensor([e["desc"]], dtype=torch.int64, device=w.device)
+            call("msml_pack_weights_batched", t, 1, dtype)
+            e["stamp"] = st
+        return e["dst"]
+
+    def refresh_if_stale(self):
+        if self.entries and self.last_epoch != WEIGHT_EPOCH:
+            self.refresh()
+
+    def refresh(self):
+        """Repack every registered operand in one launch (call after the optimizer step)."""
+        self.last_epoch = WEIGHT_EPOCH
+        if not self.entries:
+            return
+        ents = list(self.entries.values())
+        ptrs = tuple(e["w"].data_ptr() for e in ents)
+        dtype = DTYPE_OF[ents[0]["dst"].dtype]
+        if self.table is None or self.order != ptrs:
+            for e in ents:
+                e["desc"][0] = e["w"].data_ptr()
+            self.table = torch.tensor([e["desc"] for e in ents], dtype=torch.int64, device=ents[0]["dst"].device)
+            self.order = ptrs
+        if any(DTYPE_OF[e["dst"].dtype] != dtype for e in ents):
+            for e in ents:       # mixed precisions: fall back to lazy per-entry packing
+                e["stamp"] = None
+            return
+        call("msml_pack_weights_batched", self.table, len(ents), dtype)
+        for e in ents:
+            e["stamp"] = self._stamp(e["w"])
+
+
+WEIGHT_EPOCH = 0          # bumped by optimizers that update parameters behind torch's back
+PACKS = PackCache()

@@ -94,6 +94,8 @@ class FlatSGD:
                  float(g["lr"]), float(self.momentum), float(self.weight_decay),
                  int(self.steps == 0), clip)
         self.steps += 1
+        from . import ops
+        ops.WEIGHT_EPOCH += 1        # parameters changed behind torch's version counters
 
     def grad_norm(self):
         return self.norm_coef[0]
