@@ -257,7 +257,13 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 
 bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
                             int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int ba, int bb,
-                            int splits, int chunk, hipStream_t st);
+                            int ntw, int splits, int chunk, hipStream_t st);
+
+// taps handled by one workgroup of the bf16 fast kernel (narrow V operands share the U tile)
+static int wgrad_ntw(int vp, int taps) {
+  static const bool off = getenv("MSML_WGRAD_NO_MULTITAP") != nullptr;
+  return (!off && vp <= 64 && taps >= 3) ? 3 : 1;
+}
 
 static int pick_tile(int c) { return c > 64 ? 128 : 64; }
 
@@ -276,6 +282,8 @@ static int pick_splits(long mpix, int out_tiles) {
 extern "C" long msml_conv_wgrad_workspace(int up, int vp, int N, int P, int Q, int R, int S) {
   int ba = pick_tile(up), bb = pick_tile(vp);
   int tiles = cdiv(up, ba) * cdiv(vp, bb) * R * S;
+  int nt = wgrad_ntw(vp, R * S);                         // upper bound on splits for either dtype
+  if (nt > 1) tiles = cdiv(up, ba) * cdiv(R * S, nt);
   int splits = pick_splits((long)N * P * Q, tiles);
   return (long)splits * up * R * S * vp * (long)sizeof(float);
 }
@@ -306,13 +314,14 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   a.rcp_q = 1.0f / (float)Q;
   const int ba = pick_tile(up), bb = pick_tile(vp);
   const int atiles = cdiv(up, ba), btiles = cdiv(vp, bb), taps = R * S;
-  const int splits = pick_splits(a.Mpix, atiles * btiles * taps);
+  const int ntw = dtype == MSML_BF16 ? wgrad_ntw(vp, taps) : 1;
+  const int splits = pick_splits(a.Mpix, ntw > 1 ? atiles * cdiv(taps, ntw) : atiles * btiles * taps);
   a.chunk = (int)(((a.Mpix + splits - 1) / splits + 63) / 64 * 64);
   dim3 grid(atiles, btiles * taps, splits);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSML_BF16 && !getenv("MSML_NO_FAST_WGRAD") &&
-      msml_wgrad_fast_launch(u, up, v, vp, a.ws, N, H, W, P, Q, R, S, stride, pad_h, pad_w, ba, bb, splits,
-                             a.chunk, st)) {
+      msml_wgrad_fast_launch(u, up, v, vp, a.ws, N, H, W, P, Q, R, S, stride, pad_h, pad_w, ba, bb, ntw,
+                             splits, a.chunk, st)) {
     MSML_LAUNCH_OK("conv_wgrad(fast)");
     long total = (long)A * taps * vp;
     int rgrid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);

@@ -39,19 +39,23 @@ __device__ __forceinline__ void divmodf(int m, int d, float rcp, int& q, int& r)
   if (r >= d) { r -= d; q++; }
 }
 
-template <int BA, int BB>
+// NTW > 1 (narrow V, vp <= 64): the BB columns of the tile are NTW consecutive taps x 64
+// channels, so one U (dY) tile and its fragments serve NTW taps -- the 64-channel layers
+// otherwise run 4 MFMAs per wave per 16 KB stage and are barrier / traffic bound.
+template <int BA, int BB, int NTW>
 __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int GA = BA / 32, GB = BB / 32;             // 32-channel groups per operand
+  constexpr int GPT = GB / NTW;                         // V groups per tap
   constexpr int TM = BA / 64, TN = BB / 64;             // 32x32 MFMA tiles per wave (2x2 waves)
   constexpr int UBYTES = 64 * BA * 2, STAGE = 64 * (BA + BB) * 2;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int btiles = (p.vp + BB - 1) / BB;
+  const int btiles = NTW > 1 ? 1 : (p.vp + BB - 1) / BB;
   const int a0 = blockIdx.x * BA;
-  const int tap = blockIdx.y / btiles, b0 = (blockIdx.y % btiles) * BB;
-  const int r = tap / p.S, s = tap % p.S;
+  const int tap0 = (blockIdx.y / btiles) * NTW, b0 = (blockIdx.y % btiles) * BB;
+  const int taps = p.R * p.S;
   const int split = blockIdx.z;
   const long k_begin = (long)split * p.chunk;
   long k_end = k_begin + p.chunk;
@@ -75,8 +79,8 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
   }
 #pragma unroll
   for (int g = 0; g < GB; g++) {
-    int c = b0 + g * 32 + lc * 8;
-    voffc[g] = c < p.vp ? (unsigned int)c * 2u : OOB_OFFSET;
+    int c = b0 + (g % GPT) * 32 + lc * 8;
+    voffc[g] = (c < p.vp && tap0 + g / GPT < taps) ? (unsigned int)c * 2u : OOB_OFFSET;
   }
 
   auto gissue = [&](int stage, int buf) {
@@ -85,17 +89,25 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
     int n, rem, py, px;
     divmodf(in ? (int)m : 0, PQ, p.rcp_pq, n, rem);
     divmodf(rem, p.Q, p.rcp_q, py, px);
-    const int iy = py * p.stride - p.pad_h + r, ix = px * p.stride - p.pad_w + s;
-    const bool vok = in & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+    const int iy0 = py * p.stride - p.pad_h, ix0 = px * p.stride - p.pad_w;
     const unsigned int ubase = in ? (unsigned int)m * (unsigned int)(p.up * 2) : OOB_OFFSET;
-    const unsigned int vbase = vok ? (unsigned int)((n * p.H + iy) * p.W + ix) * (unsigned int)(p.vp * 2) : OOB_OFFSET;
+    unsigned int vbase[NTW];
+#pragma unroll
+    for (int tw = 0; tw < NTW; tw++) {
+      const int tp = tap0 + tw;
+      const int r = tp / p.S, s = tp - r * p.S;         // wave-uniform
+      const int iy = iy0 + r, ix = ix0 + s;
+      const bool vok = in & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      vbase[tw] = vok ? (unsigned int)((n * p.H + iy) * p.W + ix) * (unsigned int)(p.vp * 2) : OOB_OFFSET;
+    }
     char* ub = smem + buf * STAGE + wave * (GA * 1024);          // [pixel group][chan group][1 KB]
     char* vb = smem + buf * STAGE + UBYTES + wave * (GB * 1024);
     unsigned int ou[GA], ov[GB];
 #pragma unroll
     for (int g = 0; g < GA; g++) ou[g] = (ubase | uoffc[g]) >= OOB_OFFSET ? OOB_OFFSET : ubase + uoffc[g];
 #pragma unroll
-    for (int g = 0; g < GB; g++) ov[g] = (vbase | voffc[g]) >= OOB_OFFSET ? OOB_OFFSET : vbase + voffc[g];
+    for (int g = 0; g < GB; g++)
+      ov[g] = (vbase[g / GPT] | voffc[g]) >= OOB_OFFSET ? OOB_OFFSET : vbase[g / GPT] + voffc[g];
 #pragma unroll
     for (int g = 0; g < GA; g++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lptr_t)(ub + g * 1024), 16, ou[g], 0, 0, 0);
@@ -155,16 +167,17 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
   }
 
   const int h = lane >> 5, c32 = lane & 31;
-  const int taps = p.R * p.S;
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
     for (int j = 0; j < TN; j++) {
-      const int b = b0 + bcol0 + 32 * j + c32;
+      const int col = bcol0 + 32 * j + c32;             // column inside the BB-wide tile
+      const int tap = tap0 + col / (GPT * 32);
+      const int b = b0 + col % (GPT * 32);
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int a = a0 + arow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (a < p.arows && b < p.vp)
+        if (a < p.arows && b < p.vp && tap < taps)
           p.ws[(((long)split * p.arows + a) * taps + tap) * p.vp + b] = acc[i][j][e];
       }
     }
@@ -177,7 +190,7 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
 // Returns false when the tensors are too large for 32-bit buffer offsets.
 bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
                             int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int ba, int bb,
-                            int splits, int chunk, hipStream_t st) {
+                            int ntw, int splits, int chunk, hipStream_t st) {
   const long ub = (long)N * P * Q * up * 2, vb = (long)N * H * W * vp * 2;
   if (ub >= 0x7fffff00L || vb >= 0x7fffff00L) return false;
   WgradFastArgs a;
@@ -190,12 +203,18 @@ bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float*
   a.chunk = chunk;
   a.rcp_pq = 1.0f / (float)(P * Q);
   a.rcp_q = 1.0f / (float)Q;
+#define WF(BA_, BB_, NTW_) k_wgrad_fast<BA_, BB_, NTW_><<<grid, dim3(256), 2 * 64 * (BA_ + BB_) * 2, st>>>(a)
+  if (ntw == 3) {                                       // narrow V: 3 taps per workgroup
+    dim3 grid(cdiv(up, ba), cdiv(R * S, 3), splits);
+    if (ba == 128) WF(128, 192, 3);
+    else WF(64, 192, 3);
+    return true;
+  }
   dim3 grid(cdiv(up, ba), cdiv(vp, bb) * R * S, splits);
-#define WF(BA_, BB_) k_wgrad_fast<BA_, BB_><<<grid, dim3(256), 2 * 64 * (BA_ + BB_) * 2, st>>>(a)
-  if (ba == 128 && bb == 128) WF(128, 128);
-  else if (ba == 128) WF(128, 64);
-  else if (bb == 128) WF(64, 128);
-  else WF(64, 64);
+  if (ba == 128 && bb == 128) WF(128, 128, 1);
+  else if (ba == 128) WF(128, 64, 1);
+  else if (bb == 128) WF(64, 128, 1);
+  else WF(64, 64, 1);
 #undef WF
   return true;
 }
