@@ -56,7 +56,6 @@ class _Rec:
 
 
 PROFILE = _Profile()
-DETAIL = bool(os.environ.get("MSML_PROFILE_DETAIL"))   # per-shape names in the event profile
 
 # When True (set by msml_amd.optim.FlatSGD) the backward kernels add parameter gradients
 # straight into the pre-zeroed param.grad views of the flat arena and autograd gets None for
@@ -143,7 +142,7 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
     # algorithmic FLOP: 2*N*Cout*P*Q*Cin*R*S, deconv form 2*N*Cin*H*W*Cout*R*S
     pix = n * h * w if transposed else n * p * q
     name = "conv_igemm"
-    if DETAIL:
+    if PROFILE.on:
         name = "conv %s c%d+%d->%d %dx%d k%dx%d s%d n%d" % ("T" if transposed else "N", c0p, c1p, coutp, h, w, r, s, stride, n)
     with PROFILE.rec(name, 2.0 * pix * cin * cout * r * s):
         call("msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats, n, h, w, p,
@@ -170,7 +169,7 @@ def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accum
     need = _lib.value("msml_conv_wgrad_workspace", up, vp, n, p, q, r, s)
     ws = workspace(need, u.device)
     name = "conv_wgrad"
-    if DETAIL:
+    if PROFILE.on:
         name = "wgrad u%d v%d %dx%d k%dx%d s%d n%d" % (up, vp, p, q, r, s, stride, n)
     with PROFILE.rec(name, 2.0 * n * p * q * a * breal * r * s):
         call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
