@@ -44,8 +44,11 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="run the step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
+                    help="graph: replay ONE captured hipGraph per step; eager: issue the ~1300 launches "
+                         "from Python with weight-gradient kernels on a second stream; auto: time both "
+                         "during warm-up and keep the faster")
+    ap.add_argument("--no-graph", action="store_true", help="alias of --launch eager")
     return ap.parse_args()
 
 
@@ -193,6 +196,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from msml_amd import ops
+    if args.no_graph:
+        args.launch = "eager"
+    side_stream = torch.cuda.Stream()
     runner = (Trainer if args.mode == "train" else Inferer)(args, rank, local_rank, world)
 
     def barrier():
@@ -201,18 +207,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up (eager), then capture ONE step into a hipGraph (static input buffers, refreshed by
-    # a device copy before every replay): the step is ~1500 short launches and is host-bound
-    # when issued from Python one by one.
+    # Two ways to issue the step (~1300 launches):
+    #  graph -- captured once into a hipGraph (static input buffers refreshed by a device copy),
+    #           immune to host speed; the replay executes the captured work in one queue;
+    #  eager -- launches issued from Python, weight-gradient kernels on a second HIP stream so
+    #           that they fill the tails of the backward-data / BatchNorm chain.
+    # `auto` times a few untimed warm-up steps of each and keeps the faster one.
     graph = None
     static = None
-    if not args.no_graph:
+
+    osb_stream = torch.cuda.Stream()
+
+    def eager_mode(on):
+        ops.WGRAD_STREAM = side_stream if on else None
+        ops.OSB_STREAM = osb_stream if on else None
+
+    for _ in range(max(args.warmup, 2)):
+        runner.step()
+    torch.cuda.synchronize()
+    t_eager = None
+    if args.launch in ("auto", "eager"):
+        eager_mode(True)
+        runner.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            runner.step()
+        barrier()
+        t_eager = (time.perf_counter() - t0) / 3
+        eager_mode(False)
+    t_graph = None
+    if args.launch in ("auto", "graph"):
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(max(args.warmup, 2)):
-                    runner.step()
+                runner.step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             static = tuple(t.clone() for t in runner.next_batch())
@@ -222,15 +252,27 @@ def main():
             mode = "thread_local" if dist.is_initialized() else "global"
             with torch.cuda.graph(graph, capture_error_mode=mode):
                 out = runner.step(static)
+            graph.replay()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                graph.replay()
+            barrier()
+            t_graph = (time.perf_counter() - t0) / 3
         except Exception as e:                              # pragma: no cover (diagnostic path)
             import traceback
             traceback.print_exc()
             print("graph capture failed, running eagerly: %r" % (e,), file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
-    if graph is None:
-        for _ in range(args.warmup):
-            runner.step()
+    use_graph = graph is not None and (t_eager is None or t_graph <= t_eager)
+    if world > 1 and t_eager is not None and graph is not None:
+        flag = torch.tensor([1.0 if use_graph else 0.0], device="cuda")     # same choice on all ranks
+        dist.all_reduce(flag, dist.ReduceOp.MIN)
+        use_graph = bool(flag.item() > 0.5)
+    if not use_graph:
+        graph = None
+        eager_mode(True)
 
     def one_step():
         if graph is None:
@@ -240,8 +282,7 @@ def main():
         graph.replay()
         return out
 
-    for _ in range(2 if graph is not None else 0):
-        one_step()
+    one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -252,6 +293,7 @@ def main():
     # launch (events cannot be recorded inside a graph replay); kernel durations are unaffected
     prof = {}
     if not args.no_kernel_events:
+        eager_mode(False)             # serial stream: event pairs then bracket one kernel each
         ops.PROFILE.start()
         for _ in range(min(args.steps, 3)):
             runner.step()
@@ -278,7 +320,9 @@ def main():
                                % (args.frb, args.classes, args.batch,
                                   "fwd+bwd+clip+SGD" if args.mode == "train" else "orig+flip forward"),
                    "global_batch": args.batch * world, "parallelism": "dp%d+class-parallel head" % world,
-                   "launch": "hipGraph replay" if graph is not None else "eager"},
+                   "launch": "hipGraph replay" if graph is not None else "eager, weight gradients on a 2nd stream",
+                   "warmup_ms_per_step": {"eager": None if t_eager is None else round(t_eager * 1e3, 2),
+                                          "graph": None if t_graph is None else round(t_graph * 1e3, 2)}},
     }
     if args.mode == "train" and out[0] is not None:
         rec["loss"] = round(float(out[0]), 4)

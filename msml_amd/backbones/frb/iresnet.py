@@ -99,14 +99,17 @@ class IResNet(nn.Module):
                 if isinstance(m, IBasicBlock):
                     nn.init.constant_(m.bn2.weight, 0)
 
-    def forward(self, x, segs, ori=None):
+    def forward(self, x, segs, ori=None, wait_segs=None):
         """x: NHWC image; segs: [seg3, seg2, seg1, seg0] NHWC 18-channel maps (detached).
+        wait_segs: event after which `segs` are valid (OSB running on another stream).
         Returns (feature (B, dim) f32, kd)."""
         if ori is not None:
             raise NotImplementedError("msml_amd: `ori` (peer knowledge) is not built yet")
         x = conv_bn(self.conv1, self.bn1, x, prelu=self.prelu)
         for k in range(4):
             x = getattr(self, "layer%d" % (k + 1))(x)
+            if k == 0 and wait_segs is not None:
+                torch.cuda.current_stream().wait_event(wait_segs)
             x, _ = self.fm_ops[k](x, segs[k], None)
         x = Fh.bn_act(x, None, self.bn2)
         if self.dropout.p > 0 and self.training:

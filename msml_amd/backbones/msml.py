@@ -88,10 +88,24 @@ class MSML(nn.Module):
         from .. import ops
         ops.PACKS.refresh_if_stale()      # one batched repack after a FlatSGD step
         xh = Fh.to_nhwc(x, BF16 if self.fp16 else F32)
-        seg_list = self.osb(xh)                    # [seg0, seg1, seg2, seg3, seg5]
+        side = ops.OSB_STREAM
+        if side is None:
+            seg_list = self.osb(xh)                # [seg0, seg1, seg2, seg3, seg5]
+            osb_done = None
+        else:
+            # OSB on its own stream: its forward overlaps the FRB stem / layer1, its backward
+            # (autograd replays nodes on their forward stream) the whole FRB backward
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            xh.record_stream(side)
+            with torch.cuda.stream(side):
+                seg_list = self.osb(xh)
+                osb_done = side.record_event()
+            for t_ in seg_list:
+                t_.record_stream(main)
         final_seg = seg_list[4]
         segs = [seg_list[3], seg_list[2], seg_list[1], seg_list[0]]
-        feature, kd = self.frb(xh, segs, ori)
+        feature, kd = self.frb(xh, segs, ori, wait_segs=osb_done)
         if self.training:
             if label is None:
                 # head-less training return for the PartialFC path (train.py:283): the reference's

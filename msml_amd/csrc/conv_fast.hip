@@ -239,22 +239,30 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
     boff[kk] = (brow0 + r32) * 128 + (((kk * 2 + h) ^ swz128(brow0 + r32)) << 4);
   }
 
+  // fragment reads of step kk+1 are issued before the MFMAs of step kk (register double buffer)
   auto compute = [&](int buf) {
     const char* A = As + buf * ABYTES;
     const char* B = Bs + buf * BBYTES;
+    u32x4 a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) a[0][i] = *reinterpret_cast<const u32x4*>(A + aoff[0] + i * 4096);
+#pragma unroll
+    for (int j = 0; j < TN; j++) b[0][j] = *reinterpret_cast<const u32x4*>(B + boff[0] + j * 4096);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {                   // 4 x 16 k per 64-wide stage
-      u32x4 a[TM], b[TN];
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk + 1 < 4) {
 #pragma unroll
-      for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const u32x4*>(A + aoff[kk] + i * 4096);
+        for (int i = 0; i < TM; i++) a[nb][i] = *reinterpret_cast<const u32x4*>(A + aoff[kk + 1] + i * 4096);
 #pragma unroll
-      for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const u32x4*>(B + boff[kk] + j * 4096);
+        for (int j = 0; j < TN; j++) b[nb][j] = *reinterpret_cast<const u32x4*>(B + boff[kk + 1] + j * 4096);
+      }
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+              __builtin_bit_cast(bf16x8, a[cb][i]), __builtin_bit_cast(bf16x8, b[cb][j]), acc[i][j], 0, 0, 0);
     }
   };
 

@@ -93,6 +93,12 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             inplace = ops.INPLACE_GRADS and ctx.wparam.grad is not None
             dw = ctx.wparam.grad.view(w.shape) if inplace else torch.empty_like(w)
+            side = ops.WGRAD_STREAM if inplace else None
+            if side is not None:                       # dW has no consumer before the optimizer
+                side.wait_stream(torch.cuda.current_stream())
+                dy.record_stream(side)
+                ctxm = torch.cuda.stream(side)
+                ctxm.__enter__()
             for x, off, ci in ((x0, 0, c0), (x1, c0, c1)):
                 if x is None:
                     continue
@@ -102,6 +108,8 @@ class _Conv(torch.autograd.Function):
                 else:
                     ops.conv_wgrad(dy, x, dw, cout, ci, c0 + c1, off, r, s, stride, ph, pw,
                                    accumulate=inplace)
+            if side is not None:
+                ctxm.__exit__(None, None, None)
             if inplace:
                 dw = None
         db = None

@@ -153,13 +153,36 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
 _WS = {}
 
 
-def workspace(nbytes, device):
-    """Grow-only scratch buffer per device (stream-ordered reuse on the current stream)."""
-    buf = _WS.get(device)
+def workspace(nbytes, device, tag="main"):
+    """Grow-only scratch buffer per (device, tag); reuse is ordered by the stream that uses the
+    tag (the weight-gradient side stream has its own buffer)."""
+    key = (device, tag)
+    buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
+
+
+# Weight gradients have no consumer until the optimizer step, so their kernels can run on a
+# second HIP stream beside the backward-data / BatchNorm chain: the tail of one kernel (tile
+# counts rarely fill 256 CUs evenly) is filled by the other.  Enabled by FlatSGD (which joins the
+# stream before it reads the gradients); None = run everything on the current stream.
+WGRAD_STREAM = None
+# The OSB (segmentation branch) only feeds detached mask maps to the FRB (unet.py:225-230), so
+# its forward can run beside the FRB stem/layer1 and its backward beside the whole FRB backward.
+OSB_STREAM = None
+
+
+def wgrad_stream_join():
+    """Make the current stream wait for every side stream that may still be writing gradients."""
+    cur = torch.cuda.current_stream()
+    if OSB_STREAM is not None:
+        cur.wait_stream(OSB_STREAM)
+        if WGRAD_STREAM is not None:
+            WGRAD_STREAM.wait_stream(OSB_STREAM)
+    if WGRAD_STREAM is not None:
+        cur.wait_stream(WGRAD_STREAM)
 
 
 def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accumulate=False):
@@ -167,7 +190,7 @@ def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accum
     n, p, q, up = u.shape
     _, h, w, vp = v.shape
     need = _lib.value("msml_conv_wgrad_workspace", up, vp, n, p, q, r, s)
-    ws = workspace(need, u.device)
+    ws = workspace(need, u.device, "wgrad" if WGRAD_STREAM is not None else "main")
     name = "conv_wgrad"
     if PROFILE.on:
         name = "wgrad u%d v%d %dx%d k%dx%d s%d n%d" % (up, vp, p, q, r, s, stride, n)

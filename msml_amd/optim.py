@@ -64,6 +64,9 @@ class FlatSGD:
             g["lr"] = g["base_lr"] * factor
 
     def zero_grad(self):
+        from . import ops
+        if ops.WGRAD_STREAM is not None:     # the side stream must see the zeroed arena
+            ops.WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
         self.flat_g.zero_()
         base = self.flat_g.data_ptr()
         for p in self.params:        # re-attach the views if something replaced .grad
@@ -73,6 +76,8 @@ class FlatSGD:
 
     def all_reduce_grads(self, world_size, bucket_bytes=64 << 20):
         """DDP gradient averaging on the flat arena: a few large all-reduces."""
+        from . import ops
+        ops.wgrad_stream_join()
         if world_size == 1 and not FORCE_COLLECTIVES:
             return
         n = self.flat_g.numel()
@@ -82,6 +87,8 @@ class FlatSGD:
         self.flat_g.mul_(1.0 / world_size)
 
     def step(self):
+        from . import ops
+        ops.wgrad_stream_join()       # weight gradients may still be in flight on the side stream
         n = self.flat_g.numel()
         clip = None
         if self.max_norm is not None:

@@ -256,3 +256,34 @@ def test_partial_fc_bf16_vs_oracle():
     assert abs(loss.item() - loss_r.item()) < 1e-3 * abs(loss_r.item())
     assert rel_err(xg.cpu().numpy(), xg_r.numpy()) < 1e-2
     assert rel_err(p.sub_weight.grad.cpu().numpy(), ref.sub_weight.grad.numpy()) < 1e-2
+
+
+def test_side_streams_match_serial():
+    """Eager multi-stream issue (OSB on its own stream, weight gradients on a second stream)
+    gives bit-identical gradients to the single-stream order (same kernels, same inputs)."""
+    from msml_amd import ops
+    from msml_amd.optim import FlatSGD, reference_param_groups
+    x, msk = eval_inputs(2)
+    label = synthetic.labels(2, 50, seed=1)
+
+    def grads(streams):
+        m = hip_msml("iresnet18", 50, fp16=True).train()
+        opt = FlatSGD(reference_param_groups(m, 2, 1), 0.9, 5e-4, 5.0)
+        ops.WGRAD_STREAM = torch.cuda.Stream() if streams else None
+        ops.OSB_STREAM = torch.cuda.Stream() if streams else None
+        try:
+            for _ in range(2):
+                opt.zero_grad()
+                cls, seg, _ = m(x.cuda(), label.cuda())
+                loss = torch.nn.functional.cross_entropy(cls, label.cuda()) + \
+                    StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
+                loss.backward()
+                ops.wgrad_stream_join()
+            torch.cuda.synchronize()
+            return opt.flat_g.clone()
+        finally:
+            ops.WGRAD_STREAM = None
+            ops.OSB_STREAM = None
+    a = grads(False)
+    b = grads(True)
+    assert torch.equal(a, b)
