@@ -196,7 +196,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from msml_amd import ops
-    if args.no_graph:
+    if args.no_graph or (world > 1 and args.launch == "auto"):
+        # multi-rank: eager only -- capturing RCCL collectives into a hipGraph was verified with a
+        # one-rank communicator only, and a capture that fails mid-collective cannot be retried
         args.launch = "eager"
     side_stream = torch.cuda.Stream()
     runner = (Trainer if args.mode == "train" else Inferer)(args, rank, local_rank, world)
