@@ -65,10 +65,10 @@ INPLACE_GRADS = False
 
 
 def cpad(c):
-    """Storage channel count: 8 for tiny tensors (RGB input, gcm1's 8 maps), otherwise a
-    multiple of 32 so that every conv over the tensor takes the LDS-DMA fast path
-    (conv_fast.hip needs Cp % 32 == 0); pad channels hold exact zeros."""
-    return 8 if c <= 8 else (c + 31) // 32 * 32
+    """Storage channel count: a multiple of 32, so that every conv over the tensor (the RGB
+    stems included) takes the LDS-DMA fast path (conv_fast.hip needs Cp % 32 == 0); pad
+    channels hold exact zeros."""
+    return (c + 31) // 32 * 32
 
 
 def kpad(k):
