@@ -141,7 +141,7 @@ def cpu_baseline(args):
     """The CPU oracle's training step on a bounded sample (rank 0, N == 1)."""
     from msml_amd import synthetic
     from oracle import model as om
-    bs = 8
+    bs = 32
     torch.manual_seed(0)
     m = om.MSML(args.frb, "unet", (1, 1, 1, 1), 8, fm_params=(3, 2, "sigmoid", "mul"),
                 header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0))
@@ -171,7 +171,7 @@ def cpu_baseline(args):
     step()
     t0 = time.time()
     n = 0
-    while n < 2 or (time.time() - t0 < 12 and n < 6):
+    while n < 1 or (time.time() - t0 < 20 and n < 5):
         step()
         n += 1
     dt = time.time() - t0

@@ -43,6 +43,15 @@ struct ConvFastArgs {
   long split_stride;
 };
 
+// exact m / d, m % d for 0 <= m < 2^24 via a float reciprocal (integer division costs ~40
+// VALU instructions; the prologue decodes up to 8 rows per thread and K can be as short as 9 stages)
+__device__ __forceinline__ void fdivmod(int m, int d, int& q, int& r) {
+  q = (int)((float)m * (1.0f / (float)d));
+  r = m - q * d;
+  if (r < 0) { r += d; q--; }
+  if (r >= d) { r -= d; q++; }
+}
+
 #define OOB_OFFSET 0x7ffffff0u      // beyond any descriptor range: the DMA writes zeros
 
 __device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }   // 128-B rows
@@ -99,9 +108,9 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   // output row index (pixel in the full P x Q grid) of class-local row m
   auto out_pixel = [&](long m) -> long {
     if (!p.parity) return m;
-    int n = (int)(m / (Pc * Qc));
-    int rem = (int)(m - (long)n * (Pc * Qc));
-    int oyc = rem / Qc, oxc = rem - oyc * Qc;
+    int n, rem, oyc, oxc;
+    fdivmod((int)m, Pc * Qc, n, rem);
+    fdivmod(rem, Qc, oyc, oxc);
     return ((long)n * p.P + 2 * oyc + cy) * p.Q + 2 * oxc + cx;
   };
 
@@ -113,9 +122,9 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
     long m = m0 + row0 + i * RPP;
     const bool ok = m < Mc;
     int mm = ok ? (int)m : 0;
-    int n = mm / PQ;
-    int rem = mm - n * PQ;
-    int oy = rem / Qc, ox = rem - oy * Qc;
+    int n, rem, oy, ox;
+    fdivmod(mm, PQ, n, rem);
+    fdivmod(rem, Qc, oy, ox);
     if (p.parity) { oy = 2 * oy + cy; ox = 2 * ox + cx; }
     const int pb = n * p.H * p.W;
     if (p.transposed) {
@@ -409,6 +418,7 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   a.Ktot = 32 * (a.nsub[0] + a.nsub[1]);
   const long in0_bytes = (long)N * H * W * c0p * 2, in1_bytes = (long)N * H * W * c1p * 2;
   const long w_bytes = (long)kop * a.Ktot * 2;
+  if ((long)N * P * Q >= (1L << 24)) return false;      // float-reciprocal pixel decode
   if (in0_bytes >= 0x7fffff00L || in1_bytes >= 0x7fffff00L || w_bytes >= 0x7fffff00L) return false;
   a.in_bytes[0] = (unsigned int)in0_bytes;
   a.in_bytes[1] = (unsigned int)in1_bytes;
