@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "msml_hip.h")
-LIBPATH = os.path.join(_HERE, "libmsml_hip.so")
+LIBPATH = os.environ.get("MSML_LIB", os.path.join(_HERE, "libmsml_hip.so"))   # (override: kernel ablation builds)
 
 F32, BF16 = 0, 1
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}

@@ -282,9 +282,13 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
     for (int st = st0; st < stages; st++) {
       if (st + 1 < stages) {
         advance(st);
+#ifndef MSML_ABLATE_LOADS
         gissue(st + 1, cur ^ 1);
+#endif
       }
+#ifndef MSML_ABLATE_COMPUTE
       compute(cur);
+#endif
       __syncthreads();
       cur ^= 1;
     }
@@ -314,6 +318,9 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   // ---------------- epilogue (same contract as k_conv_igemm) -----------------------------------
   // bf16 results go through an LDS transpose tile [BM][BN + 8] and leave as 16-B row chunks;
   // f32 results (head logits) are stored directly.
+#ifdef MSML_ABLATE_EPILOGUE
+  if (p.M >= 0) return;
+#endif
   TOUT* outp = reinterpret_cast<TOUT*>(p.out) + (p.ksplits > 1 ? blockIdx.z * p.split_stride : 0);
   constexpr bool VIA_LDS = sizeof(TOUT) == 2;
   constexpr int OP = BN + 8;                           // tile pitch in elements
@@ -444,10 +451,11 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
     a.parity = ok ? 1 : 0;
   }
   // big tile only when it still fills the 256 CUs
-  static const bool use_big = getenv("MSML_CONV_BIG_TILE") != nullptr;
+  static const int use_big = getenv("MSML_CONV_BIG_TILE") ? atoi(getenv("MSML_CONV_BIG_TILE")) : 0;
   const bool big = use_big && bn == 128 && (long)cdiv(a.M, 256) * cdiv(coutp, 128) >= 256;
 #define FAST_CASE(TO)                                                   \
-  if (big) launch_fast<TO, 256, 128, 4, 2, 3>(a, st);                   \
+  if (big && use_big == 3) launch_fast<TO, 256, 128, 4, 2, 3>(a, st);   \
+  else if (big) launch_fast<TO, 256, 128, 4, 2, 2>(a, st);              \
   else if (bn == 128) launch_fast<TO, 128, 128, 2, 2, 2>(a, st);        \
   else if (bn == 64) launch_fast<TO, 256, 64, 4, 1, 2>(a, st);          \
   else launch_fast<TO, 256, 32, 4, 1, 2>(a, st);
