@@ -76,6 +76,8 @@ class Trainer:
         self.pfc = PartialFC(rank, local_rank, world, args.batch, False,
                              ArcMargin(64.0, 0.48, 0.0, 0.0), args.classes, fp16=fp16)
         self.opt = FlatSGD(reference_param_groups(self.model, args.batch, world), 0.9, 5e-4, 5.0)
+        if world > 1 or os.environ.get("MSML_FORCE_DIST"):
+            self.opt.enable_overlap(world)
         self.opt_pfc = FlatSGD([{"params": [self.pfc.sub_weight], "lr": 0.1 / 512 * args.batch * world}],
                                0.9, 5e-4, None)
         self.pfc.weight = self.pfc.sub_weight.data

@@ -112,6 +112,7 @@ class _Conv(torch.autograd.Function):
                 ctxm.__exit__(None, None, None)
             if inplace:
                 dw = None
+                ops.grad_ready(ctx.wparam)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[3]:
             m = dy.numel() // dy.shape[-1]
@@ -123,6 +124,7 @@ class _Conv(torch.autograd.Function):
             call("msml_bias_grad", dy, m, cp, cout, db, int(binplace), wsb, wsb.numel() // 4, dtype)
             if binplace:
                 db = None
+                ops.grad_ready(ctx.bparam)
         return grads[0], grads[1], dw, db, None, None
 
 
@@ -194,6 +196,8 @@ class _BnAct(torch.autograd.Function):
                  tg[0], tg[1], tg[2], int(inplace), m, c, ws, ws.numel() // 4, dtype)
         if ctx.res_first:
             dy = dres
+        if inplace:
+            ops.grad_ready(*[prm for w, prm in zip(want, (gamma, beta, alpha_p)) if w])
         return (dx, None,
                 pg[0] if want[0] and not inplace else None,
                 pg[1] if want[1] and not inplace else None,

@@ -174,6 +174,19 @@ WGRAD_STREAM = None
 OSB_STREAM = None
 
 
+# Optional callback `fn(param)` invoked by the backward functions right after they have enqueued
+# the kernel that completes param.grad (in-place mode): FlatSGD uses it to launch the bucketed
+# gradient all-reduce while the rest of the backward is still running.
+GRAD_READY = None
+
+
+def grad_ready(*params):
+    if GRAD_READY is not None:
+        for p in params:
+            if p is not None:
+                GRAD_READY(p)
+
+
 def wgrad_stream_join():
     """Make the current stream wait for every side stream that may still be writing gradients."""
     cur = torch.cuda.current_stream()

@@ -74,9 +74,72 @@ class FlatSGD:
             if p.grad is None or p.grad.data_ptr() != base + 4 * off:
                 p.grad = self.flat_g[off:off + p.numel()].view_as(p.data)
 
-    def all_reduce_grads(self, world_size, bucket_bytes=64 << 20):
-        """DDP gradient averaging on the flat arena: a few large all-reduces."""
+    # ---- gradient all-reduce overlapped with backward -------------------------------------
+    def enable_overlap(self, world_size, bucket_bytes=32 << 20):
+        """Bucket the arena (contiguous ranges of ~bucket_bytes) and all-reduce every bucket on
+        a communication stream as soon as the backward kernels of all its parameters have been
+        enqueued (ops.GRAD_READY callbacks from the in-place gradient path).  xGMI is a
+        point-to-point mesh: a few tens of MB per message keep every link busy without
+        serialising the tail of the backward behind one huge ring pass."""
         from . import ops
+        self.ov_world = world_size
+        self.comm = torch.cuda.Stream()
+        self.buckets = []          # [start, end, n_params]
+        self.bucket_of = {}
+        start, count, cur = 0, 0, 0
+        for p in self.params:
+            off = self.offsets[id(p)]
+            end = off + (p.numel() + 3) // 4 * 4
+            self.bucket_of[id(p)] = len(self.buckets)
+            count += 1
+            cur = end
+            if (cur - start) * 4 >= bucket_bytes:
+                self.buckets.append([start, cur, count])
+                start, count = cur, 0
+        if count:
+            self.buckets.append([start, cur, count])
+        self.pending = [b[2] for b in self.buckets]
+        self.fired = [False] * len(self.buckets)
+        self.works = []
+        ops.GRAD_READY = self._grad_ready
+
+    def _fire(self, bi):
+        from . import ops
+        self.fired[bi] = True
+        s, e, _ = self.buckets[bi]
+        cur = torch.cuda.current_stream()
+        self.comm.wait_stream(cur)
+        for st in (ops.WGRAD_STREAM, ops.OSB_STREAM):
+            if st is not None:
+                self.comm.wait_stream(st)
+        with torch.cuda.stream(self.comm):
+            self.works.append(dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _grad_ready(self, p):
+        bi = self.bucket_of.get(id(p))
+        if bi is None or self.fired[bi]:
+            return
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0:
+            self._fire(bi)
+
+    def all_reduce_grads(self, world_size, bucket_bytes=64 << 20):
+        """DDP gradient averaging on the flat arena: a few large all-reduces (overlapped with
+        the backward when enable_overlap() was called, otherwise issued here)."""
+        from . import ops
+        if getattr(self, "buckets", None) is not None:
+            for bi in range(len(self.buckets)):          # parameters that never reported
+                if not self.fired[bi]:
+                    self._fire(bi)
+            for w in self.works:
+                w.wait()
+            torch.cuda.current_stream().wait_stream(self.comm)
+            ops.wgrad_stream_join()
+            self.flat_g.mul_(1.0 / self.ov_world)
+            self.pending = [b[2] for b in self.buckets]
+            self.fired = [False] * len(self.buckets)
+            self.works = []
+            return
         ops.wgrad_stream_join()
         if world_size == 1 and not FORCE_COLLECTIVES:
             return

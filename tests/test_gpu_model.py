@@ -287,3 +287,50 @@ def test_side_streams_match_serial():
     a = grads(False)
     b = grads(True)
     assert torch.equal(a, b)
+
+
+def test_overlapped_allreduce_one_rank():
+    """Bucketed gradient all-reduce overlapped with backward (RCCL, one-rank communicator):
+    every bucket fires exactly once and the gradients equal the non-overlapped path."""
+    import os
+    import torch.distributed as dist
+    from msml_amd import ops
+    from msml_amd.optim import FlatSGD, reference_param_groups
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    x, msk = eval_inputs(2)
+    label = synthetic.labels(2, 50, seed=1)
+
+    def grads(overlap):
+        m = hip_msml("iresnet18", 50, fp16=True).train()
+        opt = FlatSGD(reference_param_groups(m, 2, 1), 0.9, 5e-4, 5.0)
+        ops.GRAD_READY = None
+        if overlap:
+            opt.enable_overlap(1, bucket_bytes=8 << 20)
+        ops.WGRAD_STREAM = torch.cuda.Stream()
+        ops.OSB_STREAM = torch.cuda.Stream()
+        try:
+            for _ in range(2):
+                opt.zero_grad()
+                cls, seg, _ = m(x.cuda(), label.cuda())
+                loss = torch.nn.functional.cross_entropy(cls, label.cuda()) + \
+                    StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
+                loss.backward()
+                if overlap:
+                    assert sum(opt.fired) >= len(opt.buckets) - 1     # fired during backward
+                    opt.all_reduce_grads(1)
+                else:
+                    ops.wgrad_stream_join()
+            torch.cuda.synchronize()
+            return opt.flat_g.clone(), (len(opt.buckets) if overlap else 0)
+        finally:
+            ops.WGRAD_STREAM = None
+            ops.OSB_STREAM = None
+            ops.GRAD_READY = None
+    a, _ = grads(False)
+    b, nb = grads(True)
+    assert nb >= 4
+    assert torch.equal(a, b)
+    dist.destroy_process_group()
