@@ -114,14 +114,11 @@ class IResNet(nn.Module):
         x = Fh.bn_act(x, None, self.bn2)
         if self.dropout.p > 0 and self.training:
             raise NotImplementedError("msml_amd: dropout > 0 is not built (reference config uses 0)")
-        # flatten(C,H,W) + Linear(25088, 512) == a 7x7 'valid' window over the NHWC map
+        # flatten(C,H,W) + Linear(25088, 512): skinny GEMM on the NHWC-ordered operand
         n, h, w, c = x.shape
         wview = self.fc.weight.view(self.fc.out_features, c, h, w)
-        cfg = {"deconv": False, "c0": c, "c1": 0, "cout": self.fc.out_features, "stride": 1,
-               "pad_h": 0, "pad_w": 0, "want_stats": self.features.training,
-               "grad_param": self.fc.weight}
-        y, stats = Fh.conv(x, None, wview, self.fc.bias, cfg)
-        y = Fh.bn_act(y, stats, self.features)
+        y = Fh.flat_fc(x, wview, self.fc.bias, self.fc.weight)
+        y = Fh.bn_act(y, None, self.features)
         return Fh.to_vec(y, self.fc.out_features), 0.0
 
 

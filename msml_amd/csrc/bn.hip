@@ -103,10 +103,26 @@ __device__ __forceinline__ void fin_reduce(const float* __restrict__ partial, in
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = 0.0;
-  if (cok)
-    for (int r = ry; r < rows; r += FIN_LANES)
+  if (cok) {
+    // four independent load streams per thread (the loop is latency-bound: up to 6272 rows)
+    double a1[NQ], a2[NQ], a3[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) a1[q] = a2[q] = a3[q] = 0.0;
+    int r = ry;
+    for (; r + 3 * FIN_LANES < rows; r += 4 * FIN_LANES)
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        acc[q] += (double)partial[((long)r * NQ + q) * C + c];
+        a1[q] += (double)partial[((long)(r + FIN_LANES) * NQ + q) * C + c];
+        a2[q] += (double)partial[((long)(r + 2 * FIN_LANES) * NQ + q) * C + c];
+        a3[q] += (double)partial[((long)(r + 3 * FIN_LANES) * NQ + q) * C + c];
+      }
+    for (; r < rows; r += FIN_LANES)
 #pragma unroll
       for (int q = 0; q < NQ; q++) acc[q] += (double)partial[((long)r * NQ + q) * C + c];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = (acc[q] + a1[q]) + (a2[q] + a3[q]);
+  }
 #pragma unroll
   for (int q = 0; q < NQ; q++) red[ry][q][cx] = acc[q];
   __syncthreads();

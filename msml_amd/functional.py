@@ -468,3 +468,71 @@ class _Normalize(torch.autograd.Function):
 
 def normalize(x):
     return _Normalize.apply(x)
+
+
+class _FlatFc(torch.autograd.Function):
+    """flatten(C,H,W) + Linear(C*H*W -> E) on an NHWC map (backbones/frb/iresnet.py:230-232).
+
+    The packed operand of the equivalent HxW 'valid' window conv is exactly the Linear weight with
+    its columns in NHWC flatten order, so forward is a skinny GEMM (M = batch, K = 25 088) run
+    with split-K, backward-data a plain GEMM against the transposed operand (the window-conv
+    formulation would visit 49 taps per output pixel with one valid), and the weight gradient the
+    window wgrad that writes straight into the parameter's (E, C, H, W) layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, grad_param):
+        n, h, w, c = x.shape
+        e = weight.shape[0]
+        dtype = DTYPE_OF[x.dtype]
+        wp = ops.PACKS.get(weight, False, 0, e, 0, c, c, 0, dtype)           # [E][H*W*C]
+        xf = x.reshape(n, h * w * c)
+        if dtype == BF16:
+            y = ops.gemm_splitk(xf, wp, cpad(e))
+        else:
+            y, _ = ops.conv2d(x, None, wp, None, cpad(e), h, w, 1, 0, 0, False, out_dtype=F32)
+            y = y.reshape(n, cpad(e))
+        y = y[:, :e] + bias.detach()
+        ctx.save_for_backward(x, weight, bias)
+        ctx.grad_param = grad_param
+        ctx.wp = wp
+        return y.to(x.dtype).reshape(n, 1, 1, e)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        n, h, w, c = x.shape
+        e = weight.shape[0]
+        dtype = DTYPE_OF[x.dtype]
+        dy = dy.contiguous()
+        k = h * w * c
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if dtype == BF16:
+                wpt = torch.empty(k, ops.kpad(e), dtype=x.dtype, device=x.device)   # [H*W*C][E]
+                call("msml_transpose", ctx.wp, e, k, k, wpt, ops.kpad(e), dtype)
+                dxf, _ = ops.conv2d(dy, None, wpt, None, k, 1, 1, 1, 0, 0, False, real=(e, k))
+                dx = dxf.reshape(n, h, w, c)
+            else:
+                wt = ops.PACKS.get(weight, True, 0, e, 0, c, e, 0, dtype)
+                dx, _ = ops.conv2d(dy, None, wt, None, c, h, w, 1, 0, 0, True, p=h, q=w, real=(e, c))
+        gp = ctx.grad_param
+        inplace = ops.INPLACE_GRADS and gp.grad is not None
+        dw = gp.grad.view(weight.shape) if inplace else torch.empty_like(weight)
+        ops.conv_wgrad(dy, x, dw, e, c, c, 0, h, w, 1, 0, 0, accumulate=inplace)
+        binplace = ops.INPLACE_GRADS and bias.grad is not None
+        rows = ops.bn_stats_rows(n, e)
+        wsb = ops.workspace(rows * 2 * e * 4, dy.device)
+        db = bias.grad if binplace else torch.empty(e, dtype=torch.float32, device=dy.device)
+        call("msml_bias_grad", dy, n, e, e, db, int(binplace), wsb, wsb.numel() // 4, dtype)
+        if binplace:
+            ops.grad_ready(bias)
+            db = None
+        if inplace:
+            ops.grad_ready(gp)
+            dw = None
+        return dx, dw, db, None
+
+
+def flat_fc(x, weight4d, bias, grad_param):
+    """x: NHWC [N,H,W,C]; weight4d: the Linear weight viewed as (E, C, H, W)."""
+    return _FlatFc.apply(x, weight4d, bias, grad_param)
