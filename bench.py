@@ -324,7 +324,8 @@ def main():
                                % (args.frb, args.classes, args.batch,
                                   "fwd+bwd+clip+SGD" if args.mode == "train" else "orig+flip forward"),
                    "global_batch": args.batch * world, "parallelism": "dp%d+class-parallel head" % world,
-                   "launch": "hipGraph replay" if graph is not None else "eager, weight gradients on a 2nd stream",
+                   "launch": ("hipGraph replay" if graph is not None else
+                              "eager, weight gradients + OSB on side streams" if args.mode == "train" else "eager"),
                    "warmup_ms_per_step": {"eager": None if t_eager is None else round(t_eager * 1e3, 2),
                                           "graph": None if t_graph is None else round(t_graph * 1e3, 2)}},
     }

@@ -226,6 +226,18 @@ int msml_pack_weights_batched(const long* table, int count, int dtype, void* str
 int msml_transpose(const void* src, int R, int C, int ld_s, void* dst, int ld_d, int dtype,
                    void* stream);
 
+/* Inference conv with the eval-mode BatchNorm folded into the epilogue (bf16 tensors only):
+ *   res_first == 0: out = prelu(acc*scale[c] + shift[c], alpha[c]) + residual   (IBasicBlock)
+ *   res_first == 1: out = prelu(acc*scale[c] + shift[c] + residual, alpha[c])   (resblock_bottle)
+ * scale/shift from msml_bn_finalize(rows = 0); alpha, residual optional.  Replaces the
+ * conv -> BatchNorm(eval) -> PReLU -> (+identity) chains of backbones/frb/iresnet.py:59-66,
+ * backbones/fm/fmoperator.py:55-67 in eval mode (eval/verification.py:271). */
+int msml_conv2d_fused(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
+                      const float* scale, const float* shift, const float* alpha,
+                      const void* residual, int res_first, void* out, int coutp, int N, int H,
+                      int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
+                      int transposed, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

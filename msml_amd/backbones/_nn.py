@@ -1,6 +1,7 @@
 """Glue between torch parameter containers (nn.Conv2d, nn.BatchNorm2d, nn.PReLU ... kept so
 that names, shapes and initialisation equal the reference's) and the HIP autograd functions.
 The containers' own forward() is never called: all arithmetic goes through the C ABI."""
+import torch
 import torch.nn as nn
 
 from .. import functional as Fh
@@ -21,6 +22,12 @@ def conv(m, x0, x1=None, want_stats=False, c0=None, c1=0):
 
 
 def conv_bn(conv_m, bn_m, x0, x1=None, prelu=None, residual=None, c1=0, res_first=False):
-    """conv -> BatchNorm (-> PReLU) (+ residual); BN statistics come from the conv epilogue."""
+    """conv -> BatchNorm (-> PReLU) (+ residual); BN statistics come from the conv epilogue.
+    Inference (eval mode, bf16, no autograd): BatchNorm / PReLU / residual are folded into the
+    conv epilogue (one kernel, no intermediate tensor)."""
+    if (not bn_m.training and not torch.is_grad_enabled() and x0.dtype == torch.bfloat16
+            and conv_m.bias is None and not isinstance(conv_m, nn.ConvTranspose2d)
+            and conv_m.out_channels % 32 == 0):
+        return Fh.conv_bn_eval(x0, x1, conv_m, bn_m, prelu, residual, c1, res_first)
     y, stats = conv(conv_m, x0, x1, want_stats=bn_m.training, c1=c1)
     return Fh.bn_act(y, stats, bn_m, prelu, residual, res_first)

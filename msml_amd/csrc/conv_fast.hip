@@ -34,6 +34,12 @@ struct ConvFastArgs {
   void* out;
   int coutp;
   const float* bias;
+  // inference epilogue fusion (eval-mode BatchNorm folded in): out = [prelu](acc * scale + bias
+  // [+ residual]) [+ residual]; scale == nullptr -> 1
+  const float* scale;
+  const float* alpha;
+  const unsigned short* residual;
+  int res_first;
   float* stats;
   long M;
   int tiles_m;
@@ -332,6 +338,9 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
     const int col = n0 + lcol;
     const bool cok = col < p.coutp;
     const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+    const float sv = (p.scale && cok) ? p.scale[col] : 1.f;
+    const bool act_here = p.alpha && !(p.residual && p.res_first);
+    const float av = (act_here && cok) ? p.alpha[col] : 1.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
@@ -339,7 +348,8 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
       for (int e = 0; e < 16; e++) {
         int row = arow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         long m = m0 + row;
-        float v = acc[i][j][e] + bv;
+        float v = acc[i][j][e] * sv + bv;
+        if (act_here) v = v > 0.f ? v : v * av;
         if (VIA_LDS) otile[row * OP + lcol] = f2bf(v);
         if (m < Mc && cok) {
           if (!VIA_LDS) store1<TOUT>(outp + out_pixel(m) * p.coutp + col, v);
@@ -360,7 +370,19 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
       int col = n0 + c8 * 8;
       if (m < Mc && col < p.coutp) {
         u32x4 v = *reinterpret_cast<const u32x4*>(otile + row * OP + c8 * 8);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + out_pixel(m) * p.coutp + col) = v;
+        const long o = out_pixel(m) * p.coutp + col;
+        if (p.residual) {                              // fused residual (+ PReLU after it)
+          Vec8 a = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v));
+          Vec8 r = load8<unsigned short>(p.residual + o);
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            float z = a.v[q] + r.v[q];
+            if (p.res_first && p.alpha) z = z > 0.f ? z : z * p.alpha[col + q];
+            a.v[q] = z;
+          }
+          store8<unsigned short>(reinterpret_cast<unsigned short*>(&v), a);
+        }
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + o) = v;
       }
     }
   }
@@ -411,8 +433,10 @@ static void launch_fast(ConvFastArgs& a, hipStream_t st) {
 bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
-                             int transposed, int in_dtype, int out_dtype, int bn, hipStream_t st) {
+                             int transposed, int in_dtype, int out_dtype, int bn, hipStream_t st,
+                             const float* scale, const float* alpha, const void* residual, int res_first) {
   if (in_dtype != MSML_BF16) return false;
+  if ((scale || alpha || residual) && out_dtype != MSML_BF16) return false;
   if (c0p % 32 != 0 || (in1 && c1p % 32 != 0)) return false;
   ConvFastArgs a;
   a.in[0] = (const unsigned short*)in0;
@@ -435,6 +459,7 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   a.stride_shift = stride == 1 ? 0 : (stride == 2 ? 1 : 2);
   a.pad_h = pad_h; a.pad_w = pad_w; a.transposed = transposed;
   a.wp = (const unsigned short*)wp; a.out = out; a.coutp = coutp; a.bias = bias; a.stats = stats;
+  a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual; a.res_first = res_first;
   a.M = (long)N * P * Q;
   a.ksplits = 1;
   a.split_stride = 0;
@@ -485,6 +510,7 @@ bool msml_conv_fast_splitk(const void* in0, int c0p, const void* wp, int kop, fl
   a.N = N; a.H = 1; a.W = 1; a.P = 1; a.Q = 1; a.R = 1; a.S = 1;
   a.stride = 1; a.stride_shift = 0; a.pad_h = 0; a.pad_w = 0; a.transposed = 0;
   a.wp = (const unsigned short*)wp; a.out = ws; a.coutp = coutp; a.bias = nullptr; a.stats = nullptr;
+  a.scale = nullptr; a.alpha = nullptr; a.residual = nullptr; a.res_first = 0;
   a.M = N;
   a.parity = 0;
   a.ksplits = ksplits;

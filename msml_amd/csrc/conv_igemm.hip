@@ -309,7 +309,8 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
-                             int transposed, int in_dtype, int out_dtype, int bn, hipStream_t st);
+                             int transposed, int in_dtype, int out_dtype, int bn, hipStream_t st,
+                             const float* scale, const float* alpha, const void* residual, int res_first);
 
 extern "C" int msml_conv_tile_m(int coutp) { return coutp <= 64 ? 256 : 128; }
 extern "C" int msml_conv_tile_n(int coutp) { return coutp <= 32 ? 32 : (coutp <= 64 ? 64 : 128); }
@@ -354,7 +355,8 @@ extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, c
   hipStream_t st = (hipStream_t)stream;
   if ((out_dtype == MSML_BF16 || out_dtype == MSML_F32) && !getenv("MSML_NO_FAST_CONV") &&
       msml_conv_fast_dispatch(in0, c0p, in1, c1p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R,
-                              S, stride, pad_h, pad_w, transposed, in_dtype, out_dtype, bn, st)) {
+                              S, stride, pad_h, pad_w, transposed, in_dtype, out_dtype, bn, st, nullptr, nullptr,
+                              nullptr, 0)) {
     MSML_LAUNCH_OK("conv2d(fast)");
     return MSML_OK;
   }
@@ -371,5 +373,25 @@ extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, c
   }
 #undef CONV_CASE
   MSML_LAUNCH_OK("conv2d");
+  return MSML_OK;
+}
+
+
+// Inference variant with the eval-mode BatchNorm (+ PReLU, + residual) folded into the conv
+// epilogue (bf16 fast path only; see msml_hip.h).
+extern "C" int msml_conv2d_fused(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
+                                 const float* scale, const float* shift, const float* alpha,
+                                 const void* residual, int res_first, void* out, int coutp, int N, int H,
+                                 int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
+                                 int transposed, void* stream) {
+  MSML_CHECK(in0 && wp && out && shift, MSML_ERR_SHAPE, "conv2d_fused: null pointer");
+  MSML_CHECK(c0p % 32 == 0 && c1p % 32 == 0 && coutp % 8 == 0, MSML_ERR_SHAPE, "conv2d_fused: channel padding");
+  const int bn = msml_conv_tile_n(coutp);
+  MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_fused: packed weight rows");
+  MSML_CHECK(msml_conv_fast_dispatch(in0, c0p, in1, c1p, wp, kop, shift, out, coutp, nullptr, N, H, W, P, Q,
+                                     R, S, stride, pad_h, pad_w, transposed, MSML_BF16, MSML_BF16, bn,
+                                     (hipStream_t)stream, scale, alpha, residual, res_first),
+             MSML_ERR_UNSUPPORTED, "conv2d_fused: shape not supported by the fast kernel");
+  MSML_LAUNCH_OK("conv2d_fused");
   return MSML_OK;
 }

@@ -536,3 +536,44 @@ class _FlatFc(torch.autograd.Function):
 def flat_fc(x, weight4d, bias, grad_param):
     """x: NHWC [N,H,W,C]; weight4d: the Linear weight viewed as (E, C, H, W)."""
     return _FlatFc.apply(x, weight4d, bias, grad_param)
+
+
+def _eval_bn_coef(bn_m, c):
+    """(scale, shift) of an eval-mode BatchNorm, cached on the module until a parameter, a running
+    statistic or the flat weight arena changes."""
+    stamp = (bn_m.weight._version, bn_m.bias._version, bn_m.running_mean._version,
+             bn_m.running_var._version, ops.WEIGHT_EPOCH, bn_m.weight.data_ptr())
+    hit = getattr(bn_m, "_msml_eval_coef", None)
+    if hit is None or hit[0] != stamp:
+        coef = torch.empty(2, c, dtype=torch.float32, device=bn_m.weight.device)
+        call("msml_bn_finalize", None, 0, c, 0.0, bn_m.weight, bn_m.bias, bn_m.running_mean,
+             bn_m.running_var, 0.1, bn_m.eps, coef[0], coef[1], None, None)
+        hit = (stamp, coef)
+        bn_m._msml_eval_coef = hit
+    return hit[1]
+
+
+def conv_bn_eval(x0, x1, conv_m, bn_m, prelu, residual, c1, res_first):
+    """Inference: conv with eval-mode BatchNorm (+PReLU, +residual) folded into its epilogue
+    (msml_conv2d_fused).  bf16 NHWC tensors, no autograd graph."""
+    n, h, w, c0p = x0.shape
+    cin, cout = conv_m.in_channels, conv_m.out_channels
+    c0 = cin - c1
+    r, s = conv_m.kernel_size
+    stride, (ph, pw) = conv_m.stride[0], conv_m.padding
+    coutp = cpad(cout)
+    assert coutp == cout == bn_m.num_features
+    wp = ops.PACKS.get(conv_m.weight, False, 0, cout, 0, cin, c0, c1, BF16)
+    coef = _eval_bn_coef(bn_m, coutp)
+    p = ops.conv_out_size(h, r, stride, ph, False)
+    q = ops.conv_out_size(w, s, stride, pw, False)
+    c1p = 0 if x1 is None else x1.shape[3]
+    out = torch.empty(n, p, q, coutp, dtype=torch.bfloat16, device=x0.device)
+    name = "conv_fused"
+    if ops.PROFILE.on:
+        name = "conv N+bn c%d+%d->%d %dx%d k%dx%d s%d n%d" % (c0p, c1p, coutp, h, w, r, s, stride, n)
+    with ops.PROFILE.rec(name, 2.0 * n * p * q * cin * cout * r * s):
+        call("msml_conv2d_fused", x0, c0p, x1, c1p, wp, wp.shape[0], coef[0], coef[1],
+             prelu.weight if prelu is not None else None, residual, int(res_first), out, coutp,
+             n, h, w, p, q, r, s, stride, ph, pw, 0)
+    return out

@@ -217,3 +217,45 @@ def test_conv1x1_s2_dgrad_bf16(h):
     got = ops.to_nchw(dx, cin).cpu().double()
     assert (got - x.grad).abs().max().item() <= 1e-2 * x.grad.abs().max().item()
     assert (got[:, :, 1::2, :] == 0).all() and (got[:, :, :, 1::2] == 0).all()
+
+
+@pytest.mark.parametrize("res_first", [False, True])
+@pytest.mark.parametrize("shape", [(64, 0, 64, 14, 3, 1, 1), (64, 0, 128, 14, 3, 2, 1), (64, 18, 64, 9, 3, 1, 1),
+                                   (128, 0, 64, 7, 1, 1, 0), (3, 0, 64, 28, 3, 1, 1)])
+def test_conv_fused_eval_bn(shape, res_first):
+    """msml_conv2d_fused (inference epilogue: eval BatchNorm + PReLU + residual in both orders)
+    against torch CPU conv2d -> affine -> prelu / residual in f32."""
+    c1, c2, cout, h, k, stride, pad = shape
+    torch.manual_seed(5)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x1 = bf(torch.randn(3, c1, h, h))
+    x2 = bf(torch.randn(3, c2, h, h)) if c2 else None
+    w = bf(torch.randn(cout, c1 + c2, k, k) * (1.0 / ((c1 + c2) * k * k)) ** 0.5)
+    scale = torch.rand(cout) + 0.5
+    shift = torch.randn(cout) * 0.3
+    alpha = torch.rand(cout) * 0.5
+    ref = F.conv2d(torch.cat([x1, x2], 1) if c2 else x1, w, None, stride, pad)
+    res = bf(torch.randn_like(ref))
+    z = ref * scale[None, :, None, None] + shift[None, :, None, None]
+    if res_first:
+        want = F.prelu(z + res, alpha)
+    else:
+        want = F.prelu(z, alpha) + res
+    xs = [ops.to_nhwc(x1.cuda(), _lib.BF16)] + ([ops.to_nhwc(x2.cuda(), _lib.BF16)] if c2 else [])
+    wp = ops.pack_weight(w.cuda(), False, c1, c2, _lib.BF16)
+    p = ref.shape[2]
+    out = torch.empty(3, p, p, cout, dtype=torch.bfloat16, device="cuda")
+    rn = ops.to_nhwc(res.cuda(), _lib.BF16)
+    _lib.call("msml_conv2d_fused", xs[0], xs[0].shape[3], xs[1] if c2 else None, xs[1].shape[3] if c2 else 0,
+              wp, wp.shape[0], scale.cuda(), shift.cuda(), alpha.cuda(), rn, int(res_first), out, cout,
+              3, h, h, p, p, k, k, stride, pad, pad, 0)
+    got = ops.to_nchw(out, cout).float().cpu()
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err < 1.5e-2, err
+    # no residual / no activation: plain affine epilogue
+    _lib.call("msml_conv2d_fused", xs[0], xs[0].shape[3], xs[1] if c2 else None, xs[1].shape[3] if c2 else 0,
+              wp, wp.shape[0], scale.cuda(), shift.cuda(), None, None, 0, out, cout,
+              3, h, h, p, p, k, k, stride, pad, pad, 0)
+    got = ops.to_nchw(out, cout).float().cpu()
+    err = (got - z).abs().max().item() / z.abs().max().item()
+    assert err < 1e-2, err

@@ -62,6 +62,27 @@ def test_eval_ires18_bf16():
     print("bf16 eval: feature rel err %.3e, mask mismatches %d" % (err, mism))
 
 
+def test_eval_bf16_fused_epilogue_matches_unfused():
+    """Inference folds eval BatchNorm / PReLU / residual into the conv epilogue (no_grad); with
+    autograd enabled the unfused conv -> bn_act kernels run.  Same arithmetic up to bf16 rounding
+    of the intermediate tensors."""
+    m = hip_msml("iresnet50", fp16=True).eval()
+    x, _ = eval_inputs(4)
+    with torch.no_grad():
+        f1, s1 = m(x.cuda())
+    with torch.enable_grad():
+        f2, s2 = m(x.cuda())
+    err = rel_err(f1.float().cpu().numpy(), f2.detach().float().cpu().numpy())
+    assert err < 3e-2, err
+    a, b = Fh.mask_index(s1), Fh.mask_index(s2.detach())
+    assert (a != b).float().mean().item() < 0.02
+    g = load("g2_ires50_eval.npz")
+    x2, _ = eval_inputs(2)
+    with torch.no_grad():
+        f3, _ = m(x2.cuda())
+    assert rel_err(f3.float().cpu().numpy(), g["feature"]) < 5e-2
+
+
 def test_state_dict_roundtrip_with_oracle():
     m = hip_msml("iresnet18", 10)
     o = om.MSML("iresnet18", num_classes=10, header_type="AMArcFace")
