@@ -1,0 +1,332 @@
+// 3x3 / stride-1 / pad-1 convolution (forward, and backward-data with the tap walk flipped) for
+// bf16 NHWC maps that are at most 15 pixels wide -- the 14x14x256 stage that holds 28 of the 48
+// 3x3 convs of IResNet-50 (backbones/frb/iresnet.py:40-67) and the 7x7 / 14x14 levels of the OSB
+// encoder (backbones/osb/unet.py:80-91).  Same contract as msml_conv2d / msml_conv2d_fused.
+//
+// k_conv_fast (im2col gather) re-fetches every input pixel 9 times and is bound by the
+// L2 -> LDS fill rate (~80 GB/s per CU).  Here a workgroup owns a strip of TH image rows and all
+// BN output channels:
+//   * the input strip WITH its 1-pixel halo goes to LDS once per 64-channel slab; the image is
+//     stored with a power-of-two row pitch (PITCH >= W + 1), so the right halo column of row y is
+//     the left halo column of row y + 1 (both zero padding) and GEMM row m <-> LDS pixel m, and
+//     the A operand of tap (r, s) is the SAME image read at the constant offset r * PITCH + s:
+//     fill traffic per MFMA drops ~1.7x, addressing is one immediate per tap,
+//   * GEMM rows whose x >= W are padding (196 real of 224 rows for 14x14) and are dropped in
+//     the epilogue; in exchange one image = one workgroup = one even wave of 256 workgroups
+//     (the 128-row tiling left the second round of workgroups half empty),
+//   * weights stream through a double-buffered [BN][64] stage per (slab, tap) by LDS-DMA,
+//   * every wave owns 32 output channels x all rows (7 accumulator tiles): one B fragment feeds
+//     7 MFMAs; per-channel BatchNorm partial sums need no cross-wave reduction.
+// LDS-DMA zero-fills out-of-range offsets (conv padding) -- see conv_fast.hip.
+#include <stdlib.h>
+
+#include "common.h"
+
+struct ConvHaloArgs {
+  const unsigned short* in;
+  unsigned int in_bytes;
+  int C;              // input channels (multiple of 64)
+  int N, H, W, tpi;   // tpi: row strips per image
+  int flip;           // backward-data: tap (r, s) reads the image at (2 - r, 2 - s)
+  const unsigned short* wp;
+  unsigned int w_bytes;
+  int Ktot;
+  unsigned short* out;
+  int coutp;
+  const float* bias;
+  const float* scale;
+  const float* alpha;
+  const unsigned short* residual;
+  int res_first;
+  float* stats;
+  int stats_rows;
+};
+
+#define HALO_OOB 0x78000000u
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int PL2, int MT, int BN>
+__global__ void __launch_bounds__(BN / 32 * 64) __attribute__((amdgpu_waves_per_eu(BN / 128, BN / 128)))
+k_conv_halo(const ConvHaloArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int PITCH = 1 << PL2, NW = BN / 32, NT = NW * 64, BM = MT * 32;
+  constexpr int TH = BM >> PL2, HR = TH + 2, HPX = HR << PL2;
+  constexpr int ABYTES = HPX * 128, BBYTES = BN * 128;
+  constexpr int NAJ = HPX / 8;                         // DMA wave-instructions per slab image
+  constexpr int NAI = (NAJ + NW - 1) / NW, NBI = BN / 8 / NW;
+  static_assert(PITCH >= 16 && HPX % 8 == 0 && BN % 32 == 0, "tile config");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                                     // [2][HPX][128 B]
+  char* Bs = smem + 2 * ABYTES;                        // [2][BN][128 B]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // scalar: LDS-DMA bases go to M0
+  const int tile = blockIdx.x;
+  const int n = tile / p.tpi, y0 = (tile - n * p.tpi) * TH;
+  const int n0 = blockIdx.y * BN;
+
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.w_bytes, 0x00020000);
+
+  // halo image: LDS pixel hp = hy * PITCH + hx holds input (y0 + hy - 1, hx - 1); its eight
+  // 16-B chunks are XOR-swizzled by (hp >> 1) & 7
+  unsigned int aoff[NAI];
+#pragma unroll
+  for (int i = 0; i < NAI; i++) {
+    const int j = wave + i * NW;
+    const int hp = j * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((hp >> 1) & 7);
+    const int iy = y0 + (hp >> PL2) - 1, ix = (hp & (PITCH - 1)) - 1;
+    const bool v = (j < NAJ) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+    aoff[i] = v ? (unsigned int)((n * p.H + iy) * p.W + ix) * (unsigned int)(p.C * 2) + logical * 16u : HALO_OOB;
+  }
+  // weights: every wave streams ITS 32 output channels through a private two-stage ring
+  // Bs[wave][2][32 rows][128 B].  Only the issuing wave reads them, so its own vmcnt orders the
+  // reads (MI355X_MICROARCH.md item 7) and the K loop needs a workgroup barrier only when the
+  // shared image slab changes (every 9 stages) -- waves drift apart and one wave's fragment
+  // reads overlap its SIMD partner's MFMAs.
+  unsigned int boffg[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = i * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    boffg[i] = (unsigned int)((n0 + wave * 32 + row) * p.Ktot) * 2u + logical * 16u;
+  }
+  auto issue_a = [&](int cs, int buf) {
+    char* a = As + buf * ABYTES;
+#pragma unroll
+    for (int i = 0; i < NAI; i++) {
+      const int j = wave + i * NW;
+      if (j < NAJ)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(a + j * 1024), 16, aoff[i] + cs * 128u, 0, 0, 0);
+    }
+  };
+  auto issue_b = [&](int cs, int tap, int buf) {
+    char* b = Bs + wave * 8192 + buf * 4096;
+    const unsigned int col = (unsigned int)(tap * p.C + cs * 64) * 2u;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(b + i * 1024), 16, boffg[i] + col, 0, 0, 0);
+  };
+
+  // D = W_frag x X_frag: accumulator rows = output channels, columns (lanes) = pixels, so a lane
+  // ends up with 4 consecutive channels of one pixel per register quad (8-B LDS stores below)
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+
+  const int r32 = lane & 31, h = lane >> 5;
+  // fragment offsets: pixel row (32 i + r32) of tap (r, s) is LDS pixel 32 i + r32 + r PITCH + s;
+  // tile i and the vertical tap r are immediates ((32 i + r PITCH) / 2 = 0 mod 8 keeps the
+  // swizzle), the horizontal tap s moves the row and its swizzle
+  int bfr[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bfr[kk] = wave * 8192 + r32 * 128 + (((kk * 2 + h) ^ ((r32 >> 1) & 7)) << 4);
+
+  const int nslab = p.C >> 6, nstage = nslab * 9;
+  issue_a(0, 0);
+  issue_b(0, 0, 0);
+  __syncthreads();                                     // (drains vmcnt first)
+  int cs = 0, tr = 0, ts = 0;                          // slab, tap row / column of stage q
+  u32x4 a[2][MT], b[2];
+  for (int q = 0; q < nstage; q++) {
+    int ncs = cs, ntr = tr, nts = ts + 1;
+    if (nts == 3) { nts = 0; ntr++; }
+    if (ntr == 3) { ntr = 0; ncs++; }
+    // this wave's weights of stage q (issued one stage ago) have landed; queue stage q + 1 and,
+    // at the first tap of a slab, this wave's share of the next slab's image
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef HALO_ABLATE_LOADS
+    if (q + 1 < nstage) {
+      issue_b(ncs, ntr * 3 + nts, (q + 1) & 1);
+      if ((tr | ts) == 0 && cs + 1 < nslab) issue_a(cs + 1, (cs + 1) & 1);
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef HALO_ABLATE_COMPUTE
+    const int r = p.flip ? 2 - tr : tr, s = p.flip ? 2 - ts : ts;
+    const int arow = r32 + s, asw = (arow >> 1) & 7;
+    const char* Arow = As + (cs & 1) * ABYTES + ((r << PL2) * 128) + arow * 128;
+    const char* B = Bs + (q & 1) * 4096;
+    // register double buffer of the fragments of one 16-deep k step; the fences keep hipcc from
+    // sinking the reads next to their MFMAs (which exposes the LDS latency at every MFMA)
+#ifdef HALO_ABLATE_READS
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; i++) {
+        a[0][i] = *reinterpret_cast<const u32x4*>(Arow + ((h ^ asw) << 4) + i * 4096);
+        a[1][i] = a[0][i];
+      }
+      b[0] = *reinterpret_cast<const u32x4*>(B + bfr[0]);
+      b[1] = b[0];
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < MT; i++) a[0][i] = *reinterpret_cast<const u32x4*>(Arow + ((h ^ asw) << 4) + i * 4096);
+    b[0] = *reinterpret_cast<const u32x4*>(B + bfr[0]);
+#endif
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const int cb = kk & 1, nb = cb ^ 1;
+#ifndef HALO_ABLATE_READS
+      if (kk + 1 < 4) {
+        const int ao = (((kk + 1) * 2 + h) ^ asw) << 4;
+#pragma unroll
+        for (int i = 0; i < MT; i++) a[nb][i] = *reinterpret_cast<const u32x4*>(Arow + ao + i * 4096);
+        b[nb] = *reinterpret_cast<const u32x4*>(B + bfr[kk + 1]);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[cb]),
+                                                         __builtin_bit_cast(bf16x8, a[cb][i]), acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    if (ncs != cs && ncs < nslab) __syncthreads();     // slab switch: next image landed everywhere
+    cs = ncs; tr = ntr; ts = nts;
+  }
+  __syncthreads();
+
+  // ---------------- epilogue: affine / PReLU, BatchNorm partials, LDS transpose, 16-B stores -----
+#ifdef HALO_ABLATE_EPILOGUE
+  if (p.N >= 0) return;
+#endif
+  constexpr int OP = BN + 8;                           // 528-B rows
+  unsigned short* otile = reinterpret_cast<unsigned short*>(smem);
+  const int kb = wave * 32 + 4 * h;                    // this lane's channels: kb + 8 g + j
+  const bool act_here = p.alpha && !(p.residual && p.res_first);
+  f32x4 bv[4], sv[4], av[4], s1[4], s2[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int col = n0 + kb + 8 * g;
+    bv[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sv[g] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    av[g] = act_here ? *reinterpret_cast<const f32x4*>(p.alpha + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    s1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < MT; i++) {
+    const int m = i * 32 + r32;
+    const int y = m >> PL2, x = m & (PITCH - 1);
+    const bool valid = (x < p.W) & (y0 + y < p.H);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float z = acc[i][g * 4 + j] * sv[g][j] + bv[g][j];
+        if (act_here) z = z > 0.f ? z : z * av[g][j];
+        v[j] = z;
+        if (valid) {
+          s1[g][j] += z;
+          s2[g][j] += z * z;
+        }
+      }
+      u32x2 pk;
+      pk[0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
+      pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
+      *reinterpret_cast<u32x2*>(otile + m * OP + kb + 8 * g) = pk;
+    }
+  }
+  __syncthreads();
+  constexpr int C8 = BN / 8;
+  for (int idx = t; idx < BM * C8; idx += NT) {
+    const int m = idx / C8, c8 = idx % C8;
+    const int y = m >> PL2, x = m & (PITCH - 1);
+    if (x < p.W && y0 + y < p.H) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(otile + m * OP + c8 * 8);
+      const int c0 = n0 + c8 * 8;
+      const long o = ((long)(n * p.H + y0 + y) * p.W + x) * p.coutp + c0;
+      if (p.residual) {
+        Vec8 a8 = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v));
+        Vec8 r8 = load8<unsigned short>(p.residual + o);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          float z = a8.v[k] + r8.v[k];
+          if (p.res_first && p.alpha) z = z > 0.f ? z : z * p.alpha[c0 + k];
+          a8.v[k] = z;
+        }
+        store8<unsigned short>(reinterpret_cast<unsigned short*>(&v), a8);
+      }
+      *reinterpret_cast<u32x4*>(p.out + o) = v;
+    }
+  }
+  if (p.stats) {
+    // per-channel (sum, sumsq) over this workgroup's pixels: lanes hold pixels, so the 32 partials
+    // of every lane go through LDS and each lane adds up one (statistic, channel) in a fixed order.
+    // One row pair per workgroup; the rows the 128-pixel tiling would have had beyond that are
+    // zeroed so msml_bn_finalize can sum the whole [rows][2][C] block.
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem) + wave * 64 * 33;
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        red[lane * 33 + g * 4 + j] = s1[g][j];
+        red[lane * 33 + 16 + g * 4 + j] = s2[g][j];
+      }
+    __syncthreads();
+    const int which = lane >> 5, kl = lane & 31;       // channel kl = 8 g + 4 hh + j
+    const int k = which * 16 + (kl >> 3) * 4 + (kl & 3), hh = (kl >> 2) & 1;
+    float sum = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < 32; rr++) sum += red[(hh * 32 + rr) * 33 + k];
+    p.stats[((long)blockIdx.x * 2 + which) * p.coutp + n0 + wave * 32 + kl] = sum;
+    for (int row = gridDim.x + blockIdx.x; row < p.stats_rows; row += gridDim.x)
+      for (int c = t; c < 2 * BN; c += NT)
+        p.stats[((long)row * 2 + c / BN) * p.coutp + n0 + c % BN] = 0.f;
+  }
+#endif
+}
+
+template <int PL2, int MT, int BN>
+static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
+  constexpr int BM = MT * 32, TH = BM >> PL2, HPX = (TH + 2) << PL2;
+  a.tpi = cdiv(a.H, TH);
+  size_t lds = 2 * (size_t)HPX * 128 + 2 * (size_t)BN * 128;
+  size_t olds = (size_t)BM * (BN + 8) * 2;
+  if (olds > lds) lds = olds;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<PL2, MT, BN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(a.N * a.tpi, a.coutp / BN);
+  k_conv_halo<PL2, MT, BN><<<grid, dim3(BN / 32 * 64), lds, st>>>(a);
+}
+
+// Tried first by msml_conv_fast_dispatch; false = shape not covered here.
+bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
+                             int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
+                             int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
+                             const float* scale, const float* alpha, const void* residual, int res_first) {
+  static const bool off = getenv("MSML_NO_HALO_CONV") != nullptr;
+  if (off) return false;
+  if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return false;
+  if (c0p % 64 != 0 || coutp % 256 != 0 || kop < coutp) return false;
+  if (W + 1 > 16) return false;
+  const int tpi = cdiv(H, 14);
+  if ((long)H * W * 10 < (long)tpi * 224 * 7) return false;       // < 70 % real GEMM rows: im2col kernel wins
+  const long tiles = (long)N * tpi;
+  const int srows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
+  if (tiles < 128 || (stats && tiles > srows)) return false;
+  const long in_bytes = (long)N * H * W * c0p * 2, w_bytes = (long)kop * 9 * c0p * 2;
+  if (in_bytes >= 0x70000000L || w_bytes >= 0x70000000L) return false;
+  ConvHaloArgs a;
+  a.in = (const unsigned short*)in0; a.in_bytes = (unsigned int)in_bytes; a.C = c0p;
+  a.N = N; a.H = H; a.W = W; a.flip = transposed;
+  a.wp = (const unsigned short*)wp; a.w_bytes = (unsigned int)w_bytes; a.Ktot = 9 * c0p;
+  a.out = (unsigned short*)out; a.coutp = coutp;
+  a.bias = bias; a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual;
+  a.res_first = res_first; a.stats = stats; a.stats_rows = srows;
+  launch_halo<4, 7, 256>(a, st);
+  return true;
+}

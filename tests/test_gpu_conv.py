@@ -259,3 +259,60 @@ def test_conv_fused_eval_bn(shape, res_first):
     got = ops.to_nchw(out, cout).float().cpu()
     err = (got - z).abs().max().item() / z.abs().max().item()
     assert err < 1e-2, err
+
+
+# (N, Cin, Cout, H, W): shapes routed to the halo-tile 3x3 kernel (conv_halo.hip): W <= 15,
+# Cin % 64 == 0, Cout % 256 == 0, >= 128 row strips
+HALO = [
+    (128, 64, 256, 14, 14),      # one 64-channel slab
+    (128, 192, 256, 14, 14),     # three slabs: image double buffer wraps
+    (130, 64, 256, 7, 7),        # too few real rows per strip: stays on the im2col kernel
+    (128, 64, 512, 13, 13),      # two channel tiles, ragged width
+    (70, 64, 256, 26, 14),       # two strips per image, the second one 12 rows
+]
+
+
+@pytest.mark.parametrize("shape", HALO)
+def test_conv_halo_fwd_dgrad_stats(shape):
+    n, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w_, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).bfloat16().float()
+    ref = F.conv2d(x, w, None, 1, 1)
+    out, stats = run_conv(x, None, w, None, 1, 1, 1, _lib.BF16)
+    got = ops.to_nchw(out, cout).cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 1.5e-2 * scale
+    ssum = stats.double().sum(0).cpu()
+    assert torch.allclose(ssum[0].float(), ref.double().sum((0, 2, 3)).float(), rtol=0,
+                          atol=1.5e-2 * scale * ref[:, 0].numel() ** 0.5)
+    assert torch.allclose(ssum[1].float(), (ref.double() ** 2).sum((0, 2, 3)).float(), rtol=2e-2)
+    # backward-data: dX = transposed gather of dY with the (ko = cin) packing; cin must be a
+    # multiple of 256 to take the halo kernel, so use the roles swapped: dY has `cin` channels
+    dy = x                                                   # [n, cin, h, w]
+    wd = (torch.randn(cin, cout, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).bfloat16().float()
+    dref = torch.nn.grad.conv2d_input((n, cout, h, w_), wd, dy, 1, 1)      # conv: cout -> cin, weight [cin][cout]
+    wp = ops.pack_weight(wd.cuda(), True, cin, 0, _lib.BF16)
+    dx, _ = ops.conv2d(ops.to_nhwc(dy.cuda(), _lib.BF16), None, wp, None, cout, 3, 3, 1, 1, 1, True, p=h, q=w_)
+    gd = ops.to_nchw(dx, cout).cpu()
+    assert (gd - dref).abs().max().item() <= 1.5e-2 * dref.abs().max().item()
+
+
+def test_conv_halo_fused_epilogue():
+    n, cin, cout, h = 128, 64, 256, 14
+    torch.manual_seed(3)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn(n, cin, h, h))
+    w = bf(torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9)) ** 0.5)
+    scale, shift, alpha = torch.rand(cout) + 0.5, torch.randn(cout) * 0.3, torch.rand(cout) * 0.5
+    ref = F.conv2d(x, w, None, 1, 1)
+    res = bf(torch.randn_like(ref))
+    z = ref * scale[None, :, None, None] + shift[None, :, None, None]
+    xn, rn = ops.to_nhwc(x.cuda(), _lib.BF16), ops.to_nhwc(res.cuda(), _lib.BF16)
+    wp = ops.pack_weight(w.cuda(), False, cin, 0, _lib.BF16)
+    out = torch.empty(n, h, h, cout, dtype=torch.bfloat16, device="cuda")
+    for res_first, want in ((0, F.prelu(z, alpha) + res), (1, F.prelu(z + res, alpha))):
+        _lib.call("msml_conv2d_fused", xn, cin, None, 0, wp, wp.shape[0], scale.cuda(), shift.cuda(),
+                  alpha.cuda(), rn, res_first, out, cout, n, h, h, h, h, 3, 3, 1, 1, 1, 0)
+        got = ops.to_nchw(out, cout).float().cpu()
+        assert (got - want).abs().max().item() <= 1.5e-2 * want.abs().max().item()
