@@ -238,6 +238,28 @@ int msml_conv2d_fused(const void* in0, int c0p, const void* in1, int c1p, const 
                       int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
                       int transposed, void* stream);
 
+/* Backward-data conv fused with the backward REDUCE of the BatchNorm(+PReLU) that produced the
+ * conv's input in the forward (IBasicBlock: bn1 -> conv1, bn2 -> prelu -> conv2,
+ * backbones/frb/iresnet.py:59-64): the conv output dX is that BatchNorm's dy, so the epilogue
+ * accumulates sum g, sum g*xhat, sum dy*min(z,0) per channel from the stored (bf16) dX and the
+ * saved BatchNorm input bn_x (same [N][P][Q][coutp] layout), one partial row [3][coutp] per
+ * workgroup.  bf16 only; MSML_ERR_UNSUPPORTED when the shape is not on the fast path (callers
+ * fall back to msml_conv2d + msml_bn_act_bwd).  partial needs msml_conv2d_bnbwd_rows() rows;
+ * *rows_used = rows written (all of them fully).  msml_bn_act_bwd_apply finishes the job:
+ * finalize over `rows` + dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) [+ add]. */
+int msml_conv2d_bnbwd_rows(int coutp, int N, int P, int Q);
+int msml_conv2d_bnbwd(const void* in0, int c0p, const void* wp, int kop, void* out, int coutp,
+                      int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                      int pad_w, int transposed, const void* bn_x, const float* bn_scale,
+                      const float* bn_shift, const float* bn_alpha, const float* bn_mean,
+                      const float* bn_invstd, float* partial, int rows_cap, int* rows_used,
+                      void* stream);
+int msml_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
+                          const float* alpha, const float* save_mean, const float* save_invstd,
+                          const float* partial, int rows, const void* add, void* dx,
+                          float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
+                          int C, float* coef_ws, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "msml_hip.h")
 LIBPATH = os.environ.get("MSML_LIB", os.path.join(_HERE, "libmsml_hip.so"))   # (override: kernel ablation builds)
 
 F32, BF16 = 0, 1
+UNSUPPORTED = -4          # MSML_ERR_UNSUPPORTED
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
 DTYPE_OF = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -97,6 +98,23 @@ def call(name, *args):
     if _protos[name][0] is not ctypes.c_int:
         return rc
     if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.msml_last_error().decode()))
+    return rc
+
+
+def try_call(name, *args):
+    """Like call(), but returns the status code instead of raising on MSML_ERR_UNSUPPORTED:
+    for entry points that cover only part of the shape space and have an unfused alternative."""
+    lib = load()
+    fn = getattr(lib, name)
+    params = _protos[name][1]
+    cargs = [_arg(a) for a in args]
+    if params and params[-1][1] == "stream" and len(cargs) == len(params) - 1:
+        cargs.append(torch.cuda.current_stream().cuda_stream)
+    if len(cargs) != len(params):
+        raise TypeError("%s expects %d arguments, got %d" % (name, len(params), len(cargs)))
+    rc = fn(*cargs)
+    if rc not in (0, UNSUPPORTED):
         raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.msml_last_error().decode()))
     return rc
 

@@ -323,8 +323,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ invstd,
                                                       const float* __restrict__ coef,
-                                                      const T* __restrict__ res, T* __restrict__ dx,
-                                                      T* __restrict__ dres, long n8, int C8) {
+                                                      const T* __restrict__ res, const T* __restrict__ add,
+                                                      T* __restrict__ dx, T* __restrict__ dres, long n8,
+                                                      int C8) {
   const int C = C8 * 8;
   const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const int c0 = (int)(tid % C8) * 8;
@@ -334,8 +335,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
   for (long i = tid; i < n8; i += (long)gridDim.x * blockDim.x) {
     Vec8 g = load8<T>(dy + i * 8);
     Vec8 v = load8<T>(x + i * 8);
-    Vec8 rr;
+    Vec8 rr, ad;
     if (res) rr = load8<T>(res + i * 8);
+    if (add) ad = load8<T>(add + i * 8);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       float gg = g.v[j];
@@ -347,6 +349,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
       float xh = (v.v[j] - mu.v[j]) * is.v[j];
       // scale[c] == gamma * invstd
       v.v[j] = sc.v[j] * (gg - k1.v[j] - xh * k2.v[j]);
+      if (add) v.v[j] += ad.v[j];
       g.v[j] = gg;
     }
     store8<T>(dx + i * 8, v);
@@ -379,7 +382,31 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
       MSML_LAUNCH_OK("bn_bwd_finalize");
       k_bn_bwd_apply<DT><<<ew_grid_c(n8, C / 8), 256, 0, st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
                                                      save_mean, save_invstd, coef, (const DT*)residual_first,
-                                                     (DT*)dx, (DT*)dres, n8, C / 8);)
+                                                     (const DT*)nullptr, (DT*)dx, (DT*)dres, n8, C / 8);)
+  MSML_LAUNCH_OK("bn_bwd_apply");
+  return MSML_OK;
+}
+
+// Second half of msml_bn_act_bwd for callers that already hold the partial sums (a backward-data
+// conv with the fused reduce, msml_conv2d_bnbwd): finalize + apply, with an optional tensor
+// `add` summed into dx (the other gradient path that joins at the BatchNorm input).
+extern "C" int msml_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
+                                     const float* alpha, const float* save_mean, const float* save_invstd,
+                                     const float* partial, int rows, const void* add, void* dx,
+                                     float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
+                                     int C, float* coef_ws, int dtype, void* stream) {
+  MSML_CHECK(dy && x && dx && scale && shift && save_mean && save_invstd && partial && coef_ws && rows > 0 &&
+                 M > 0 && C > 0 && C % 8 == 0 && C <= 2048,
+             MSML_ERR_SHAPE, "bn_act_bwd_apply: bad args M=%ld C=%d rows=%d", M, C, rows);
+  hipStream_t st = (hipStream_t)stream;
+  long n8 = M * (C / 8);
+  k_bn_bwd_finalize<<<cdiv(C, 32), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef_ws, accumulate);
+  MSML_LAUNCH_OK("bn_bwd_finalize");
+  MSML_DISPATCH_DTYPE(
+      dtype, "bn_act_bwd_apply",
+      k_bn_bwd_apply<DT><<<ew_grid_c(n8, C / 8), 256, 0, st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
+                                                     save_mean, save_invstd, coef_ws, (const DT*)nullptr,
+                                                     (const DT*)add, (DT*)dx, (DT*)nullptr, n8, C / 8);)
   MSML_LAUNCH_OK("bn_bwd_apply");
   return MSML_OK;
 }

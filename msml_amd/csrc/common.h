@@ -136,3 +136,53 @@ __device__ __forceinline__ float wave_max(float v) {
     msml_set_error("%s: unsupported dtype %d", name, (int)(dtype)); \
     return MSML_ERR_DTYPE;                                          \
   }
+
+
+// ---- BatchNorm backward-reduce fused into a backward-data conv epilogue ---------------------
+// The conv's output dX is the gradient dy of a training-mode BatchNorm(+PReLU) output; the conv
+// epilogue accumulates that BatchNorm's backward sums from the bf16-rounded dX it stores and the
+// saved BatchNorm input x (same NHWC shape as dX):  q0 = sum g, q1 = sum g * xhat,
+// q2 = sum dy * min(z, 0)  with z = x * scale + shift, g = dy * prelu'(z), xhat = (x - mean) * invstd
+// (same definitions as k_bn_bwd_reduce in bn.hip).  partial: [rows][3][C], one row per workgroup.
+struct BnBwdFuse {
+  const unsigned short* x;
+  const float* scale;
+  const float* shift;
+  const float* alpha;      // nullptr: no PReLU
+  const float* mean;
+  const float* invstd;
+  float* partial;
+};
+
+struct BnbCoef {
+  float sc[8], sh[8], al[8], mu[8], is[8];
+};
+__device__ __forceinline__ BnbCoef bnb_load_coef(const BnBwdFuse& f, int c0) {
+  BnbCoef k;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    k.sc[j] = f.scale[c0 + j];
+    k.sh[j] = f.shift[c0 + j];
+    k.al[j] = f.alpha ? f.alpha[c0 + j] : 1.f;
+    k.mu[j] = f.mean[c0 + j];
+    k.is[j] = f.invstd[c0 + j];
+  }
+  return k;
+}
+__device__ __forceinline__ void bnb_accum(const BnbCoef& k, bool has_alpha, const Vec8& dy, const Vec8& x,
+                                          float (&q)[3][8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    float gg = dy.v[j];
+    if (has_alpha) {
+      const float z = x.v[j] * k.sc[j] + k.sh[j];
+      if (z <= 0.f) {
+        q[2][j] += gg * z;
+        gg *= k.al[j];
+      }
+    }
+    const float xh = (x.v[j] - k.mu[j]) * k.is[j];
+    q[0][j] += gg;
+    q[1][j] += gg * xh;
+  }
+}

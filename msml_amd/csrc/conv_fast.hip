@@ -41,6 +41,7 @@ struct ConvFastArgs {
   const unsigned short* residual;
   int res_first;
   float* stats;
+  BnBwdFuse bnb;      // bnb.partial != nullptr: fused BatchNorm backward-reduce (common.h)
   long M;
   int tiles_m;
   int parity;         // transposed gather with stride 2: one launch slice (blockIdx.z) per output
@@ -109,7 +110,13 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
     Pc = (p.P - cy + 1) >> 1; Qc = (p.Q - cx + 1) >> 1;
   }
   const long Mc = p.parity ? (long)p.N * Pc * Qc : p.M;
-  if (m0 >= Mc) return;
+  const long prow = (long)bid + (p.parity ? (long)blockIdx.z * p.tiles_m : 0);   // fused-reduce row
+  if (m0 >= Mc) {
+    if (p.bnb.partial)                                 // empty tile of a small parity class
+      for (int i = t; i < 3 * BN; i += NT)
+        if (n0 + i % BN < p.coutp) p.bnb.partial[(prow * 3 + i / BN) * p.coutp + n0 + i % BN] = 0.f;
+    return;
+  }
   const int taps = nr * ns;
   // output row index (pixel in the full P x Q grid) of class-local row m
   auto out_pixel = [&](long m) -> long {
@@ -364,6 +371,15 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   if (VIA_LDS) {
     __syncthreads();
     constexpr int C8 = BN / 8;
+    static_assert(NT % C8 == 0, "a thread keeps one 8-channel chunk in the copy-out loop");
+    const bool fuse = p.bnb.partial != nullptr && n0 + (t % C8) * 8 < p.coutp;
+    BnbCoef bk;
+    float bq[3][8];
+    if (fuse) bk = bnb_load_coef(p.bnb, n0 + (t % C8) * 8);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) bq[q][j] = 0.f;
     for (int idx = t; idx < BM * C8; idx += NT) {
       int row = idx / C8, c8 = idx % C8;
       long m = m0 + row;
@@ -383,6 +399,26 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
           store8<unsigned short>(reinterpret_cast<unsigned short*>(&v), a);
         }
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + o) = v;
+        if (fuse)
+          bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v)),
+                    load8<unsigned short>(p.bnb.x + o), bq);
+      }
+    }
+    if (p.bnb.partial) {
+      // the NT / C8 threads that share a channel chunk meet in LDS; fixed-order sums
+      constexpr int G = NT / C8;
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[((t / C8) * 3 + q) * BN + (t % C8) * 8 + j] = bq[q][j];
+      __syncthreads();
+      for (int i = t; i < 3 * BN; i += NT) {
+        const int q = i / BN, c = i % BN;
+        float sum = 0.f;
+        for (int g = 0; g < G; g++) sum += red[(g * 3 + q) * BN + c];
+        if (n0 + c < p.coutp) p.bnb.partial[(prow * 3 + q) * p.coutp + n0 + c] = sum;
       }
     }
   }
@@ -431,7 +467,8 @@ static void launch_fast(ConvFastArgs& a, hipStream_t st) {
 bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
                              int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
-                             const float* scale, const float* alpha, const void* residual, int res_first);
+                             const float* scale, const float* alpha, const void* residual, int res_first,
+                             const BnBwdFuse* bnb, int* bnb_rows);
 
 // Called by msml_conv2d (conv_igemm.hip) when the fast-path conditions hold.  Returns false if
 // this kernel does not apply.
@@ -439,13 +476,15 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
                              int transposed, int in_dtype, int out_dtype, int bn, hipStream_t st,
-                             const float* scale, const float* alpha, const void* residual, int res_first) {
+                             const float* scale, const float* alpha, const void* residual, int res_first,
+                             const BnBwdFuse* bnb, int* bnb_rows) {
   if (in_dtype != MSML_BF16) return false;
+  if (bnb && (out_dtype != MSML_BF16 || stats)) return false;
   if ((scale || alpha || residual) && out_dtype != MSML_BF16) return false;
   if (c0p % 32 != 0 || (in1 && c1p % 32 != 0)) return false;
   if (!in1 && out_dtype == MSML_BF16 &&
       msml_conv_halo_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h,
-                              pad_w, transposed, st, scale, alpha, residual, res_first))
+                              pad_w, transposed, st, scale, alpha, residual, res_first, bnb, bnb_rows))
     return true;
   ConvFastArgs a;
   a.in[0] = (const unsigned short*)in0;
@@ -469,6 +508,8 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   a.pad_h = pad_h; a.pad_w = pad_w; a.transposed = transposed;
   a.wp = (const unsigned short*)wp; a.out = out; a.coutp = coutp; a.bias = bias; a.stats = stats;
   a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual; a.res_first = res_first;
+  a.bnb = BnBwdFuse{};
+  if (bnb) a.bnb = *bnb;
   a.M = (long)N * P * Q;
   a.ksplits = 1;
   a.split_stride = 0;
@@ -496,6 +537,7 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   if (out_dtype == MSML_BF16) { FAST_CASE(unsigned short) }
   else { FAST_CASE(float) }
 #undef FAST_CASE
+  if (bnb_rows) *bnb_rows = a.tiles_m * (a.parity ? 4 : 1);
   return true;
 }
 
@@ -520,6 +562,7 @@ bool msml_conv_fast_splitk(const void* in0, int c0p, const void* wp, int kop, fl
   a.stride = 1; a.stride_shift = 0; a.pad_h = 0; a.pad_w = 0; a.transposed = 0;
   a.wp = (const unsigned short*)wp; a.out = ws; a.coutp = coutp; a.bias = nullptr; a.stats = nullptr;
   a.scale = nullptr; a.alpha = nullptr; a.residual = nullptr; a.res_first = 0;
+  a.bnb = BnBwdFuse{};
   a.M = N;
   a.parity = 0;
   a.ksplits = ksplits;

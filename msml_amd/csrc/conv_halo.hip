@@ -40,6 +40,7 @@ struct ConvHaloArgs {
   int res_first;
   float* stats;
   int stats_rows;
+  BnBwdFuse bnb;      // bnb.partial != nullptr: fused BatchNorm backward-reduce (common.h)
 };
 
 #define HALO_OOB 0x78000000u
@@ -237,6 +238,15 @@ k_conv_halo(const ConvHaloArgs p) {
   }
   __syncthreads();
   constexpr int C8 = BN / 8;
+  static_assert(NT % C8 == 0, "a thread keeps one 8-channel chunk in the copy-out loop");
+  const bool fuse = p.bnb.partial != nullptr;
+  BnbCoef bk;
+  float bq[3][8];
+  if (fuse) bk = bnb_load_coef(p.bnb, n0 + (t % C8) * 8);
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) bq[q][j] = 0.f;
   for (int idx = t; idx < BM * C8; idx += NT) {
     const int m = idx / C8, c8 = idx % C8;
     const int y = m >> PL2, x = m & (PITCH - 1);
@@ -256,6 +266,25 @@ k_conv_halo(const ConvHaloArgs p) {
         store8<unsigned short>(reinterpret_cast<unsigned short*>(&v), a8);
       }
       *reinterpret_cast<u32x4*>(p.out + o) = v;
+      if (fuse)
+        bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v)),
+                  load8<unsigned short>(p.bnb.x + o), bq);
+    }
+  }
+  if (fuse) {
+    constexpr int G = NT / C8;
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) red[((t / C8) * 3 + q) * BN + (t % C8) * 8 + j] = bq[q][j];
+    __syncthreads();
+    for (int i = t; i < 3 * BN; i += NT) {
+      const int q = i / BN, c = i % BN;
+      float sum = 0.f;
+      for (int g = 0; g < G; g++) sum += red[(g * 3 + q) * BN + c];
+      p.bnb.partial[((long)blockIdx.x * 3 + q) * p.coutp + n0 + c] = sum;
     }
   }
   if (p.stats) {
@@ -307,7 +336,8 @@ static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
 bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
                              int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
-                             const float* scale, const float* alpha, const void* residual, int res_first) {
+                             const float* scale, const float* alpha, const void* residual, int res_first,
+                             const BnBwdFuse* bnb, int* bnb_rows) {
   static const bool off = getenv("MSML_NO_HALO_CONV") != nullptr;
   if (off) return false;
   if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return false;
@@ -327,6 +357,9 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   a.out = (unsigned short*)out; a.coutp = coutp;
   a.bias = bias; a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual;
   a.res_first = res_first; a.stats = stats; a.stats_rows = srows;
+  a.bnb = BnBwdFuse{};
+  if (bnb) a.bnb = *bnb;
+  if (bnb_rows) *bnb_rows = (int)tiles;
   launch_halo<4, 7, 256>(a, st);
   return true;
 }

@@ -310,7 +310,8 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
                              int transposed, int in_dtype, int out_dtype, int bn, hipStream_t st,
-                             const float* scale, const float* alpha, const void* residual, int res_first);
+                             const float* scale, const float* alpha, const void* residual, int res_first,
+                             const BnBwdFuse* bnb, int* bnb_rows);
 
 extern "C" int msml_conv_tile_m(int coutp) { return coutp <= 64 ? 256 : 128; }
 extern "C" int msml_conv_tile_n(int coutp) { return coutp <= 32 ? 32 : (coutp <= 64 ? 64 : 128); }
@@ -356,7 +357,7 @@ extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, c
   if ((out_dtype == MSML_BF16 || out_dtype == MSML_F32) && !getenv("MSML_NO_FAST_CONV") &&
       msml_conv_fast_dispatch(in0, c0p, in1, c1p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R,
                               S, stride, pad_h, pad_w, transposed, in_dtype, out_dtype, bn, st, nullptr, nullptr,
-                              nullptr, 0)) {
+                              nullptr, 0, nullptr, nullptr)) {
     MSML_LAUNCH_OK("conv2d(fast)");
     return MSML_OK;
   }
@@ -390,8 +391,39 @@ extern "C" int msml_conv2d_fused(const void* in0, int c0p, const void* in1, int 
   MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_fused: packed weight rows");
   MSML_CHECK(msml_conv_fast_dispatch(in0, c0p, in1, c1p, wp, kop, shift, out, coutp, nullptr, N, H, W, P, Q,
                                      R, S, stride, pad_h, pad_w, transposed, MSML_BF16, MSML_BF16, bn,
-                                     (hipStream_t)stream, scale, alpha, residual, res_first),
+                                     (hipStream_t)stream, scale, alpha, residual, res_first, nullptr, nullptr),
              MSML_ERR_UNSUPPORTED, "conv2d_fused: shape not supported by the fast kernel");
   MSML_LAUNCH_OK("conv2d_fused");
+  return MSML_OK;
+}
+
+
+// Backward-data conv whose output is the gradient of a training-mode BatchNorm(+PReLU) output:
+// the epilogue also produces that BatchNorm's backward partial sums (see msml_hip.h).
+extern "C" int msml_conv2d_bnbwd_rows(int coutp, int N, int P, int Q) {
+  // upper bound of partial rows any kernel choice writes: one per pixel tile, x4 parity classes
+  const long m = (long)N * P * Q;
+  return 4 * (cdiv(m, 128) + 4);
+}
+
+extern "C" int msml_conv2d_bnbwd(const void* in0, int c0p, const void* wp, int kop, void* out, int coutp,
+                                 int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                                 int pad_w, int transposed, const void* bn_x, const float* bn_scale,
+                                 const float* bn_shift, const float* bn_alpha, const float* bn_mean,
+                                 const float* bn_invstd, float* partial, int rows_cap, int* rows_used,
+                                 void* stream) {
+  MSML_CHECK(in0 && wp && out && bn_x && bn_scale && bn_shift && bn_mean && bn_invstd && partial && rows_used,
+             MSML_ERR_SHAPE, "conv2d_bnbwd: null pointer");
+  MSML_CHECK(c0p % 32 == 0 && coutp % 8 == 0, MSML_ERR_SHAPE, "conv2d_bnbwd: channel padding");
+  MSML_CHECK(rows_cap >= msml_conv2d_bnbwd_rows(coutp, N, P, Q), MSML_ERR_WORKSPACE,
+             "conv2d_bnbwd: partial buffer has %d rows, need %d", rows_cap, msml_conv2d_bnbwd_rows(coutp, N, P, Q));
+  const int bn = msml_conv_tile_n(coutp);
+  MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_bnbwd: packed weight rows");
+  BnBwdFuse f{(const unsigned short*)bn_x, bn_scale, bn_shift, bn_alpha, bn_mean, bn_invstd, partial};
+  MSML_CHECK(msml_conv_fast_dispatch(in0, c0p, nullptr, 0, wp, kop, nullptr, out, coutp, nullptr, N, H, W, P, Q,
+                                     R, S, stride, pad_h, pad_w, transposed, MSML_BF16, MSML_BF16, bn,
+                                     (hipStream_t)stream, nullptr, nullptr, nullptr, 0, &f, rows_used),
+             MSML_ERR_UNSUPPORTED, "conv2d_bnbwd: shape not supported by the fast kernel");
+  MSML_LAUNCH_OK("conv2d_bnbwd");
   return MSML_OK;
 }

@@ -1,11 +1,12 @@
 """Thin tensor-level wrappers over the C ABI (no autograd): allocate outputs with torch,
 pass raw pointers.  Everything here requires the HIP library and a GPU tensor."""
+import ctypes
 import os
 
 import torch
 
 from . import _lib
-from ._lib import BF16, DTYPE_OF, F32, TORCH_DTYPE, call
+from ._lib import BF16, DTYPE_OF, F32, TORCH_DTYPE, call, try_call
 
 
 class _Profile:
@@ -148,6 +149,31 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
         call("msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats, n, h, w, p,
              q, r, s, stride, pad_h, pad_w, int(transposed), in_dtype, out_dtype)
     return out, stats
+
+
+def conv_dgrad_bnbwd(dy, wp, coutp, r, s, stride, pad_h, pad_w, p, q, bn_x, coef, alpha, real=None):
+    """Backward-data conv (transposed gather) whose epilogue also reduces the backward sums of
+    the BatchNorm(+PReLU) that fed the conv (msml_conv2d_bnbwd).  coef: [4][C] scale, shift,
+    mean, invstd saved by the BatchNorm forward.  Returns (dx, partial[rows][3][C]) or None when
+    the shape is not covered (caller runs the unfused kernels)."""
+    n, h, w, c0p = dy.shape
+    if dy.dtype != torch.bfloat16:
+        return None
+    cap = _lib.value("msml_conv2d_bnbwd_rows", coutp, n, p, q)
+    partial = torch.empty(cap, 3, coutp, dtype=torch.float32, device=dy.device)
+    out = torch.empty(n, p, q, coutp, dtype=torch.bfloat16, device=dy.device)
+    used = ctypes.c_int(0)
+    cin, cout = real if real is not None else (c0p, coutp)
+    name = "conv_igemm"
+    if PROFILE.on:
+        name = "conv T+bnb c%d+0->%d %dx%d k%dx%d s%d n%d" % (c0p, coutp, h, w, r, s, stride, n)
+    with PROFILE.rec(name, 2.0 * n * h * w * cin * cout * r * s):
+        rc = try_call("msml_conv2d_bnbwd", dy, c0p, wp, wp.shape[0], out, coutp, n, h, w, p, q, r, s, stride,
+                      pad_h, pad_w, 1, bn_x, coef[0], coef[1], alpha, coef[2], coef[3], partial, cap,
+                      ctypes.byref(used))
+    if rc != 0:
+        return None
+    return out, partial[:used.value]
 
 
 _WS = {}

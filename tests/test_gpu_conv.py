@@ -316,3 +316,55 @@ def test_conv_halo_fused_epilogue():
                   alpha.cuda(), rn, res_first, out, cout, n, h, h, h, h, 3, 3, 1, 1, 1, 0)
         got = ops.to_nchw(out, cout).float().cpu()
         assert (got - want).abs().max().item() <= 1.5e-2 * want.abs().max().item()
+
+
+def _bn_bwd_unfused(dy, x, coef, alpha, m, c):
+    dx = torch.empty_like(x)
+    pg = torch.zeros(3, c, device="cuda")
+    rows = ops.bn_stats_rows(m, c)
+    ws = torch.empty(rows * 3 * c + 2 * c, device="cuda")
+    _lib.call("msml_bn_act_bwd", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], None, dx, None, pg[0], pg[1],
+              pg[2] if alpha is not None else None, 0, m, c, ws, ws.numel(), _lib.BF16)
+    return dx, pg
+
+
+# (N, K = dy channels, C = dX / BatchNorm channels, H, stride): halo kernel, im2col kernel with
+# full and ragged tiles, stride-2 parity classes (odd size: unequal classes)
+BNBWD = [(128, 64, 256, 14, 1), (3, 64, 64, 14, 1), (5, 128, 64, 9, 1), (4, 64, 128, 14, 2), (3, 128, 64, 9, 2)]
+
+
+@pytest.mark.parametrize("with_alpha", [False, True])
+@pytest.mark.parametrize("shape", BNBWD)
+def test_conv_dgrad_fused_bn_backward_reduce(shape, with_alpha):
+    """msml_conv2d_bnbwd + msml_bn_act_bwd_apply == msml_conv2d (dgrad) + msml_bn_act_bwd, and the
+    `add` operand of the apply step is summed into dx."""
+    n, k, c, h, stride = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    ho = (h + 2 - 3) // stride + 1
+    dyc = torch.randn(n, k, ho, ho, generator=g).bfloat16().float()          # gradient of the conv output
+    w = (torch.randn(k, c, 3, 3, generator=g) * 0.05).bfloat16().float()      # conv: c -> k
+    xbn = ops.to_nhwc(torch.randn(n, c, h, h, generator=g).cuda(), _lib.BF16)   # saved BatchNorm input
+    coef = torch.stack([torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3,
+                        torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5]).cuda()
+    alpha = (torch.rand(c, generator=g) * 0.5).cuda() if with_alpha else None
+    wp = ops.pack_weight(w.cuda(), True, k, 0, _lib.BF16)
+    dyd = ops.to_nhwc(dyc.cuda(), _lib.BF16)
+    m = n * h * h
+    dx_ref, _ = ops.conv2d(dyd, None, wp, None, c, 3, 3, stride, 1, 1, True, p=h, q=h)
+    want_dx, want_pg = _bn_bwd_unfused(dx_ref, xbn, coef, alpha, m, c)
+    got = ops.conv_dgrad_bnbwd(dyd, wp, c, 3, 3, stride, 1, 1, h, h, xbn, coef, alpha)
+    assert got is not None
+    dxc, partial = got
+    assert torch.equal(dxc, dx_ref)
+    add = ops.to_nhwc(torch.randn(n, c, h, h, generator=g).cuda(), _lib.BF16)
+    for addt in (None, add):
+        dx = torch.empty_like(xbn)
+        pg = torch.zeros(3, c, device="cuda")
+        cw = torch.empty(2 * c, device="cuda")
+        _lib.call("msml_bn_act_bwd_apply", dxc, xbn, coef[0], coef[1], alpha, coef[2], coef[3], partial,
+                  partial.shape[0], addt, dx, pg[0], pg[1], pg[2] if with_alpha else None, 0, m, c, cw, _lib.BF16)
+        ref = want_dx.float() + (addt.float() if addt is not None else 0)
+        scale = ref.abs().max().item()
+        assert (dx.float() - ref).abs().max().item() <= 1e-2 * scale
+        for i in range(3 if with_alpha else 2):
+            assert torch.allclose(pg[i], want_pg[i], rtol=1e-3, atol=1e-3 * want_pg[i].abs().max().item())
