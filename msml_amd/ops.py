@@ -180,9 +180,10 @@ _WS = {}
 
 
 def workspace(nbytes, device, tag="main"):
-    """Grow-only scratch buffer per (device, tag); reuse is ordered by the stream that uses the
-    tag (the weight-gradient side stream has its own buffer)."""
-    key = (device, tag)
+    """Grow-only scratch buffer per (device, tag, current stream): reuse is ordered by the stream,
+    and kernels of different streams (weight-gradient stream, OSB stream, whose backward runs
+    beside the FRB backward) never share scratch memory."""
+    key = (device, tag, torch.cuda.current_stream().cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
