@@ -246,7 +246,8 @@ int msml_conv2d_fused(const void* in0, int c0p, const void* in1, int c1p, const 
  * workgroup.  bf16 only; MSML_ERR_UNSUPPORTED when the shape is not on the fast path (callers
  * fall back to msml_conv2d + msml_bn_act_bwd).  partial needs msml_conv2d_bnbwd_rows() rows;
  * *rows_used = rows written (all of them fully).  msml_bn_act_bwd_apply finishes the job:
- * finalize over `rows` + dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) [+ add]. */
+ * finalize over `rows` + dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) [+ add];
+ * coef_ws: 98*C floats of scratch (2*C coefficients + 32 folded partial rows). */
 int msml_conv2d_bnbwd_rows(int coutp, int N, int P, int Q);
 int msml_conv2d_bnbwd(const void* in0, int c0p, const void* wp, int kop, void* out, int coutp,
                       int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,

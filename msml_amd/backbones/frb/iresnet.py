@@ -9,6 +9,7 @@ out of scope this round and raise if requested.
 import torch
 from torch import nn
 
+from ... import blocks, ops
 from ... import functional as Fh
 from .._nn import conv, conv_bn
 
@@ -42,6 +43,8 @@ class IBasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if self.training and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and ops.BLOCK_FUNCTION:
+            return blocks.iblock(self, x)          # one autograd node, fused backward (blocks.py)
         out = Fh.bn_act(x, None, self.bn1)
         out = conv_bn(self.conv1, self.bn2, out, prelu=self.prelu)
         identity = x

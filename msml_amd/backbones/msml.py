@@ -87,6 +87,15 @@ class MSML(nn.Module):
             raise NotImplementedError("msml_amd: use_osb=False is not built")
         from .. import ops
         ops.PACKS.refresh_if_stale()      # one batched repack after a FlatSGD step
+        ops.DEFER_BN_COUNTERS = True      # num_batches_tracked: one foreach add per forward
+        try:
+            return self._forward(x, label, ori)
+        finally:
+            ops.DEFER_BN_COUNTERS = False
+            ops.flush_bn_counters()
+
+    def _forward(self, x, label, ori):
+        from .. import ops
         xh = Fh.to_nhwc(x, BF16 if self.fp16 else F32)
         side = ops.OSB_STREAM
         if side is None:

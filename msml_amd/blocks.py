@@ -1,0 +1,196 @@
+"""Block-level autograd function for IBasicBlock (backbones/frb/iresnet.py:38-67 of the
+reference; also the OSB encoder's blocks, backbones/osb/unet.py:80-91) in bf16 training mode.
+
+One autograd node per residual block instead of eight: the backward is written out by hand, so
+  * the backward-data conv of conv2 / conv1 reduces the backward sums of bn2 / bn1 in its
+    epilogue (msml_conv2d_bnbwd) -- those BatchNorms lose their reduce pass over dy and x,
+  * the gradient that joins at the block input (identity or downsample path + bn1 path) is
+    summed inside bn1's apply kernel instead of a separate element-wise add,
+  * Python / autograd bookkeeping per block drops to one node.
+Arithmetic per tensor is the same as the op-by-op graph in functional.py (same kernels, same
+order of the fixed-order reductions), which stays the path for f32 parity mode and inference.
+"""
+import torch
+
+from . import ops
+from ._lib import BF16, call
+from .ops import cpad
+
+
+def _bn_fwd(x, stats, bn, alpha, residual):
+    """Training-mode BatchNorm (+PReLU) (+residual after it) on raw NHWC tensors.
+    Returns (y, coef[4][C] = scale, shift, mean, invstd)."""
+    c = x.shape[-1]
+    m = x.numel() // c
+    coef = torch.empty(4, c, dtype=torch.float32, device=x.device)
+    if stats is None:
+        rows = ops.bn_stats_rows(m, c)
+        stats = torch.empty(rows, 2, c, dtype=torch.float32, device=x.device)
+        with ops.PROFILE.rec("bn_stats", 0.0, x.numel() * x.element_size()):
+            call("msml_bn_stats", x, m, c, stats, BF16)
+    call("msml_bn_finalize", stats, stats.shape[0], c, float(m), bn.weight, bn.bias, bn.running_mean,
+         bn.running_var, 0.1 if bn.momentum is None else bn.momentum, bn.eps, coef[0], coef[1], coef[2],
+         coef[3])
+    y = torch.empty_like(x)
+    with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
+        call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, 0, y, m, c, BF16)
+    ops.bn_counter(bn)
+    return y, coef
+
+
+def _conv_fwd(x, cm):
+    w = cm.weight
+    cout, cin, r, s = w.shape
+    wp = ops.PACKS.get(w, False, 0, cout, 0, cin, cin, 0, BF16)
+    return ops.conv2d(x, None, wp, None, cpad(cout), r, s, cm.stride[0], cm.padding[0], cm.padding[1], False,
+                      want_stats=True, real=(cin, cout))
+
+
+def _wgrad(dy, x, wparam, cm):
+    """dW of conv `cm` from its output gradient and input; in-place into the flat gradient arena
+    (on the weight-gradient stream) when FlatSGD owns .grad, else a fresh tensor."""
+    cout, cin, r, s = wparam.shape
+    inplace = ops.INPLACE_GRADS and wparam.grad is not None
+    dw = wparam.grad.view(wparam.shape) if inplace else torch.empty_like(wparam)
+    side = ops.WGRAD_STREAM if inplace else None
+    args = (dy, x, dw, cout, cin, cin, 0, r, s, cm.stride[0], cm.padding[0], cm.padding[1])
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+        dy.record_stream(side)             # both operands may be freed (by this stream's allocator
+        x.record_stream(side)              # pool) while the side stream still reads them
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(*args, accumulate=True)
+    else:
+        ops.conv_wgrad(*args, accumulate=inplace)
+    if inplace:
+        ops.grad_ready(wparam)
+        return None
+    return dw
+
+
+def _dgrad(dy, wparam, cm, h, w, bn_x=None, coef=None, alpha=None):
+    """dX of conv `cm`; with bn_x / coef the epilogue also reduces the backward sums of the
+    BatchNorm that produced the conv input.  Returns (dx, partial or None)."""
+    cout, cin, r, s = wparam.shape
+    wp = ops.PACKS.get(wparam.detach(), True, 0, cout, 0, cin, cout, 0, BF16)
+    stride, ph, pw = cm.stride[0], cm.padding[0], cm.padding[1]
+    if bn_x is not None and ops.FUSE_BN_BWD:
+        got = ops.conv_dgrad_bnbwd(dy, wp, cpad(cin), r, s, stride, ph, pw, h, w, bn_x, coef, alpha,
+                                   real=(cout, cin))
+        if got is not None:
+            return got
+    dx, _ = ops.conv2d(dy, None, wp, None, cpad(cin), r, s, stride, ph, pw, True, p=h, q=w, real=(cout, cin))
+    return dx, None
+
+
+class _ParamGrads:
+    """Targets for (dgamma, dbeta, dalpha) of one BatchNorm(+PReLU): the parameters' .grad views of
+    the flat arena (accumulate) or fresh rows that the function returns."""
+
+    def __init__(self, params, c, dev):
+        self.params = params
+        self.want = [p is not None and p.requires_grad for p in params]
+        self.inplace = ops.INPLACE_GRADS and all((not w) or p.grad is not None for w, p in zip(self.want, params))
+        if self.inplace:
+            self.tg = [p.grad if w else None for w, p in zip(self.want, params)]
+        else:
+            pg = torch.empty(3, c, dtype=torch.float32, device=dev)
+            self.tg = [pg[i] if p is not None else None for i, p in enumerate(params)]
+
+    def done(self):
+        if self.inplace:
+            ops.grad_ready(*[p for w, p in zip(self.want, self.params) if w])
+
+    def out(self, i):
+        return self.tg[i] if (self.want[i] and not self.inplace) else None
+
+
+def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None):
+    """BatchNorm(+PReLU) backward.  partial: sums already reduced by the producing conv."""
+    c = x.shape[-1]
+    m = x.numel() // c
+    dx = torch.empty_like(x)
+    if partial is None:
+        rows = ops.bn_stats_rows(m, c)
+        ws = ops.workspace((rows * 3 * c + 2 * c) * 4, x.device)
+        with ops.PROFILE.rec("bn_act_bwd", 0.0, x.numel() * x.element_size() * 5):
+            call("msml_bn_act_bwd", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], None, dx, None,
+                 pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, ws, ws.numel() // 4, BF16)
+        if add is not None:
+            call("msml_add", dx, add, dx, dx.numel(), BF16)
+    else:
+        cw = torch.empty(98 * c, dtype=torch.float32, device=x.device)
+        with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (4 if add is not None else 3)):
+            call("msml_bn_act_bwd_apply", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial,
+                 partial.shape[0], add, dx, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, cw, BF16)
+    pgr.done()
+    return dx
+
+
+class _IBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, blk, *params):
+        # params (for autograd bookkeeping only): conv1.w, conv2.w, [down.w], bn1 g/b, bn2 g/b, prelu,
+        # bn3 g/b, [down bn g/b] -- the arithmetic reads them from the module
+        ds = blk.downsample
+        o1, k1 = _bn_fwd(x, None, blk.bn1, None, None)
+        c1, st1 = _conv_fwd(o1, blk.conv1)
+        o2, k2 = _bn_fwd(c1, st1, blk.bn2, blk.prelu.weight, None)
+        c2, st2 = _conv_fwd(o2, blk.conv2)
+        if ds is not None:
+            d, std = _conv_fwd(x, ds[0])
+            idn, kd = _bn_fwd(d, std, ds[1], None, None)
+        else:
+            d, kd, idn = None, None, x
+        out, k3 = _bn_fwd(c2, st2, blk.bn3, None, idn)
+        ctx.blk = blk
+        ctx.save_for_backward(x, o1, c1, o2, c2, d, k1, k2, k3, kd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, o1, c1, o2, c2, d, k1, k2, k3, kd = ctx.saved_tensors
+        blk = ctx.blk
+        ds = blk.downsample
+        dev = x.device
+        dout = dout.contiguous()
+        n, h, w, _ = x.shape
+        # bn3 (its dy is the block output gradient, which also flows to the identity path)
+        g3 = _ParamGrads((blk.bn3.weight, blk.bn3.bias, None), c2.shape[-1], dev)
+        dc2 = _bn_bwd(dout, c2, k3, None, g3)
+        # conv2: dW beside, dX with bn2's backward sums from the epilogue
+        dw2 = _wgrad(dc2, o2, blk.conv2.weight, blk.conv2)
+        do2, part2 = _dgrad(dc2, blk.conv2.weight, blk.conv2, c1.shape[1], c1.shape[2], c1, k2, blk.prelu.weight)
+        g2 = _ParamGrads((blk.bn2.weight, blk.bn2.bias, blk.prelu.weight), c1.shape[-1], dev)
+        dc1 = _bn_bwd(do2, c1, k2, blk.prelu.weight, g2, part2)
+        # conv1
+        dw1 = _wgrad(dc1, o1, blk.conv1.weight, blk.conv1)
+        do1, part1 = _dgrad(dc1, blk.conv1.weight, blk.conv1, h, w, x, k1, None)
+        # identity / downsample path
+        dwd, gd = None, None
+        if ds is not None:
+            gd = _ParamGrads((ds[1].weight, ds[1].bias, None), d.shape[-1], dev)
+            dd = _bn_bwd(dout, d, kd, None, gd)
+            dwd = _wgrad(dd, x, ds[0].weight, ds[0])
+            join, _ = _dgrad(dd, ds[0].weight, ds[0], h, w)
+        else:
+            join = dout
+        # bn1: dx = bn1 path + joined gradient in one kernel
+        g1 = _ParamGrads((blk.bn1.weight, blk.bn1.bias, None), x.shape[-1], dev)
+        dx = _bn_bwd(do1, x, k1, None, g1, part1, add=join)
+        grads = [dw1, dw2] + ([dwd] if ds is not None else [])
+        grads += [g1.out(0), g1.out(1), g2.out(0), g2.out(1), g2.out(2), g3.out(0), g3.out(1)]
+        if ds is not None:
+            grads += [gd.out(0), gd.out(1)]
+        return (dx, None) + tuple(grads)
+
+
+def iblock(blk, x):
+    """Run IBasicBlock `blk` (training mode, bf16 NHWC input) as one autograd node."""
+    ds = blk.downsample
+    params = [blk.conv1.weight, blk.conv2.weight] + ([ds[0].weight] if ds is not None else [])
+    params += [blk.bn1.weight, blk.bn1.bias, blk.bn2.weight, blk.bn2.bias, blk.prelu.weight,
+               blk.bn3.weight, blk.bn3.bias]
+    if ds is not None:
+        params += [ds[1].weight, ds[1].bias]
+    return _IBlock.apply(x, blk, *params)

@@ -300,6 +300,28 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy,
   });
 }
 
+// Many partial rows (a fused conv epilogue writes one per workgroup: up to ~50k) are first folded
+// to FOLD_ROWS rows by FOLD_ROWS x C/32 workgroups; each fold block owns a contiguous chunk, so
+// the result does not depend on scheduling.
+#define FOLD_ROWS 32
+#define FOLD_MIN_ROWS 512
+template <int NQ>
+__global__ void __launch_bounds__(1024) k_fold_rows(const float* __restrict__ partial, int rows, int C,
+                                                    float* __restrict__ out) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool cok = c < C;
+  const int chunk = (rows + FOLD_ROWS - 1) / FOLD_ROWS;
+  const int r0 = blockIdx.y * chunk;
+  int nr = rows - r0;
+  if (nr > chunk) nr = chunk;
+  if (nr < 0) nr = 0;
+  double s[NQ];
+  fin_reduce<NQ>(partial + (long)r0 * NQ * C, nr, C, c, cok, s);
+  if (threadIdx.x >= 32 || !cok) return;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) out[((long)blockIdx.y * NQ + q) * C + c] = (float)s[q];
+}
+
 __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restrict__ partial, int rows, int C, double count,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   float* __restrict__ dalpha, float* __restrict__ coef, int accumulate) {
@@ -400,6 +422,13 @@ extern "C" int msml_bn_act_bwd_apply(const void* dy, const void* x, const float*
              MSML_ERR_SHAPE, "bn_act_bwd_apply: bad args M=%ld C=%d rows=%d", M, C, rows);
   hipStream_t st = (hipStream_t)stream;
   long n8 = M * (C / 8);
+  if (rows > FOLD_MIN_ROWS) {
+    float* folded = coef_ws + 2 * C;
+    k_fold_rows<3><<<dim3(cdiv(C, 32), FOLD_ROWS), 1024, 0, st>>>(partial, rows, C, folded);
+    MSML_LAUNCH_OK("bn_bwd_fold");
+    partial = folded;
+    rows = FOLD_ROWS;
+  }
   k_bn_bwd_finalize<<<cdiv(C, 32), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef_ws, accumulate);
   MSML_LAUNCH_OK("bn_bwd_finalize");
   MSML_DISPATCH_DTYPE(

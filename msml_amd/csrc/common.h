@@ -155,34 +155,41 @@ struct BnBwdFuse {
 };
 
 struct BnbCoef {
-  float sc[8], sh[8], al[8], mu[8], is[8];
+  float sc[8], sh[8], al[8], is[8], nm[8];     // nm = -mean * invstd: xhat = x * is + nm
 };
 __device__ __forceinline__ BnbCoef bnb_load_coef(const BnBwdFuse& f, int c0) {
   BnbCoef k;
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(f.scale + c0), s1 = *reinterpret_cast<const f32x4*>(f.scale + c0 + 4);
+  const f32x4 h0 = *reinterpret_cast<const f32x4*>(f.shift + c0), h1 = *reinterpret_cast<const f32x4*>(f.shift + c0 + 4);
+  const f32x4 m0 = *reinterpret_cast<const f32x4*>(f.mean + c0), m1 = *reinterpret_cast<const f32x4*>(f.mean + c0 + 4);
+  const f32x4 i0 = *reinterpret_cast<const f32x4*>(f.invstd + c0), i1 = *reinterpret_cast<const f32x4*>(f.invstd + c0 + 4);
+  f32x4 a0 = {1.f, 1.f, 1.f, 1.f}, a1 = a0;
+  if (f.alpha) {
+    a0 = *reinterpret_cast<const f32x4*>(f.alpha + c0);
+    a1 = *reinterpret_cast<const f32x4*>(f.alpha + c0 + 4);
+  }
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    k.sc[j] = f.scale[c0 + j];
-    k.sh[j] = f.shift[c0 + j];
-    k.al[j] = f.alpha ? f.alpha[c0 + j] : 1.f;
-    k.mu[j] = f.mean[c0 + j];
-    k.is[j] = f.invstd[c0 + j];
+  for (int j = 0; j < 4; j++) {
+    k.sc[j] = s0[j]; k.sc[4 + j] = s1[j];
+    k.sh[j] = h0[j]; k.sh[4 + j] = h1[j];
+    k.al[j] = a0[j]; k.al[4 + j] = a1[j];
+    k.is[j] = i0[j]; k.is[4 + j] = i1[j];
+    k.nm[j] = -m0[j] * i0[j]; k.nm[4 + j] = -m1[j] * i1[j];
   }
   return k;
 }
+// branch-free; has_alpha is wave-uniform
 __device__ __forceinline__ void bnb_accum(const BnbCoef& k, bool has_alpha, const Vec8& dy, const Vec8& x,
                                           float (&q)[3][8]) {
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    float gg = dy.v[j];
-    if (has_alpha) {
-      const float z = x.v[j] * k.sc[j] + k.sh[j];
-      if (z <= 0.f) {
-        q[2][j] += gg * z;
-        gg *= k.al[j];
-      }
-    }
-    const float xh = (x.v[j] - k.mu[j]) * k.is[j];
-    q[0][j] += gg;
-    q[1][j] += gg * xh;
+    const float d = dy.v[j];
+    const float z = x.v[j] * k.sc[j] + k.sh[j];
+    const bool neg = has_alpha & (z <= 0.f);
+    const float g = neg ? d * k.al[j] : d;
+    const float xh = x.v[j] * k.is[j] + k.nm[j];
+    q[0][j] += g;
+    q[1][j] += g * xh;
+    q[2][j] += neg ? d * z : 0.f;
   }
 }

@@ -69,8 +69,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // NST = 3: ring with TWO stages in flight across the barrier: counted `s_waitcnt vmcnt(L)` (L =
 //          DMA instructions per thread per stage) + raw s_barrier, never vmcnt(0) in the loop
 //          (cdna_hip_programming.md "Pipelining across barriers").
-template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST>
-__global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs p) {
+// FUSE: backward-data launch with the fused BatchNorm backward-reduce epilogue (bf16 out, no
+// bias / residual / statistics); a separate instantiation so the plain kernel's register
+// allocation is not disturbed by the extra epilogue state.
+template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST, bool FUSE = false>
+__global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(const ConvFastArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in the device pass only
   constexpr int NW = WGM * WGN, NT = NW * 64, RPP = NW * 8;    // waves, threads, rows per pass
   constexpr int NA = BM / RPP, NB = BN / RPP;                  // DMA instructions per thread
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   const long Mc = p.parity ? (long)p.N * Pc * Qc : p.M;
   const long prow = (long)bid + (p.parity ? (long)blockIdx.z * p.tiles_m : 0);   // fused-reduce row
   if (m0 >= Mc) {
-    if (p.bnb.partial)                                 // empty tile of a small parity class
+    if constexpr (FUSE)                                // empty tile of a small parity class
       for (int i = t; i < 3 * BN; i += NT)
         if (n0 + i % BN < p.coutp) p.bnb.partial[(prow * 3 + i / BN) * p.coutp + n0 + i % BN] = 0.f;
     return;
@@ -338,6 +341,25 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
   constexpr bool VIA_LDS = sizeof(TOUT) == 2;
   constexpr int OP = BN + 8;                           // tile pitch in elements
   unsigned short* otile = reinterpret_cast<unsigned short*>(smem);
+  // fused BatchNorm backward-reduce: the saved BatchNorm input of this thread's copy-out chunks is
+  // requested first, so the loads fly during the accumulator -> LDS transpose
+  constexpr int C8 = BN / 8, ITERS = FUSE ? BM * C8 / NT : 1;
+  const int c8 = t % C8, ccol = n0 + c8 * 8;
+  u32x4 xr[ITERS];
+  unsigned int oo[ITERS];                              // element offsets (tensors < 2^31 elements)
+  constexpr unsigned int NO_CHUNK = 0xffffffffu;
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int k = 0; k < ITERS; k++) {
+      const long m = m0 + (t + k * NT) / C8;
+      oo[k] = (m < Mc && ccol < p.coutp) ? (unsigned int)(out_pixel(m) * p.coutp + ccol) : NO_CHUNK;
+#ifdef FAST_ABL_BNB_LOAD
+      xr[k] = u32x4{0, 0, 0, 0};
+#else
+      xr[k] = oo[k] != NO_CHUNK ? *reinterpret_cast<const u32x4*>(p.bnb.x + oo[k]) : u32x4{0, 0, 0, 0};
+#endif
+    }
+  }
   float s1v[TN], s2v[TN];
 #pragma unroll
   for (int j = 0; j < TN; j++) {
@@ -369,42 +391,31 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
     s2v[j] = s2;
   }
   if (VIA_LDS) {
-    __syncthreads();
-    constexpr int C8 = BN / 8;
-    static_assert(NT % C8 == 0, "a thread keeps one 8-channel chunk in the copy-out loop");
-    const bool fuse = p.bnb.partial != nullptr && n0 + (t % C8) * 8 < p.coutp;
-    BnbCoef bk;
-    float bq[3][8];
-    if (fuse) bk = bnb_load_coef(p.bnb, n0 + (t % C8) * 8);
+    static_assert(NT % C8 == 0 && (BM * C8) % NT == 0, "a thread keeps one 8-channel chunk in the copy-out loop");
+    const int col = ccol;
+    if constexpr (FUSE) {
+      // fused BatchNorm backward-reduce (x chunks were fetched before the transpose)
+      const bool cok = col < p.coutp;
+      __syncthreads();
+      BnbCoef bk;
+      if (cok) bk = bnb_load_coef(p.bnb, col);
+      float bq[3][8];
 #pragma unroll
-    for (int q = 0; q < 3; q++)
+      for (int q = 0; q < 3; q++)
 #pragma unroll
-      for (int j = 0; j < 8; j++) bq[q][j] = 0.f;
-    for (int idx = t; idx < BM * C8; idx += NT) {
-      int row = idx / C8, c8 = idx % C8;
-      long m = m0 + row;
-      int col = n0 + c8 * 8;
-      if (m < Mc && col < p.coutp) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(otile + row * OP + c8 * 8);
-        const long o = out_pixel(m) * p.coutp + col;
-        if (p.residual) {                              // fused residual (+ PReLU after it)
-          Vec8 a = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v));
-          Vec8 r = load8<unsigned short>(p.residual + o);
+        for (int j = 0; j < 8; j++) bq[q][j] = 0.f;
 #pragma unroll
-          for (int q = 0; q < 8; q++) {
-            float z = a.v[q] + r.v[q];
-            if (p.res_first && p.alpha) z = z > 0.f ? z : z * p.alpha[col + q];
-            a.v[q] = z;
-          }
-          store8<unsigned short>(reinterpret_cast<unsigned short*>(&v), a);
-        }
-        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + o) = v;
-        if (fuse)
+      for (int k = 0; k < ITERS; k++) {
+        if (oo[k] != NO_CHUNK) {
+          const int row = (t + k * NT) / C8;
+          u32x4 v = *reinterpret_cast<const u32x4*>(otile + row * OP + c8 * 8);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + oo[k]) = v;
+#ifndef FAST_ABL_BNB_ACC
           bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v)),
-                    load8<unsigned short>(p.bnb.x + o), bq);
+                    load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[k])), bq);
+#endif
+        }
       }
-    }
-    if (p.bnb.partial) {
       // the NT / C8 threads that share a channel chunk meet in LDS; fixed-order sums
       constexpr int G = NT / C8;
       __syncthreads();
@@ -412,13 +423,35 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
 #pragma unroll
       for (int q = 0; q < 3; q++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) red[((t / C8) * 3 + q) * BN + (t % C8) * 8 + j] = bq[q][j];
+        for (int j = 0; j < 8; j++) red[((t / C8) * 3 + q) * BN + c8 * 8 + j] = bq[q][j];
       __syncthreads();
       for (int i = t; i < 3 * BN; i += NT) {
         const int q = i / BN, c = i % BN;
         float sum = 0.f;
         for (int g = 0; g < G; g++) sum += red[(g * 3 + q) * BN + c];
         if (n0 + c < p.coutp) p.bnb.partial[(prow * 3 + q) * p.coutp + n0 + c] = sum;
+      }
+    } else {
+      __syncthreads();
+      for (int idx = t; idx < BM * C8; idx += NT) {
+        const int row = idx / C8;
+        const long m = m0 + row;
+        if (m < Mc && col < p.coutp) {
+          u32x4 v = *reinterpret_cast<const u32x4*>(otile + row * OP + c8 * 8);
+          const long o = out_pixel(m) * p.coutp + col;
+          if (p.residual) {                            // fused residual (+ PReLU after it)
+            Vec8 a = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v));
+            Vec8 r = load8<unsigned short>(p.residual + o);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              float z = a.v[q] + r.v[q];
+              if (p.res_first && p.alpha) z = z > 0.f ? z : z * p.alpha[col + q];
+              a.v[q] = z;
+            }
+            store8<unsigned short>(reinterpret_cast<unsigned short*>(&v), a);
+          }
+          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + o) = v;
+        }
       }
     }
   }
@@ -452,7 +485,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64) k_conv_fast(const ConvFastArgs
 #endif
 }
 
-template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST>
+template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST, bool FUSE = false>
 static void launch_fast(ConvFastArgs& a, hipStream_t st) {
   // parity mode: tiles sized for the largest class (cy = cx = 0); smaller classes exit early
   const long mtile = a.parity ? (long)a.N * ((a.P + 1) / 2) * ((a.Q + 1) / 2) : a.M;
@@ -461,7 +494,7 @@ static void launch_fast(ConvFastArgs& a, hipStream_t st) {
   size_t lds = (size_t)NST * (BM + BN) * 128;
   size_t olds = sizeof(TOUT) == 2 ? (size_t)BM * (BN + 8) * 2 : 0;
   if (olds > lds) lds = olds;
-  k_conv_fast<TOUT, BM, BN, WGM, WGN, NST><<<grid, dim3(WGM * WGN * 64), lds, st>>>(a);
+  k_conv_fast<TOUT, BM, BN, WGM, WGN, NST, FUSE><<<grid, dim3(WGM * WGN * 64), lds, st>>>(a);
 }
 
 bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
@@ -534,7 +567,12 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   else if (bn == 128) launch_fast<TO, 128, 128, 2, 2, 2>(a, st);        \
   else if (bn == 64) launch_fast<TO, 256, 64, 4, 1, 2>(a, st);          \
   else launch_fast<TO, 256, 32, 4, 1, 2>(a, st);
-  if (out_dtype == MSML_BF16) { FAST_CASE(unsigned short) }
+  if (bnb) {
+    if (bias || residual || scale || alpha) return false;
+    if (bn == 128) launch_fast<unsigned short, 128, 128, 2, 2, 2, true>(a, st);
+    else if (bn == 64) launch_fast<unsigned short, 256, 64, 4, 1, 2, true>(a, st);
+    else launch_fast<unsigned short, 256, 32, 4, 1, 2, true>(a, st);
+  } else if (out_dtype == MSML_BF16) { FAST_CASE(unsigned short) }
   else { FAST_CASE(float) }
 #undef FAST_CASE
   if (bnb_rows) *bnb_rows = a.tiles_m * (a.parity ? 4 : 1);

@@ -47,7 +47,9 @@ struct ConvHaloArgs {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int PL2, int MT, int BN>
+// FUSE: backward-data launch with the fused BatchNorm backward-reduce (no bias / scale / PReLU /
+// residual / statistics in that case) -- a compile-time split keeps both epilogues in registers.
+template <int PL2, int MT, int BN, bool FUSE>
 __global__ void __launch_bounds__(BN / 32 * 64) __attribute__((amdgpu_waves_per_eu(BN / 128, BN / 128)))
 k_conv_halo(const ConvHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -200,14 +202,39 @@ k_conv_halo(const ConvHaloArgs p) {
 #endif
   constexpr int OP = BN + 8;                           // 528-B rows
   unsigned short* otile = reinterpret_cast<unsigned short*>(smem);
+  // copy-out: thread t stores 16-B chunk c8 of rows (t + k NT) / C8.  With the fused BatchNorm
+  // backward-reduce the saved BatchNorm input of those chunks is requested now, so the loads fly
+  // during the accumulator -> LDS transpose.
+  constexpr int C8 = BN / 8, ITERS = BM * C8 / NT;
+  static_assert(NT % C8 == 0 && (BM * C8) % NT == 0, "a thread keeps one 8-channel chunk in the copy-out loop");
+  const int c8 = t % C8;
+  constexpr bool fuse = FUSE;
+  u32x4 xr[ITERS];
+  BnbCoef bk;
+  float bq[3][8];
+  if (fuse) {
+#pragma unroll
+    for (int k = 0; k < ITERS; k++) {
+      const int m = (t + k * NT) / C8;
+      const int y = m >> PL2, x = m & (PITCH - 1);
+      const bool ok = (x < p.W) & (y0 + y < p.H);
+      const long o = ((long)(n * p.H + y0 + y) * p.W + x) * p.coutp + n0 + c8 * 8;
+      xr[k] = ok ? *reinterpret_cast<const u32x4*>(p.bnb.x + o) : u32x4{0, 0, 0, 0};
+    }
+    bk = bnb_load_coef(p.bnb, n0 + c8 * 8);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) bq[q][j] = 0.f;
   const int kb = wave * 32 + 4 * h;                    // this lane's channels: kb + 8 g + j
-  const bool act_here = p.alpha && !(p.residual && p.res_first);
+  const bool act_here = !FUSE && p.alpha && !(p.residual && p.res_first);
   f32x4 bv[4], sv[4], av[4], s1[4], s2[4];
 #pragma unroll
   for (int g = 0; g < 4; g++) {
     const int col = n0 + kb + 8 * g;
-    bv[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-    sv[g] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bv[g] = (!FUSE && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sv[g] = (!FUSE && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + col) : f32x4{1.f, 1.f, 1.f, 1.f};
     av[g] = act_here ? *reinterpret_cast<const f32x4*>(p.alpha + col) : f32x4{1.f, 1.f, 1.f, 1.f};
     s1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     s2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -222,10 +249,13 @@ k_conv_halo(const ConvHaloArgs p) {
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        float z = acc[i][g * 4 + j] * sv[g][j] + bv[g][j];
-        if (act_here) z = z > 0.f ? z : z * av[g][j];
+        float z = acc[i][g * 4 + j];
+        if (!FUSE) {
+          z = z * sv[g][j] + bv[g][j];
+          if (act_here) z = z > 0.f ? z : z * av[g][j];
+        }
         v[j] = z;
-        if (valid) {
+        if (!FUSE && valid) {
           s1[g][j] += z;
           s2[g][j] += z * z;
         }
@@ -237,38 +267,29 @@ k_conv_halo(const ConvHaloArgs p) {
     }
   }
   __syncthreads();
-  constexpr int C8 = BN / 8;
-  static_assert(NT % C8 == 0, "a thread keeps one 8-channel chunk in the copy-out loop");
-  const bool fuse = p.bnb.partial != nullptr;
-  BnbCoef bk;
-  float bq[3][8];
-  if (fuse) bk = bnb_load_coef(p.bnb, n0 + (t % C8) * 8);
 #pragma unroll
-  for (int q = 0; q < 3; q++)
-#pragma unroll
-    for (int j = 0; j < 8; j++) bq[q][j] = 0.f;
-  for (int idx = t; idx < BM * C8; idx += NT) {
-    const int m = idx / C8, c8 = idx % C8;
+  for (int k = 0; k < ITERS; k++) {
+    const int m = (t + k * NT) / C8;
     const int y = m >> PL2, x = m & (PITCH - 1);
     if (x < p.W && y0 + y < p.H) {
       u32x4 v = *reinterpret_cast<const u32x4*>(otile + m * OP + c8 * 8);
       const int c0 = n0 + c8 * 8;
       const long o = ((long)(n * p.H + y0 + y) * p.W + x) * p.coutp + c0;
-      if (p.residual) {
+      if (!FUSE && p.residual) {
         Vec8 a8 = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v));
         Vec8 r8 = load8<unsigned short>(p.residual + o);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          float z = a8.v[k] + r8.v[k];
-          if (p.res_first && p.alpha) z = z > 0.f ? z : z * p.alpha[c0 + k];
-          a8.v[k] = z;
+        for (int j = 0; j < 8; j++) {
+          float z = a8.v[j] + r8.v[j];
+          if (p.res_first && p.alpha) z = z > 0.f ? z : z * p.alpha[c0 + j];
+          a8.v[j] = z;
         }
         store8<unsigned short>(reinterpret_cast<unsigned short*>(&v), a8);
       }
       *reinterpret_cast<u32x4*>(p.out + o) = v;
       if (fuse)
         bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v)),
-                  load8<unsigned short>(p.bnb.x + o), bq);
+                  load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[k])), bq);
     }
   }
   if (fuse) {
@@ -287,7 +308,7 @@ k_conv_halo(const ConvHaloArgs p) {
       p.bnb.partial[((long)blockIdx.x * 3 + q) * p.coutp + n0 + c] = sum;
     }
   }
-  if (p.stats) {
+  if (!FUSE && p.stats) {
     // per-channel (sum, sumsq) over this workgroup's pixels: lanes hold pixels, so the 32 partials
     // of every lane go through LDS and each lane adds up one (statistic, channel) in a fixed order.
     // One row pair per workgroup; the rows the 128-pixel tiling would have had beyond that are
@@ -315,7 +336,7 @@ k_conv_halo(const ConvHaloArgs p) {
 #endif
 }
 
-template <int PL2, int MT, int BN>
+template <int PL2, int MT, int BN, bool FUSE>
 static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   constexpr int BM = MT * 32, TH = BM >> PL2, HPX = (TH + 2) << PL2;
   a.tpi = cdiv(a.H, TH);
@@ -324,12 +345,12 @@ static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   if (olds > lds) lds = olds;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<PL2, MT, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<PL2, MT, BN, FUSE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(a.N * a.tpi, a.coutp / BN);
-  k_conv_halo<PL2, MT, BN><<<grid, dim3(BN / 32 * 64), lds, st>>>(a);
+  k_conv_halo<PL2, MT, BN, FUSE><<<grid, dim3(BN / 32 * 64), lds, st>>>(a);
 }
 
 // Tried first by msml_conv_fast_dispatch; false = shape not covered here.
@@ -360,6 +381,11 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
   if (bnb_rows) *bnb_rows = (int)tiles;
-  launch_halo<4, 7, 256>(a, st);
+  if (bnb) {
+    if (bias || scale || alpha || residual || stats) return false;
+    launch_halo<4, 7, 256, true>(a, st);
+  } else {
+    launch_halo<4, 7, 256, false>(a, st);
+  }
   return true;
 }

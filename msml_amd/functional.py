@@ -97,6 +97,9 @@ class _Conv(torch.autograd.Function):
             if side is not None:                       # dW has no consumer before the optimizer
                 side.wait_stream(torch.cuda.current_stream())
                 dy.record_stream(side)
+                for xs in (x0, x1):                    # saved activations are freed after this node
+                    if xs is not None:
+                        xs.record_stream(side)
                 ctxm = torch.cuda.stream(side)
                 ctxm.__enter__()
             for x, off, ci in ((x0, 0, c0), (x1, c0, c1)):
@@ -209,8 +212,8 @@ def bn_act(x, stats, bn, prelu=None, residual=None, res_first=False):
     """Apply an nn.BatchNorm module `bn` (+ optional nn.PReLU, + residual) to an NHWC tensor.
     res_first: prelu(bn(x) + residual) instead of prelu(bn(x)) + residual."""
     training = bn.training
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        ops.bn_counter(bn)
     return _BnAct.apply(x, stats, bn.weight, bn.bias, prelu.weight if prelu is not None else None,
                         residual, bn.running_mean, bn.running_var, training,
                         0.1 if bn.momentum is None else bn.momentum, bn.eps, res_first)

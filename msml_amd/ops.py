@@ -201,6 +201,32 @@ WGRAD_STREAM = None
 OSB_STREAM = None
 
 
+# Block-level autograd function for IBasicBlock (blocks.py) and, inside it, the BatchNorm
+# backward-reduce fused into the backward-data conv epilogue.  Switches exist for A/B tests.
+BLOCK_FUNCTION = os.environ.get("MSML_NO_BLOCK_FUNCTION") is None
+FUSE_BN_BWD = os.environ.get("MSML_NO_FUSE_BN_BWD") is None
+
+# nn.BatchNorm's num_batches_tracked += 1 is one tiny kernel per BatchNorm per step; MSML.forward
+# defers them and bumps all counters with one foreach add.
+DEFER_BN_COUNTERS = False
+_PENDING_COUNTERS = []
+
+
+def bn_counter(bn):
+    if bn.num_batches_tracked is None:
+        return
+    if DEFER_BN_COUNTERS:
+        _PENDING_COUNTERS.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
+def flush_bn_counters():
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
+
+
 # Optional callback `fn(param)` invoked by the backward functions right after they have enqueued
 # the kernel that completes param.grad (in-place mode): FlatSGD uses it to launch the bucketed
 # gradient all-reduce while the rest of the backward is still running.

@@ -360,7 +360,7 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, with_alpha):
     for addt in (None, add):
         dx = torch.empty_like(xbn)
         pg = torch.zeros(3, c, device="cuda")
-        cw = torch.empty(2 * c, device="cuda")
+        cw = torch.empty(98 * c, device="cuda")
         _lib.call("msml_bn_act_bwd_apply", dxc, xbn, coef[0], coef[1], alpha, coef[2], coef[3], partial,
                   partial.shape[0], addt, dx, pg[0], pg[1], pg[2] if with_alpha else None, 0, m, c, cw, _lib.BF16)
         ref = want_dx.float() + (addt.float() if addt is not None else 0)

@@ -355,3 +355,53 @@ def test_overlapped_allreduce_one_rank():
     assert nb >= 4
     assert torch.equal(a, b)
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg", [(4, 64, 64, 14, 1), (3, 64, 128, 14, 2), (128, 256, 256, 14, 1), (5, 32, 64, 9, 2)])
+def test_block_function_matches_op_graph(cfg):
+    """IBasicBlock as ONE autograd node (blocks.py: BatchNorm backward sums from the dgrad epilogue,
+    gradient join inside bn1's apply) against the op-by-op graph of functional.py: same forward
+    bits, gradients equal up to the order of the f32 partial sums / one bf16 rounding of the join."""
+    import copy
+    from torch import nn
+    from msml_amd import ops
+    from msml_amd.backbones.frb.iresnet import IBasicBlock, conv1x1
+    n, cin, cout, h, stride = cfg
+    torch.manual_seed(sum(cfg))
+    down = None
+    if stride != 1 or cin != cout:
+        down = nn.Sequential(conv1x1(cin, cout, stride), nn.BatchNorm2d(cout, eps=1e-05))
+    blk = IBasicBlock(cin, cout, stride, down)
+    for p in blk.parameters():
+        if p.dim() == 1:
+            nn.init.uniform_(p, 0.5, 1.5)
+        else:
+            nn.init.normal_(p, 0, (1.0 / (p.shape[1] * 9)) ** 0.5)
+    nn.init.uniform_(blk.prelu.weight, 0.1, 0.4)
+    blk = blk.cuda().train()
+    x0 = ops.to_nhwc(torch.randn(n, cin, h, h).cuda(), 1)
+    dout = None
+    res = []
+    for use_fn in (False, True):
+        b = copy.deepcopy(blk)
+        x = x0.clone().requires_grad_(True)
+        old = ops.BLOCK_FUNCTION
+        ops.BLOCK_FUNCTION = use_fn
+        try:
+            y = b(x)
+            if dout is None:
+                dout = torch.randn_like(y)
+            y.backward(dout)
+        finally:
+            ops.BLOCK_FUNCTION = old
+        torch.cuda.synchronize()
+        res.append((y.detach().float(), x.grad.float(), {k: v.grad.float() for k, v in b.named_parameters()},
+                    {k: v.clone() for k, v in b.named_buffers()}))
+    (y1, dx1, g1, buf1), (y2, dx2, g2, buf2) = res
+    assert torch.equal(y1, y2)
+    for k in buf1:
+        assert torch.equal(buf1[k], buf2[k]), k
+    assert (dx1 - dx2).abs().max().item() <= 2e-2 * dx1.abs().max().item()
+    assert rel_err(dx2.cpu().numpy(), dx1.cpu().numpy()) < 5e-3
+    for k in g1:
+        assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-2, k
