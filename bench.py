@@ -346,7 +346,7 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         k = fam["conv_igemm"]
         ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
-        rec["roofline_family"] = {"bound": "mfma", "kernel": "k_conv_fast / k_conv_igemm (implicit-GEMM conv fwd + dgrad, every shape of the step)",
+        rec["roofline_family"] = {"bound": "mfma", "kernel": "k_conv_halo / k_conv_fast / k_conv_igemm (conv fwd + dgrad, every shape of the step)",
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": None,
                            "launches": k["n"], "avg_us": round(k["ms"] * 1e3 / k["n"], 2)}
@@ -363,7 +363,7 @@ def main():
                 traffic = pm[top]["hbm_bytes"]
         except Exception:
             pass
-        rec["roofline"] = {"bound": "mfma", "kernel": "k_conv_fast<bf16,128,128>", "launch": top,
+        rec["roofline"] = {"bound": "mfma", "kernel": top[top.index("[") + 1:-1] if "[" in top else "conv", "launch": top,
                            "achieved": round(tach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(tach / peak, 4), "traffic": traffic,
                            "algorithmic_flop": tv["flops"] / tv["n"], "launches": tv["n"],

@@ -261,6 +261,11 @@ int msml_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, con
                           float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
                           int C, float* coef_ws, int dtype, void* stream);
 
+/* Name of the kernel the conv entry points launch for a shape (profiling labels only). */
+const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, int H, int W, int P, int Q,
+                               int R, int S, int stride, int pad_h, int pad_w, int transposed,
+                               int in_dtype, int out_dtype, int want_stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -354,11 +354,9 @@ static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
 }
 
 // Tried first by msml_conv_fast_dispatch; false = shape not covered here.
-bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
-                             int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
-                             int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
-                             const float* scale, const float* alpha, const void* residual, int res_first,
-                             const BnBwdFuse* bnb, int* bnb_rows) {
+// Shape test shared by the dispatch and by msml_conv2d_kernel (the name query).
+bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                            int stride, int pad_h, int pad_w, bool want_stats) {
   static const bool off = getenv("MSML_NO_HALO_CONV") != nullptr;
   if (off) return false;
   if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return false;
@@ -368,9 +366,22 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   if ((long)H * W * 10 < (long)tpi * 224 * 7) return false;       // < 70 % real GEMM rows: im2col kernel wins
   const long tiles = (long)N * tpi;
   const int srows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
-  if (tiles < 128 || (stats && tiles > srows)) return false;
+  if (tiles < 128 || (want_stats && tiles > srows)) return false;
   const long in_bytes = (long)N * H * W * c0p * 2, w_bytes = (long)kop * 9 * c0p * 2;
-  if (in_bytes >= 0x70000000L || w_bytes >= 0x70000000L) return false;
+  return in_bytes < 0x70000000L && w_bytes < 0x70000000L;
+}
+
+bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
+                             int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
+                             int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
+                             const float* scale, const float* alpha, const void* residual, int res_first,
+                             const BnBwdFuse* bnb, int* bnb_rows) {
+  if (!msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
+    return false;
+  const int tpi = cdiv(H, 14);
+  const long tiles = (long)N * tpi;
+  const int srows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
+  const long in_bytes = (long)N * H * W * c0p * 2, w_bytes = (long)kop * 9 * c0p * 2;
   ConvHaloArgs a;
   a.in = (const unsigned short*)in0; a.in_bytes = (unsigned int)in_bytes; a.C = c0p;
   a.N = N; a.H = H; a.W = W; a.flip = transposed;

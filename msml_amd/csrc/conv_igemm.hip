@@ -427,3 +427,22 @@ extern "C" int msml_conv2d_bnbwd(const void* in0, int c0p, const void* wp, int k
   MSML_LAUNCH_OK("conv2d_bnbwd");
   return MSML_OK;
 }
+
+
+bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                            int stride, int pad_h, int pad_w, bool want_stats);
+
+// Name of the kernel msml_conv2d / msml_conv2d_fused / msml_conv2d_bnbwd launches for a shape
+// (profiling labels: bench.py's roofline names the kernel it measured).
+extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, int H, int W, int P, int Q,
+                                          int R, int S, int stride, int pad_h, int pad_w, int transposed,
+                                          int in_dtype, int out_dtype, int want_stats) {
+  const int bn = msml_conv_tile_n(coutp);
+  const bool fast = in_dtype == MSML_BF16 && !getenv("MSML_NO_FAST_CONV") && c0p % 32 == 0 && c1p % 32 == 0 &&
+                    (c1p == 0 || ((R * S * (c0p / 32)) & 1) == 0) && (long)N * P * Q < (1L << 24);
+  if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
+      msml_conv_halo_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
+    return "k_conv_halo<pitch 16, 224 x 256, 8 waves>";
+  if (fast) return bn == 128 ? "k_conv_fast<128 x 128, 4 waves>" : (bn == 64 ? "k_conv_fast<256 x 64, 4 waves>" : "k_conv_fast<256 x 32, 4 waves>");
+  return bn == 128 ? "k_conv_igemm<128 x 128>" : (bn == 64 ? "k_conv_igemm<256 x 64>" : "k_conv_igemm<256 x 32>");
+}

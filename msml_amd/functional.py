@@ -574,7 +574,7 @@ def conv_bn_eval(x0, x1, conv_m, bn_m, prelu, residual, c1, res_first):
     out = torch.empty(n, p, q, coutp, dtype=torch.bfloat16, device=x0.device)
     name = "conv_fused"
     if ops.PROFILE.on:
-        name = "conv N+bn c%d+%d->%d %dx%d k%dx%d s%d n%d" % (c0p, c1p, coutp, h, w, r, s, stride, n)
+        name = ops.conv_label("N+bn", c0p, c1p, coutp, n, h, w, p, q, r, s, stride, ph, pw, 0, BF16, BF16, False)
     with ops.PROFILE.rec(name, 2.0 * n * p * q * cin * cout * r * s):
         call("msml_conv2d_fused", x0, c0p, x1, c1p, wp, wp.shape[0], coef[0], coef[1],
              prelu.weight if prelu is not None else None, residual, int(res_first), out, coutp,

@@ -124,6 +124,14 @@ def conv_out_size(h, r, stride, pad, transposed, out_pad=0):
     return (h + 2 * pad - r) // stride + 1
 
 
+def conv_label(kind, c0p, c1p, coutp, n, h, w, p, q, r, s, stride, pad_h, pad_w, transposed, in_dtype, out_dtype,
+               want_stats):
+    """Profiling label of one conv launch: shape + the kernel the library picks for it."""
+    kern = _lib.value("msml_conv2d_kernel", c0p, c1p, coutp, n, h, w, p, q, r, s, stride, pad_h, pad_w,
+                      int(transposed), in_dtype, out_dtype, int(bool(want_stats))).decode()
+    return "conv %s c%d+%d->%d %dx%d k%dx%d s%d n%d [%s]" % (kind, c0p, c1p, coutp, h, w, r, s, stride, n, kern)
+
+
 def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=None, q=None,
            out_dtype=None, want_stats=False, real=None):
     """Raw implicit-GEMM conv.  x0/x1: NHWC tensors; returns (out NHWC, stats or None)."""
@@ -144,7 +152,8 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
     pix = n * h * w if transposed else n * p * q
     name = "conv_igemm"
     if PROFILE.on:
-        name = "conv %s c%d+%d->%d %dx%d k%dx%d s%d n%d" % ("T" if transposed else "N", c0p, c1p, coutp, h, w, r, s, stride, n)
+        name = conv_label("T" if transposed else "N", c0p, c1p, coutp, n, h, w, p, q, r, s, stride, pad_h, pad_w,
+                          transposed, in_dtype, out_dtype, want_stats)
     with PROFILE.rec(name, 2.0 * pix * cin * cout * r * s):
         call("msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats, n, h, w, p,
              q, r, s, stride, pad_h, pad_w, int(transposed), in_dtype, out_dtype)
@@ -166,7 +175,7 @@ def conv_dgrad_bnbwd(dy, wp, coutp, r, s, stride, pad_h, pad_w, p, q, bn_x, coef
     cin, cout = real if real is not None else (c0p, coutp)
     name = "conv_igemm"
     if PROFILE.on:
-        name = "conv T+bnb c%d+0->%d %dx%d k%dx%d s%d n%d" % (c0p, coutp, h, w, r, s, stride, n)
+        name = conv_label("T+bnb", c0p, 0, coutp, n, h, w, p, q, r, s, stride, pad_h, pad_w, 1, BF16, BF16, False)
     with PROFILE.rec(name, 2.0 * n * h * w * cin * cout * r * s):
         rc = try_call("msml_conv2d_bnbwd", dy, c0p, wp, wp.shape[0], out, coutp, n, h, w, p, q, r, s, stride,
                       pad_h, pad_w, 1, bn_x, coef[0], coef[1], alpha, coef[2], coef[3], partial, cap,
