@@ -1,7 +1,8 @@
 // 3x3 / stride-1 / pad-1 convolution (forward, and backward-data with the tap walk flipped) for
-// bf16 NHWC maps that are at most 15 pixels wide -- the 14x14x256 stage that holds 28 of the 48
-// 3x3 convs of IResNet-50 (backbones/frb/iresnet.py:40-67) and the 7x7 / 14x14 levels of the OSB
-// encoder (backbones/osb/unet.py:80-91).  Same contract as msml_conv2d / msml_conv2d_fused.
+// bf16 NHWC maps with Cin % 64 == 0 and Cout % 128 == 0 -- the 28x28x128 and 14x14x256 stages that
+// hold 36 of the 48 3x3 convs of IResNet-50 (backbones/frb/iresnet.py:40-67) and the matching
+// levels of the OSB encoder (backbones/osb/unet.py:80-91).  The image is cut into 14 x 14 pixel
+// tiles; same contract as msml_conv2d / msml_conv2d_fused.
 //
 // k_conv_fast (im2col gather) re-fetches every input pixel 9 times and is bound by the
 // L2 -> LDS fill rate (~80 GB/s per CU).  Here a workgroup owns a strip of TH image rows and all
@@ -26,7 +27,7 @@ struct ConvHaloArgs {
   const unsigned short* in;
   unsigned int in_bytes;
   int C;              // input channels (multiple of 64)
-  int N, H, W, tpi;   // tpi: row strips per image
+  int N, H, W, tpy, tpx;   // 14 x 14 pixel tiles per image column / row
   int flip;           // backward-data: tap (r, s) reads the image at (2 - r, 2 - s)
   const unsigned short* wp;
   unsigned int w_bytes;
@@ -49,39 +50,48 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // FUSE: backward-data launch with the fused BatchNorm backward-reduce (no bias / scale / PReLU /
 // residual / statistics in that case) -- a compile-time split keeps both epilogues in registers.
-template <int PL2, int MT, int BN, bool FUSE>
-__global__ void __launch_bounds__(BN / 32 * 64) __attribute__((amdgpu_waves_per_eu(BN / 128, BN / 128)))
+// BN output channels per workgroup, NWM wave groups along the pixel rows: (256, 1) = 8 waves x
+// 7 accumulator tiles, (128, 2) = 4 channel groups x {4, 3} tiles -- waves w and w + 4 share a SIMD,
+// so every SIMD still carries 7 tiles.
+template <int BN, int NWM, bool FUSE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo(const ConvHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int PITCH = 1 << PL2, NW = BN / 32, NT = NW * 64, BM = MT * 32;
-  constexpr int TH = BM >> PL2, HR = TH + 2, HPX = HR << PL2;
-  constexpr int ABYTES = HPX * 128, BBYTES = BN * 128;
+  constexpr int PL2 = 4, PITCH = 16, MT = 7, KG = BN / 32, NW = KG * NWM, NT = NW * 64, BM = MT * 32;
+  constexpr int TW = 14, TH = 14, HR = TH + 2, HPX = HR << PL2;
+  constexpr int MTW = NWM == 1 ? MT : 4;               // accumulator tiles of one wave (at most)
+  constexpr int ABYTES = HPX * 128;
   constexpr int NAJ = HPX / 8;                         // DMA wave-instructions per slab image
-  constexpr int NAI = (NAJ + NW - 1) / NW, NBI = BN / 8 / NW;
-  static_assert(PITCH >= 16 && HPX % 8 == 0 && BN % 32 == 0, "tile config");
+  constexpr int NAI = (NAJ + NW - 1) / NW;
+  static_assert(NW == 8 && HPX % 8 == 0, "tile config");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                                     // [2][HPX][128 B]
-  char* Bs = smem + 2 * ABYTES;                        // [2][BN][128 B]
+  char* Bs = smem + 2 * ABYTES;                        // [NW][2][32][128 B]
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // scalar: LDS-DMA bases go to M0
-  const int tile = blockIdx.x;
-  const int n = tile / p.tpi, y0 = (tile - n * p.tpi) * TH;
+  const int kg = wave % KG, mg = wave / KG;            // channel group, pixel-row group
+  const int i0 = mg * 4, nmt = NWM == 1 ? MT : (mg == 0 ? 4 : 3);   // this wave's tiles [i0, i0 + nmt)
+  const int tile = blockIdx.x, tpi = p.tpy * p.tpx;
+  const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+  const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
   const int n0 = blockIdx.y * BN;
+  auto pix_ok = [&](int m) { return ((m & 15) < TW) & (x0 + (m & 15) < p.W) & (y0 + (m >> 4) < p.H); };
+  auto pix_off = [&](int m) { return ((long)(n * p.H + y0 + (m >> 4)) * p.W + x0 + (m & 15)) * p.coutp; };
 
   __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.w_bytes, 0x00020000);
 
-  // halo image: LDS pixel hp = hy * PITCH + hx holds input (y0 + hy - 1, hx - 1); its eight
-  // 16-B chunks are XOR-swizzled by (hp >> 1) & 7
+  // halo image: LDS pixel hp = hy * PITCH + hx holds input (y0 + hy - 1, x0 + hx - 1) (zeros
+  // outside the image); its eight 16-B chunks are XOR-swizzled by (hp >> 1) & 7
   unsigned int aoff[NAI];
 #pragma unroll
   for (int i = 0; i < NAI; i++) {
     const int j = wave + i * NW;
     const int hp = j * 8 + (lane >> 3);
     const int logical = (lane & 7) ^ ((hp >> 1) & 7);
-    const int iy = y0 + (hp >> PL2) - 1, ix = (hp & (PITCH - 1)) - 1;
+    const int iy = y0 + (hp >> PL2) - 1, ix = x0 + (hp & (PITCH - 1)) - 1;
     const bool v = (j < NAJ) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
     aoff[i] = v ? (unsigned int)((n * p.H + iy) * p.W + ix) * (unsigned int)(p.C * 2) + logical * 16u : HALO_OOB;
   }
@@ -95,7 +105,7 @@ k_conv_halo(const ConvHaloArgs p) {
   for (int i = 0; i < 4; i++) {
     const int row = i * 8 + (lane >> 3);
     const int logical = (lane & 7) ^ ((row >> 1) & 7);
-    boffg[i] = (unsigned int)((n0 + wave * 32 + row) * p.Ktot) * 2u + logical * 16u;
+    boffg[i] = (unsigned int)((n0 + kg * 32 + row) * p.Ktot) * 2u + logical * 16u;
   }
   auto issue_a = [&](int cs, int buf) {
     char* a = As + buf * ABYTES;
@@ -116,9 +126,9 @@ k_conv_halo(const ConvHaloArgs p) {
 
   // D = W_frag x X_frag: accumulator rows = output channels, columns (lanes) = pixels, so a lane
   // ends up with 4 consecutive channels of one pixel per register quad (8-B LDS stores below)
-  f32x16 acc[MT];
+  f32x16 acc[MTW];
 #pragma unroll
-  for (int i = 0; i < MT; i++)
+  for (int i = 0; i < MTW; i++)
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
 
@@ -135,7 +145,7 @@ k_conv_halo(const ConvHaloArgs p) {
   issue_b(0, 0, 0);
   __syncthreads();                                     // (drains vmcnt first)
   int cs = 0, tr = 0, ts = 0;                          // slab, tap row / column of stage q
-  u32x4 a[2][MT], b[2];
+  u32x4 a[2][MTW], b[2];
   for (int q = 0; q < nstage; q++) {
     int ncs = cs, ntr = tr, nts = ts + 1;
     if (nts == 3) { nts = 0; ntr++; }
@@ -153,14 +163,14 @@ k_conv_halo(const ConvHaloArgs p) {
 #ifndef HALO_ABLATE_COMPUTE
     const int r = p.flip ? 2 - tr : tr, s = p.flip ? 2 - ts : ts;
     const int arow = r32 + s, asw = (arow >> 1) & 7;
-    const char* Arow = As + (cs & 1) * ABYTES + ((r << PL2) * 128) + arow * 128;
+    const char* Arow = As + (cs & 1) * ABYTES + (((r << PL2) + i0 * 32) * 128) + arow * 128;
     const char* B = Bs + (q & 1) * 4096;
     // register double buffer of the fragments of one 16-deep k step; the fences keep hipcc from
     // sinking the reads next to their MFMAs (which exposes the LDS latency at every MFMA)
 #ifdef HALO_ABLATE_READS
     if (q == 0) {
 #pragma unroll
-      for (int i = 0; i < MT; i++) {
+      for (int i = 0; i < MTW; i++) {
         a[0][i] = *reinterpret_cast<const u32x4*>(Arow + ((h ^ asw) << 4) + i * 4096);
         a[1][i] = a[0][i];
       }
@@ -169,7 +179,8 @@ k_conv_halo(const ConvHaloArgs p) {
     }
 #else
 #pragma unroll
-    for (int i = 0; i < MT; i++) a[0][i] = *reinterpret_cast<const u32x4*>(Arow + ((h ^ asw) << 4) + i * 4096);
+    for (int i = 0; i < MTW; i++)
+      if (i < nmt) a[0][i] = *reinterpret_cast<const u32x4*>(Arow + ((h ^ asw) << 4) + i * 4096);
     b[0] = *reinterpret_cast<const u32x4*>(B + bfr[0]);
 #endif
 #pragma unroll
@@ -179,15 +190,17 @@ k_conv_halo(const ConvHaloArgs p) {
       if (kk + 1 < 4) {
         const int ao = (((kk + 1) * 2 + h) ^ asw) << 4;
 #pragma unroll
-        for (int i = 0; i < MT; i++) a[nb][i] = *reinterpret_cast<const u32x4*>(Arow + ao + i * 4096);
+        for (int i = 0; i < MTW; i++)
+          if (i < nmt) a[nb][i] = *reinterpret_cast<const u32x4*>(Arow + ao + i * 4096);
         b[nb] = *reinterpret_cast<const u32x4*>(B + bfr[kk + 1]);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < MT; i++)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[cb]),
-                                                         __builtin_bit_cast(bf16x8, a[cb][i]), acc[i], 0, 0, 0);
+      for (int i = 0; i < MTW; i++)
+        if (i < nmt)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[cb]),
+                                                           __builtin_bit_cast(bf16x8, a[cb][i]), acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
 #endif
@@ -216,10 +229,7 @@ k_conv_halo(const ConvHaloArgs p) {
 #pragma unroll
     for (int k = 0; k < ITERS; k++) {
       const int m = (t + k * NT) / C8;
-      const int y = m >> PL2, x = m & (PITCH - 1);
-      const bool ok = (x < p.W) & (y0 + y < p.H);
-      const long o = ((long)(n * p.H + y0 + y) * p.W + x) * p.coutp + n0 + c8 * 8;
-      xr[k] = ok ? *reinterpret_cast<const u32x4*>(p.bnb.x + o) : u32x4{0, 0, 0, 0};
+      xr[k] = pix_ok(m) ? *reinterpret_cast<const u32x4*>(p.bnb.x + pix_off(m) + n0 + c8 * 8) : u32x4{0, 0, 0, 0};
     }
     bk = bnb_load_coef(p.bnb, n0 + c8 * 8);
   }
@@ -227,7 +237,7 @@ k_conv_halo(const ConvHaloArgs p) {
   for (int q = 0; q < 3; q++)
 #pragma unroll
     for (int j = 0; j < 8; j++) bq[q][j] = 0.f;
-  const int kb = wave * 32 + 4 * h;                    // this lane's channels: kb + 8 g + j
+  const int kb = kg * 32 + 4 * h;                      // this lane's channels: kb + 8 g + j
   const bool act_here = !FUSE && p.alpha && !(p.residual && p.res_first);
   f32x4 bv[4], sv[4], av[4], s1[4], s2[4];
 #pragma unroll
@@ -240,10 +250,10 @@ k_conv_halo(const ConvHaloArgs p) {
     s2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
-  for (int i = 0; i < MT; i++) {
-    const int m = i * 32 + r32;
-    const int y = m >> PL2, x = m & (PITCH - 1);
-    const bool valid = (x < p.W) & (y0 + y < p.H);
+  for (int i = 0; i < MTW; i++) {
+    if (i >= nmt) break;
+    const int m = (i0 + i) * 32 + r32;
+    const bool valid = pix_ok(m);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       float v[4];
@@ -270,11 +280,10 @@ k_conv_halo(const ConvHaloArgs p) {
 #pragma unroll
   for (int k = 0; k < ITERS; k++) {
     const int m = (t + k * NT) / C8;
-    const int y = m >> PL2, x = m & (PITCH - 1);
-    if (x < p.W && y0 + y < p.H) {
+    if (pix_ok(m)) {
       u32x4 v = *reinterpret_cast<const u32x4*>(otile + m * OP + c8 * 8);
       const int c0 = n0 + c8 * 8;
-      const long o = ((long)(n * p.H + y0 + y) * p.W + x) * p.coutp + c0;
+      const long o = pix_off(m) + c0;
       if (!FUSE && p.residual) {
         Vec8 a8 = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v));
         Vec8 r8 = load8<unsigned short>(p.residual + o);
@@ -323,12 +332,16 @@ k_conv_halo(const ConvHaloArgs p) {
         red[lane * 33 + 16 + g * 4 + j] = s2[g][j];
       }
     __syncthreads();
-    const int which = lane >> 5, kl = lane & 31;       // channel kl = 8 g + 4 hh + j
-    const int k = which * 16 + (kl >> 3) * 4 + (kl & 3), hh = (kl >> 2) & 1;
-    float sum = 0.f;
+    if (mg == 0) {                                     // the waves of pixel-row group 0 add both groups
+      const int which = lane >> 5, kl = lane & 31;     // channel kl = 8 g + 4 hh + j
+      const int k = which * 16 + (kl >> 3) * 4 + (kl & 3), hh = (kl >> 2) & 1;
+      float sum = 0.f;
+#pragma unroll
+      for (int gm = 0; gm < NWM; gm++)
 #pragma unroll 8
-    for (int rr = 0; rr < 32; rr++) sum += red[(hh * 32 + rr) * 33 + k];
-    p.stats[((long)blockIdx.x * 2 + which) * p.coutp + n0 + wave * 32 + kl] = sum;
+        for (int rr = 0; rr < 32; rr++) sum += red[gm * KG * 64 * 33 + (hh * 32 + rr) * 33 + k];
+      p.stats[((long)blockIdx.x * 2 + which) * p.coutp + n0 + kg * 32 + kl] = sum;
+    }
     for (int row = gridDim.x + blockIdx.x; row < p.stats_rows; row += gridDim.x)
       for (int c = t; c < 2 * BN; c += NT)
         p.stats[((long)row * 2 + c / BN) * p.coutp + n0 + c % BN] = 0.f;
@@ -336,41 +349,41 @@ k_conv_halo(const ConvHaloArgs p) {
 #endif
 }
 
-template <int PL2, int MT, int BN, bool FUSE>
+template <int BN, int NWM, bool FUSE>
 static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
-  constexpr int BM = MT * 32, TH = BM >> PL2, HPX = (TH + 2) << PL2;
-  a.tpi = cdiv(a.H, TH);
-  size_t lds = 2 * (size_t)HPX * 128 + 2 * (size_t)BN * 128;
-  size_t olds = (size_t)BM * (BN + 8) * 2;
+  size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;      // two halo images + eight private weight rings
+  size_t olds = (size_t)224 * (BN + 8) * 2;
   if (olds > lds) lds = olds;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<PL2, MT, BN, FUSE>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(a.N * a.tpi, a.coutp / BN);
-  k_conv_halo<PL2, MT, BN, FUSE><<<grid, dim3(BN / 32 * 64), lds, st>>>(a);
+  dim3 grid(a.N * a.tpy * a.tpx, a.coutp / BN);
+  k_conv_halo<BN, NWM, FUSE><<<grid, dim3(512), lds, st>>>(a);
 }
 
-// Tried first by msml_conv_fast_dispatch; false = shape not covered here.
 // Shape test shared by the dispatch and by msml_conv2d_kernel (the name query).
 bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                             int stride, int pad_h, int pad_w, bool want_stats) {
   static const bool off = getenv("MSML_NO_HALO_CONV") != nullptr;
   if (off) return false;
+  static const bool wide_only = getenv("MSML_HALO_WIDE_ONLY") != nullptr;    // A/B switch
+  if (wide_only && coutp % 256 != 0) return false;
   if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return false;
-  if (c0p % 64 != 0 || coutp % 256 != 0 || kop < coutp) return false;
-  if (W + 1 > 16) return false;
-  const int tpi = cdiv(H, 14);
-  if ((long)H * W * 10 < (long)tpi * 224 * 7) return false;       // < 70 % real GEMM rows: im2col kernel wins
-  const long tiles = (long)N * tpi;
+  if (c0p % 64 != 0 || c0p < 128 || coutp % 128 != 0 || kop < coutp) return false;   // (one 64-channel
+  // slab = a 9-stage K loop: prologue and epilogue of the single resident workgroup dominate)
+  const long tiles = (long)N * cdiv(H, 14) * cdiv(W, 14);
+  if ((long)N * H * W * 10 < tiles * 224 * 7) return false;       // < 70 % real GEMM rows: im2col kernel wins
   const int srows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
-  if (tiles < 128 || (want_stats && tiles > srows)) return false;
+  if (want_stats && tiles > srows) return false;        // (no batch-size threshold: the kernel choice, and
+  // with it the summation order, must not depend on N -- results are batch-composition independent)
   const long in_bytes = (long)N * H * W * c0p * 2, w_bytes = (long)kop * 9 * c0p * 2;
   return in_bytes < 0x70000000L && w_bytes < 0x70000000L;
 }
 
+// Tried first by msml_conv_fast_dispatch; false = shape not covered here.
 bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
                              int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
@@ -378,25 +391,28 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
                              const BnBwdFuse* bnb, int* bnb_rows) {
   if (!msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
     return false;
-  const int tpi = cdiv(H, 14);
-  const long tiles = (long)N * tpi;
-  const int srows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
-  const long in_bytes = (long)N * H * W * c0p * 2, w_bytes = (long)kop * 9 * c0p * 2;
+  if (bnb && (bias || scale || alpha || residual || stats)) return false;
   ConvHaloArgs a;
+  a.tpy = cdiv(H, 14); a.tpx = cdiv(W, 14);
+  const long tiles = (long)N * a.tpy * a.tpx;
+  const long in_bytes = (long)N * H * W * c0p * 2, w_bytes = (long)kop * 9 * c0p * 2;
   a.in = (const unsigned short*)in0; a.in_bytes = (unsigned int)in_bytes; a.C = c0p;
   a.N = N; a.H = H; a.W = W; a.flip = transposed;
   a.wp = (const unsigned short*)wp; a.w_bytes = (unsigned int)w_bytes; a.Ktot = 9 * c0p;
   a.out = (unsigned short*)out; a.coutp = coutp;
   a.bias = bias; a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual;
-  a.res_first = res_first; a.stats = stats; a.stats_rows = srows;
+  a.res_first = res_first; a.stats = stats;
+  a.stats_rows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
   if (bnb_rows) *bnb_rows = (int)tiles;
+  const bool wide = coutp % 256 == 0;
   if (bnb) {
-    if (bias || scale || alpha || residual || stats) return false;
-    launch_halo<4, 7, 256, true>(a, st);
+    if (wide) launch_halo<256, 1, true>(a, st);
+    else launch_halo<128, 2, true>(a, st);
   } else {
-    launch_halo<4, 7, 256, false>(a, st);
+    if (wide) launch_halo<256, 1, false>(a, st);
+    else launch_halo<128, 2, false>(a, st);
   }
   return true;
 }

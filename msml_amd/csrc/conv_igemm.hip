@@ -442,7 +442,7 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
                     (c1p == 0 || ((R * S * (c0p / 32)) & 1) == 0) && (long)N * P * Q < (1L << 24);
   if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
       msml_conv_halo_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
-    return "k_conv_halo<pitch 16, 224 x 256, 8 waves>";
+    return coutp % 256 == 0 ? "k_conv_halo<14x14 px x 256 ch, 8 waves>" : "k_conv_halo<14x14 px x 128 ch, 8 waves>";
   if (fast) return bn == 128 ? "k_conv_fast<128 x 128, 4 waves>" : (bn == 64 ? "k_conv_fast<256 x 64, 4 waves>" : "k_conv_fast<256 x 32, 4 waves>");
   return bn == 128 ? "k_conv_igemm<128 x 128>" : (bn == 64 ? "k_conv_igemm<256 x 64>" : "k_conv_igemm<256 x 32>");
 }

@@ -55,6 +55,7 @@ class _Conv(torch.autograd.Function):
                               cfg["pad_w"], deconv, out_dtype=cfg.get("out_dtype"),
                               want_stats=cfg.get("want_stats", False), real=(c0 + c1, cout))
         ctx.cfg = cfg
+        ctx.set_materialize_grads(False)       # no zeros tensor for the statistics output's "gradient"
         ctx.has_bias = bias is not None
         ctx.wparam = cfg.get("grad_param", weight)      # the leaf whose .grad receives dW
         ctx.bparam = bias
@@ -68,6 +69,8 @@ class _Conv(torch.autograd.Function):
     def backward(ctx, dy, _dstats):
         x0, x1, weight = ctx.saved_tensors
         cfg = ctx.cfg
+        if dy is None:
+            return None, None, None, None, None, None
         deconv, c0, c1, cout = cfg["deconv"], cfg["c0"], cfg["c1"], cfg["cout"]
         stride, ph, pw = cfg["stride"], cfg["pad_h"], cfg["pad_w"]
         r, s = weight.shape[2], weight.shape[3]

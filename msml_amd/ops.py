@@ -295,6 +295,7 @@ class PackCache:
 
     def __init__(self):
         self.entries = {}          # key -> dict(desc, dst, stamp)
+        self.stale_log = None      # debugging: list that collects every lazy (non-batched) repack
         self.table = None
         self.order = []
         self.last_epoch = -1
@@ -324,6 +325,8 @@ class PackCache:
             self.table = None
         st = self._stamp(w)
         if e["stamp"] != st:
+            if self.stale_log is not None:
+                self.stale_log.append((tuple(w.shape), transpose, e["stamp"], st))
             e["desc"][0] = w.data_ptr()
             t = torch.tensor([e["desc"]], dtype=torch.int64, device=w.device)
             call("msml_pack_weights_batched", t, 1, dtype)

@@ -263,12 +263,16 @@ def test_conv_fused_eval_bn(shape, res_first):
 
 # (N, Cin, Cout, H, W): shapes routed to the halo-tile 3x3 kernel (conv_halo.hip): W <= 15,
 # Cin % 64 == 0, Cout % 256 == 0, >= 128 row strips
-HALO = [
+HALO = [   # (Cin = 64 stays on the im2col kernel: the shapes below with 64 input channels test that fallback too)
     (128, 64, 256, 14, 14),      # one 64-channel slab
     (128, 192, 256, 14, 14),     # three slabs: image double buffer wraps
     (130, 64, 256, 7, 7),        # too few real rows per strip: stays on the im2col kernel
     (128, 64, 512, 13, 13),      # two channel tiles, ragged width
     (70, 64, 256, 26, 14),       # two strips per image, the second one 12 rows
+    (40, 64, 256, 28, 28),       # 2 x 2 tiles per image: interior halos are real pixels
+    (40, 128, 128, 28, 28),      # 128 output channels: 4 channel groups x 2 pixel-row groups
+    (24, 64, 128, 28, 40),       # ragged last tile column (12 px), 6 tiles per image
+    (10, 64, 384, 56, 56),       # 128-channel variant with 3 channel tiles, 16 tiles per image
 ]
 
 
@@ -330,7 +334,7 @@ def _bn_bwd_unfused(dy, x, coef, alpha, m, c):
 
 # (N, K = dy channels, C = dX / BatchNorm channels, H, stride): halo kernel, im2col kernel with
 # full and ragged tiles, stride-2 parity classes (odd size: unequal classes)
-BNBWD = [(128, 64, 256, 14, 1), (3, 64, 64, 14, 1), (5, 128, 64, 9, 1), (4, 64, 128, 14, 2), (3, 128, 64, 9, 2)]
+BNBWD = [(128, 64, 256, 14, 1), (40, 128, 128, 28, 1), (3, 64, 64, 14, 1), (5, 128, 64, 9, 1), (4, 64, 128, 14, 2), (3, 128, 64, 9, 2)]
 
 
 @pytest.mark.parametrize("with_alpha", [False, True])
