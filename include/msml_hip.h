@@ -220,6 +220,12 @@ int msml_gemm_splitk(const void* a, int M, int K, const void* wp, int kop, float
  * w[Afull][Bfull][R][S].  Used once per training step for the forward and backward-data operands
  * of every conv / deconv / linear of the model. */
 int msml_pack_weights_batched(const long* table, int count, int dtype, void* stream);
+/* Same packing through LDS tiles (coalesced on both sides; the per-step refresh).  Only the real
+ * elements are written: dst must carry its zero padding already (R*S <= 49).  tile_prefix: device
+ * array [count] with the exclusive prefix sum of msml_pack_tiles(A, B, R, S) over the entries. */
+int msml_pack_tiles(int A, int B, int R, int S);
+int msml_pack_weights_tiled(const long* table, const int* tile_prefix, int count, int total_tiles,
+                            int dtype, void* stream);
 
 /* dst[c][r] = src[r][c] (storage dtype), dst rows ld_d long, zero-filled for r >= R.  Wn^T for the
  * PartialFC dX GEMM (headers/partial_fc.py:169). */

@@ -167,6 +167,72 @@ extern "C" int msml_pack_weights_batched(const long* table, int count, int dtype
 }
 
 
+// Tiled variant for the per-step refresh: a workgroup moves a 32 x BT block of (a, b) index pairs
+// with all R*S taps through LDS, so the f32 parameter is read in contiguous BT*R*S-float runs and
+// the packed operand is written in contiguous channel runs (the element-wise kernel above reads
+// with a stride of R*S floats and spends its time on integer division: 0.75 ms per step for the
+// 55 M parameters of ires50-MSML).  Writes only real elements: the zero padding of dst (channel,
+// K and row padding) must already be there (it never changes).
+static inline int pack_bt(int RS) { return RS <= 9 ? 32 : (RS <= 16 ? 16 : 8); }
+extern "C" int msml_pack_tiles(int A, int B, int R, int S) { return cdiv(A, 32) * cdiv(B, pack_bt(R * S)); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_pack_tiled(const long* __restrict__ table, const int* __restrict__ prefix,
+                                                    int count) {
+  extern __shared__ float tile[];                      // [32][BT * RS + 1]
+  // entry of this block: last e with prefix[e] <= blockIdx.x
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long* d = table + (long)lo * 16;
+  const float* w = reinterpret_cast<const float*>(d[0]);
+  T* dst = reinterpret_cast<T*>(d[1]);
+  const int Bfull = (int)d[3], a_off = (int)d[4], A = (int)d[5], b_off = (int)d[6], B = (int)d[7];
+  const int R = (int)d[8], S = (int)d[9], transpose = (int)d[10];
+  const int C1 = (int)d[11], C1p = (int)d[12], C2 = (int)d[13], C2p = (int)d[14];
+  const int RS = R * S, BT = RS <= 9 ? 32 : (RS <= 16 ? 16 : 8);
+  const int K0 = (RS * C1p + 31) / 32 * 32;
+  const int K1 = C2 > 0 ? (RS * C2p + 31) / 32 * 32 : 0;
+  const int Ktot = K0 + K1;
+  const int tiles_b = (B + BT - 1) / BT;
+  const int lt = blockIdx.x - prefix[lo];
+  const int a0 = (lt / tiles_b) * 32, b0 = (lt % tiles_b) * BT;
+  const int na = A - a0 < 32 ? A - a0 : 32, nb = B - b0 < BT ? B - b0 : BT;
+  const int run = nb * RS, pitch = BT * RS + 1;
+  for (int i = threadIdx.x; i < na * run; i += 256) {
+    const int a = i / run, j = i - a * run;
+    tile[a * pitch + j] = w[((long)(a_off + a0 + a) * Bfull + b_off + b0) * RS + j];
+  }
+  __syncthreads();
+  // the contiguous channel index of dst is b (forward packs) or a (transposed packs): make it the
+  // fastest thread index
+  const int nc = transpose ? na : nb, no = transpose ? nb : na;
+  for (int i = threadIdx.x; i < no * RS * nc; i += 256) {
+    const int cidx = i % nc, rest = i / nc;
+    const int tap = rest % RS, oidx = rest / RS;
+    const int a = transpose ? cidx : oidx, bb = transpose ? oidx : cidx;
+    const int ko = transpose ? b0 + bb : a0 + a;       // packed row
+    const int ci = transpose ? a0 + a : b0 + bb;       // channel inside the concatenated input
+    const int seg = ci >= C1;
+    const int c = seg ? ci - C1 : ci;
+    const int cp = seg ? C2p : C1p;
+    store1<T>(dst + (long)ko * Ktot + (seg ? K0 : 0) + tap * cp + c, tile[a * pitch + bb * RS + tap]);
+  }
+}
+
+extern "C" int msml_pack_weights_tiled(const long* table, const int* tile_prefix, int count, int total_tiles,
+                                       int dtype, void* stream) {
+  MSML_CHECK(table && tile_prefix && count > 0 && total_tiles > 0, MSML_ERR_SHAPE, "pack_weights_tiled: bad args");
+  const size_t lds = (size_t)32 * (32 * 9 + 1 > 8 * 49 + 1 ? 32 * 9 + 1 : 8 * 49 + 1) * sizeof(float);
+  MSML_DISPATCH_DTYPE(dtype, "pack_weights_tiled",
+                      k_pack_tiled<DT><<<total_tiles, 256, lds, (hipStream_t)stream>>>(table, tile_prefix, count);)
+  MSML_LAUNCH_OK("pack_weights_tiled");
+  return MSML_OK;
+}
+
+
 // ---------------------------------------------------------------- 2-D transpose ---------------
 // dst[c][r] = src[r][c] for r < R, c < C; dst rows are ld_d long and zero-filled for r in
 // [R, ld_d).  64 x 64 tiles through LDS (coalesced both ways).  Used for Wn^T of the PartialFC

@@ -317,7 +317,7 @@ class PackCache:
             kop = (cpad(ko) + tile_n(cpad(ko)) - 1) // tile_n(cpad(ko)) * tile_n(cpad(ko))
             c1p, c2p = cpad(c1), cpad(c2) if c2 else 0
             ktot = kpad(r * s * c1p) + (kpad(r * s * c2p) if c2 else 0)
-            dst = torch.empty(kop, ktot, dtype=TORCH_DTYPE[dtype], device=w.device)
+            dst = torch.zeros(kop, ktot, dtype=TORCH_DTYPE[dtype], device=w.device)   # padding stays zero
             desc = [0, dst.data_ptr(), afull, bfull, a_off, a_n, b_off, b_n, r, s, int(transpose), c1,
                     c1p, c2, c2p, kop]
             e = {"desc": desc, "dst": dst, "stamp": None, "w": w}
@@ -348,13 +348,23 @@ class PackCache:
         if self.table is None or self.order != ptrs:
             for e in ents:
                 e["desc"][0] = e["w"].data_ptr()
-            self.table = torch.tensor([e["desc"] for e in ents], dtype=torch.int64, device=ents[0]["dst"].device)
+            dev = ents[0]["dst"].device
+            self.table = torch.tensor([e["desc"] for e in ents], dtype=torch.int64, device=dev)
+            tiles = [_lib.value("msml_pack_tiles", e["desc"][5], e["desc"][7], e["desc"][8], e["desc"][9]) for e in ents]
+            pre = [0]
+            for n_ in tiles[:-1]:
+                pre.append(pre[-1] + n_)
+            self.prefix = torch.tensor(pre, dtype=torch.int32, device=dev)
+            self.total_tiles = pre[-1] + tiles[-1]
             self.order = ptrs
         if any(DTYPE_OF[e["dst"].dtype] != dtype for e in ents):
             for e in ents:       # mixed precisions: fall back to lazy per-entry packing
                 e["stamp"] = None
             return
-        call("msml_pack_weights_batched", self.table, len(ents), dtype)
+        if max(e["desc"][8] * e["desc"][9] for e in ents) <= 49:
+            call("msml_pack_weights_tiled", self.table, self.prefix, len(ents), self.total_tiles, dtype)
+        else:
+            call("msml_pack_weights_batched", self.table, len(ents), dtype)
         for e in ents:
             e["stamp"] = self._stamp(e["w"])
 

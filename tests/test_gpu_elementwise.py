@@ -96,3 +96,34 @@ def test_fm_full_size_linearity():
     _lib.call("msml_fm_fuse_fwd", x, y1, za, n, 0, 0, _lib.F32)
     _lib.call("msml_fm_fuse_fwd", x, y1 + y2, zb, n, 0, 0, _lib.F32)
     assert ((zb - za) - 2 * y2).abs().max().item() < 1e-5
+
+
+def test_pack_refresh_tiled_matches_elementwise():
+    """PackCache.refresh() (LDS-tiled batched kernel, real elements only) == the element-wise pack
+    of the same sub-blocks: forward / transposed operands, concat segments, sub-block offsets,
+    1x1 / 3x3 / 4x4 / 7x7 taps, channel counts that are not multiples of the tile."""
+    from msml_amd import ops
+    torch.manual_seed(3)
+    specs = [  # (shape [A][B][R][S], transpose, a_off, a_n, b_off, b_n, c1, c2)
+        ((64, 64, 3, 3), False, 0, 64, 0, 64, 64, 0),
+        ((64, 82, 3, 3), False, 0, 64, 0, 82, 64, 18),       # FM same_conv on cat(yf, yo)
+        ((128, 64, 3, 3), True, 0, 128, 0, 64, 128, 0),      # backward-data operand
+        ((64, 82, 3, 3), True, 0, 64, 64, 18, 64, 0),        # backward-data of the 2nd segment
+        ((36, 18, 4, 4), True, 0, 36, 0, 18, 36, 0),         # deconv forward operand
+        ((36, 18, 4, 4), False, 18, 18, 0, 18, 18, 0),       # deconv backward, sub-block of rows
+        ((18, 64, 7, 1), False, 0, 18, 0, 64, 64, 0),
+        ((40, 40, 7, 7), False, 0, 40, 0, 40, 40, 0),
+        ((256, 128, 1, 1), False, 0, 256, 0, 128, 128, 0),
+    ]
+    ws = [torch.randn(sp[0], device="cuda") for sp in specs]
+    cache = ops.PackCache()
+    for w, sp in zip(ws, specs):
+        cache.get(w, *sp[1:], _lib.BF16)
+    for w in ws:
+        w.mul_(1.5).add_(0.25)
+    cache.refresh()
+    ref = ops.PackCache()
+    for w, sp in zip(ws, specs):
+        want = ref.get(w, *sp[1:], _lib.BF16)
+        got = cache.get(w, *sp[1:], _lib.BF16)
+        assert torch.equal(got, want), sp
