@@ -505,6 +505,12 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
 
 // Called by msml_conv2d (conv_igemm.hip) when the fast-path conditions hold.  Returns false if
 // this kernel does not apply.
+bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
+                           int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
+                           int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
+                           const float* scale, const float* alpha, const void* residual, int res_first,
+                           const BnBwdFuse* bnb, int* bnb_rows);
+
 bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
@@ -515,6 +521,10 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   if (bnb && (out_dtype != MSML_BF16 || stats)) return false;
   if ((scale || alpha || residual) && out_dtype != MSML_BF16) return false;
   if (c0p % 32 != 0 || (in1 && c1p % 32 != 0)) return false;
+  if (!in1 && out_dtype == MSML_BF16 &&
+      msml_conv_ws_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h,
+                            pad_w, transposed, st, scale, alpha, residual, res_first, bnb, bnb_rows))
+    return true;
   if (!in1 && out_dtype == MSML_BF16 &&
       msml_conv_halo_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h,
                               pad_w, transposed, st, scale, alpha, residual, res_first, bnb, bnb_rows))

@@ -431,6 +431,8 @@ extern "C" int msml_conv2d_bnbwd(const void* in0, int c0p, const void* wp, int k
 
 bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                             int stride, int pad_h, int pad_w, bool want_stats);
+bool msml_conv_ws_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                          int stride, int pad_h, int pad_w, bool want_stats);
 
 // Name of the kernel msml_conv2d / msml_conv2d_fused / msml_conv2d_bnbwd launches for a shape
 // (profiling labels: bench.py's roofline names the kernel it measured).
@@ -440,6 +442,9 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
   const int bn = msml_conv_tile_n(coutp);
   const bool fast = in_dtype == MSML_BF16 && !getenv("MSML_NO_FAST_CONV") && c0p % 32 == 0 && c1p % 32 == 0 &&
                     (c1p == 0 || ((R * S * (c0p / 32)) & 1) == 0) && (long)N * P * Q < (1L << 24);
+  if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
+      msml_conv_ws_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
+    return "k_conv_ws<64 -> 64 channels, weights resident, persistent>";
   if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
       msml_conv_halo_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
     return coutp % 256 == 0 ? "k_conv_halo<14x14 px x 256 ch, 8 waves>" : "k_conv_halo<14x14 px x 128 ch, 8 waves>";

@@ -1,0 +1,338 @@
+// Weights-stationary persistent 3x3 / stride-1 / pad-1 convolution for bf16 NHWC maps with
+// Cin = Cout = 64: the 112x112 and 56x56 levels of the FRB and the OSB encoder
+// (backbones/frb/iresnet.py:40-67, backbones/osb/unet.py:80-91) -- forward, and backward-data with
+// the tap walk flipped.  Same contract as msml_conv2d / msml_conv2d_fused / msml_conv2d_bnbwd.
+//
+// With 64 x 64 channels the whole packed weight (9 taps x 64 x 64 bf16 = 72 KB) fits in LDS, so
+// one workgroup per CU loads it ONCE and then walks over 14 x 14 pixel tiles (halo image in LDS,
+// as in conv_halo.hip): per tile only 32 KB of input enter LDS for 16.5 MFLOP (the im2col kernel
+// fills 40 KB per 2.1 MFLOP at this width and is bound by that fill).  The next tile's image is
+// fetched during the current tile's MFMAs (two image buffers); the bf16 output tile is transposed
+// through the image buffer that was just consumed.  No barrier and no load wait inside a tile's
+// 36 k-steps.  BatchNorm partial statistics (forward) and the fused BatchNorm backward-reduce
+// (backward-data) accumulate in registers over all tiles of the workgroup and leave one partial
+// row per workgroup.
+#include <stdlib.h>
+
+#include "common.h"
+
+struct ConvWsArgs {
+  const unsigned short* in;
+  unsigned int in_bytes;
+  int N, H, W, tpy, tpx, ntiles;
+  int flip;
+  const unsigned short* wp;      // [64][576] bf16, K order [tap][c]
+  unsigned short* out;
+  const float* bias;
+  const float* scale;
+  const float* alpha;
+  const unsigned short* residual;
+  int res_first;
+  float* stats;
+  int stats_rows;
+  BnBwdFuse bnb;
+};
+
+#define WS_OOB 0x78000000u
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool FUSE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_ws(const ConvWsArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = 64, PL2 = 4, PITCH = 16, TW = 14, TH = 14, BM = 224, NT = 512;
+  constexpr int WBYTES = 9 * 64 * 128, ABYTES = 256 * 128;
+  constexpr int OP = C + 8;                            // transposed output tile pitch (elements)
+  constexpr int C8 = C / 8, ITERS = (BM * C8 + NT - 1) / NT;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ws = smem;                                     // [9 taps][64 rows][128 B]
+  char* As = smem + WBYTES;                            // [2][256 px][128 B]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kg = wave & 1, mg = wave >> 1;             // channel group (32), pixel-row group
+  const int i0 = 2 * mg, nmt = mg < 3 ? 2 : 1;         // this wave's 32-pixel tiles [i0, i0 + nmt)
+  const int r32 = lane & 31, h = lane >> 5;
+  const int tpi = p.tpy * p.tpx;
+
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 64 * 576 * 2, 0x00020000);
+
+  // ---- weights: 72 pieces of 8 rows x 128 B; piece j = tap * 8 + row block
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int j = wave + i * 8, tap = j >> 3, row = (j & 7) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    const unsigned int off = (unsigned int)(row * 576 + tap * 64) * 2u + logical * 16u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + j * 1024), 16, off, 0, 0, 0);
+  }
+  // ---- halo image of a tile: LDS pixel hp = hy * 16 + hx <- input (y0 + hy - 1, x0 + hx - 1)
+  auto issue_a = [&](int tile, int buf) {
+    const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+    const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
+    char* a = As + buf * ABYTES;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int j = wave + i * 8;
+      const int hp = j * 8 + (lane >> 3);
+      const int logical = (lane & 7) ^ ((hp >> 1) & 7);
+      const int iy = y0 + (hp >> PL2) - 1, ix = x0 + (hp & (PITCH - 1)) - 1;
+      const bool v = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      const unsigned int off = v ? (unsigned int)((n * p.H + iy) * p.W + ix) * (unsigned int)(C * 2) + logical * 16u : WS_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(a + j * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  // fragment offsets (see conv_halo.hip): weights row kg * 32 + r32, pixels (i0 + i) * 32 + r32 + tap offset
+  int bfr[4];
+  {
+    const int row = kg * 32 + r32;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) bfr[kk] = row * 128 + (((kk * 2 + h) ^ ((row >> 1) & 7)) << 4);
+  }
+  const int kb = kg * 32 + 4 * h;                      // this lane's output channels: kb + 8 g + j
+  const int c8 = t % C8;
+
+  // epilogue coefficients and the accumulators that live across all tiles of this workgroup
+  const bool act_here = !FUSE && p.alpha && !(p.residual && p.res_first);
+  f32x4 bv[4], sv[4], av[4], s1[4], s2[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int col = kb + 8 * g;
+    bv[g] = (!FUSE && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sv[g] = (!FUSE && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    av[g] = act_here ? *reinterpret_cast<const f32x4*>(p.alpha + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+    s1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  BnbCoef bk;
+  float bq[3][8];
+  if (FUSE) bk = bnb_load_coef(p.bnb, c8 * 8);
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) bq[q][j] = 0.f;
+
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) issue_a(tile, 0);
+  __syncthreads();                                     // weights + first image landed (drains vmcnt)
+
+  for (int it = 0; tile < p.ntiles; it++, tile += gridDim.x) {
+    const int cur = it & 1;
+    const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+    const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
+    auto pix_ok = [&](int m) { return ((m & 15) < TW) & (x0 + (m & 15) < p.W) & (y0 + (m >> 4) < p.H); };
+    auto pix_off = [&](int m) { return ((long)(n * p.H + y0 + (m >> 4)) * p.W + x0 + (m & 15)) * C; };
+    // next tile's image (its buffer was the transpose tile of the previous iteration: the barrier
+    // that closes an iteration orders those reads before this write)
+    if (tile + (int)gridDim.x < p.ntiles) issue_a(tile + gridDim.x, cur ^ 1);
+    u32x4 xr[ITERS];
+    if (FUSE) {                                        // saved BatchNorm input of this thread's chunks
+#pragma unroll
+      for (int k = 0; k < ITERS; k++) {
+        const int idx = t + k * NT, m = idx / C8;
+        xr[k] = (idx < BM * C8 && pix_ok(m)) ? *reinterpret_cast<const u32x4*>(p.bnb.x + pix_off(m) + c8 * 8)
+                                              : u32x4{0, 0, 0, 0};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+    const char* Abase = As + cur * ABYTES + i0 * 32 * 128;
+    u32x4 a[2][2], b[2];
+    for (int tap = 0; tap < 9; tap++) {
+      const int tr = tap / 3, ts = tap - tr * 3;
+      const int r = p.flip ? 2 - tr : tr, s = p.flip ? 2 - ts : ts;
+      const int arow = r32 + s, asw = (arow >> 1) & 7;
+      const char* Arow = Abase + ((r << PL2) + arow) * 128;
+      const char* B = Ws + tap * 8192;
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+        if (i < nmt) a[0][i] = *reinterpret_cast<const u32x4*>(Arow + ((h ^ asw) << 4) + i * 4096);
+      b[0] = *reinterpret_cast<const u32x4*>(B + bfr[0]);
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int cb = kk & 1, nb = cb ^ 1;
+        if (kk + 1 < 4) {
+          const int ao = (((kk + 1) * 2 + h) ^ asw) << 4;
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+            if (i < nmt) a[nb][i] = *reinterpret_cast<const u32x4*>(Arow + ao + i * 4096);
+          b[nb] = *reinterpret_cast<const u32x4*>(B + bfr[kk + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+          if (i < nmt)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[cb]),
+                                                             __builtin_bit_cast(bf16x8, a[cb][i]), acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();     // every wave is done with image `cur`; the next image has landed (vmcnt drained)
+
+    // ---- epilogue: affine / PReLU / statistics in registers, transpose through the consumed image
+    unsigned short* otile = reinterpret_cast<unsigned short*>(As + cur * ABYTES);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (i >= nmt) break;
+      const int m = (i0 + i) * 32 + r32;
+      const bool valid = pix_ok(m);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float z = acc[i][g * 4 + j];
+          if (!FUSE) {
+            z = z * sv[g][j] + bv[g][j];
+            if (act_here) z = z > 0.f ? z : z * av[g][j];
+          }
+          v[j] = z;
+          if (!FUSE && valid) {
+            s1[g][j] += z;
+            s2[g][j] += z * z;
+          }
+        }
+        u32x2 pk;
+        pk[0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
+        pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(otile + m * OP + kb + 8 * g) = pk;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITERS; k++) {
+      const int idx = t + k * NT, m = idx / C8;
+      if (idx < BM * C8 && pix_ok(m)) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(otile + m * OP + c8 * 8);
+        const long o = pix_off(m) + c8 * 8;
+        if (!FUSE && p.residual) {
+          Vec8 a8 = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v));
+          Vec8 r8 = load8<unsigned short>(p.residual + o);
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            float z = a8.v[j] + r8.v[j];
+            if (p.res_first && p.alpha) z = z > 0.f ? z : z * p.alpha[c8 * 8 + j];
+            a8.v[j] = z;
+          }
+          store8<unsigned short>(reinterpret_cast<unsigned short*>(&v), a8);
+        }
+        *reinterpret_cast<u32x4*>(p.out + o) = v;
+        if (FUSE)
+          bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v)),
+                    load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[k])), bq);
+      }
+    }
+    __syncthreads();     // transpose tile read out: its buffer may take the image after next
+  }
+
+  // ---- one partial row per workgroup (the weight region of LDS is free now)
+  if (FUSE) {
+    constexpr int G = NT / C8;                         // 64 threads share a channel chunk
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) red[((t / C8) * 3 + q) * C + c8 * 8 + j] = bq[q][j];
+    __syncthreads();
+    for (int i = t; i < 3 * C; i += NT) {
+      const int q = i / C, c = i % C;
+      float sum = 0.f;
+      for (int g = 0; g < G; g++) sum += red[(g * 3 + q) * C + c];
+      p.bnb.partial[((long)blockIdx.x * 3 + q) * C + c] = sum;
+    }
+  }
+  if (!FUSE && p.stats) {
+    float* red = reinterpret_cast<float*>(smem) + wave * 64 * 33;
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        red[lane * 33 + g * 4 + j] = s1[g][j];
+        red[lane * 33 + 16 + g * 4 + j] = s2[g][j];
+      }
+    __syncthreads();
+    if (mg == 0) {                                     // waves 0 / 1 add the four pixel-row groups
+      const int which = lane >> 5, kl = lane & 31;     // channel kl = 8 g + 4 hh + j
+      const int k = which * 16 + (kl >> 3) * 4 + (kl & 3), hh = (kl >> 2) & 1;
+      float sum = 0.f;
+#pragma unroll
+      for (int gm = 0; gm < 4; gm++)
+#pragma unroll 8
+        for (int rr = 0; rr < 32; rr++) sum += red[gm * 2 * 64 * 33 + (hh * 32 + rr) * 33 + k];
+      p.stats[((long)blockIdx.x * 2 + which) * C + kg * 32 + kl] = sum;
+    }
+    for (int row = gridDim.x + blockIdx.x; row < p.stats_rows; row += gridDim.x)
+      for (int c = t; c < 2 * C; c += NT) p.stats[(long)row * 2 * C + c] = 0.f;
+  }
+#endif
+}
+
+static int ws_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+  }
+  return n;
+}
+
+bool msml_conv_ws_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                          int stride, int pad_h, int pad_w, bool want_stats) {
+  static const bool off = getenv("MSML_NO_WS_CONV") != nullptr;
+  if (off) return false;
+  if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return false;
+  if (c0p != 64 || coutp != 64 || kop < 64) return false;
+  const long tiles = (long)N * cdiv(H, 14) * cdiv(W, 14);
+  if ((long)N * H * W * 10 < tiles * 224 * 7) return false;       // < 70 % real GEMM rows: im2col kernel wins
+  const int wgs = tiles < ws_num_cus() ? (int)tiles : ws_num_cus();
+  if (want_stats && wgs > cdiv((long)N * P * Q, msml_conv_tile_m(coutp))) return false;
+  return (long)N * H * W * c0p * 2 < 0x70000000L && tiles < (1L << 30);
+}
+
+template <bool FUSE>
+static void launch_ws(ConvWsArgs& a, hipStream_t st) {
+  const size_t lds = 9 * 64 * 128 + 2 * 256 * 128 + 512;      // (+ the 2 pixels the padding rows read past an image)
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_ws<FUSE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int wgs = a.ntiles < ws_num_cus() ? a.ntiles : ws_num_cus();
+  k_conv_ws<FUSE><<<dim3(wgs), dim3(512), lds, st>>>(a);
+}
+
+// Tried by msml_conv_fast_dispatch before the im2col kernel; false = shape not covered here.
+bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
+                           int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
+                           int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
+                           const float* scale, const float* alpha, const void* residual, int res_first,
+                           const BnBwdFuse* bnb, int* bnb_rows) {
+  if (!msml_conv_ws_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
+    return false;
+  if (bnb && (bias || scale || alpha || residual || stats)) return false;
+  ConvWsArgs a;
+  a.tpy = cdiv(H, 14); a.tpx = cdiv(W, 14);
+  a.ntiles = N * a.tpy * a.tpx;
+  a.in = (const unsigned short*)in0; a.in_bytes = (unsigned int)((long)N * H * W * c0p * 2);
+  a.N = N; a.H = H; a.W = W; a.flip = transposed;
+  a.wp = (const unsigned short*)wp;
+  a.out = (unsigned short*)out;
+  a.bias = bias; a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual;
+  a.res_first = res_first; a.stats = stats;
+  a.stats_rows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
+  a.bnb = BnBwdFuse{};
+  if (bnb) a.bnb = *bnb;
+  if (bnb_rows) *bnb_rows = a.ntiles < ws_num_cus() ? a.ntiles : ws_num_cus();
+  if (bnb) launch_ws<true>(a, st);
+  else launch_ws<false>(a, st);
+  return true;
+}

@@ -273,6 +273,8 @@ HALO = [   # (Cin = 64 stays on the im2col kernel: the shapes below with 64 inpu
     (40, 128, 128, 28, 28),      # 128 output channels: 4 channel groups x 2 pixel-row groups
     (24, 64, 128, 28, 40),       # ragged last tile column (12 px), 6 tiles per image
     (10, 64, 384, 56, 56),       # 128-channel variant with 3 channel tiles, 16 tiles per image
+    (20, 64, 64, 56, 56),        # weights-stationary persistent kernel (conv_ws.hip): 320 tiles > 256 CUs
+    (5, 64, 64, 28, 40),         # ... ragged tile column, fewer tiles than CUs
 ]
 
 
@@ -334,7 +336,7 @@ def _bn_bwd_unfused(dy, x, coef, alpha, m, c):
 
 # (N, K = dy channels, C = dX / BatchNorm channels, H, stride): halo kernel, im2col kernel with
 # full and ragged tiles, stride-2 parity classes (odd size: unequal classes)
-BNBWD = [(128, 64, 256, 14, 1), (40, 128, 128, 28, 1), (3, 64, 64, 14, 1), (5, 128, 64, 9, 1), (4, 64, 128, 14, 2), (3, 128, 64, 9, 2)]
+BNBWD = [(128, 64, 256, 14, 1), (40, 128, 128, 28, 1), (3, 64, 64, 14, 1), (20, 64, 64, 56, 1), (5, 128, 64, 9, 1), (4, 64, 128, 14, 2), (3, 128, 64, 9, 2)]
 
 
 @pytest.mark.parametrize("with_alpha", [False, True])
