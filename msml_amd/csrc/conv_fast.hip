@@ -282,12 +282,18 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
 #pragma unroll
         for (int j = 0; j < TN; j++) b[nb][j] = *reinterpret_cast<const u32x4*>(B + boff[kk + 1] + j * 4096);
       }
+#ifndef MSML_NO_SCHED_FENCE
+      __builtin_amdgcn_sched_barrier(0);               // keep the reads of step kk + 1 ahead of these MFMAs
+#endif
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
               __builtin_bit_cast(bf16x8, a[cb][i]), __builtin_bit_cast(bf16x8, b[cb][j]), acc[i][j], 0, 0, 0);
+#ifndef MSML_NO_SCHED_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   };
 

@@ -148,19 +148,34 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
     if (st + 1 < nstages) gissue(st + 1, cur ^ 1);
     const char* ub = smem + cur * STAGE + aofs;
     const char* vb = smem + cur * STAGE + UBYTES + bofs;
+    // register double buffer of the fragments of one pixel group (16 k-values); the fences keep
+    // hipcc from sinking the transposing reads next to their MFMAs
+    s16x8 a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) a[0][i] = trf(ub + i * 1024);
+#pragma unroll
+    for (int j = 0; j < TN; j++) b[0][j] = trf(vb + j * 1024);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {                    // pixel group kk = 16 k-values
-      s16x8 a[TM], b[TN];
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (kk + 1 < 4) {
 #pragma unroll
-      for (int i = 0; i < TM; i++) a[i] = trf(ub + kk * (GA * 1024) + i * 1024);
+        for (int i = 0; i < TM; i++) a[nb][i] = trf(ub + (kk + 1) * (GA * 1024) + i * 1024);
 #pragma unroll
-      for (int j = 0; j < TN; j++) b[j] = trf(vb + kk * (GB * 1024) + j * 1024);
+        for (int j = 0; j < TN; j++) b[nb][j] = trf(vb + (kk + 1) * (GB * 1024) + j * 1024);
+      }
+#ifndef MSML_NO_SCHED_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+              __builtin_bit_cast(bf16x8, a[cb][i]), __builtin_bit_cast(bf16x8, b[cb][j]), acc[i][j], 0, 0, 0);
+#ifndef MSML_NO_SCHED_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     __syncthreads();
     cur ^= 1;
