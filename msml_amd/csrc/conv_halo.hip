@@ -249,11 +249,16 @@ k_conv_halo(const ConvHaloArgs p) {
     s1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     s2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // Forward launches without a residual store straight from registers: v_permlane32_swap gives
+  // the lane pair of a pixel 16 contiguous channels each (32 B), so a wave writes 64 B runs per
+  // pixel with two 16-B stores per lane and tile -- no LDS transpose, no barrier.
+  const bool direct = !FUSE && p.residual == nullptr;
 #pragma unroll
   for (int i = 0; i < MTW; i++) {
     if (i >= nmt) break;
     const int m = (i0 + i) * 32 + r32;
     const bool valid = pix_ok(m);
+    u32x2 pk[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       float v[4];
@@ -270,12 +275,29 @@ k_conv_halo(const ConvHaloArgs p) {
           s2[g][j] += z * z;
         }
       }
-      u32x2 pk;
-      pk[0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
-      pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
-      *reinterpret_cast<u32x2*>(otile + m * OP + kb + 8 * g) = pk;
+      pk[g][0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
+      pk[g][1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
+      if (!direct) *reinterpret_cast<u32x2*>(otile + m * OP + kb + 8 * g) = pk[g];
+    }
+    if (direct) {
+      // lanes (pixel, h = 0 / 1) hold channels 8 g + 4 h + (0..3); after the swaps h = 0 holds
+      // channels 0-7 and 16-23, h = 1 holds 8-15 and 24-31 of the wave's 32
+      u32x4 lo, hi;
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        auto r01 = __builtin_amdgcn_permlane32_swap(pk[0][e], pk[1][e], false, false);
+        auto r23 = __builtin_amdgcn_permlane32_swap(pk[2][e], pk[3][e], false, false);
+        lo[e] = r01[0]; lo[2 + e] = r01[1];
+        hi[e] = r23[0]; hi[2 + e] = r23[1];
+      }
+      if (valid) {
+        unsigned short* o = p.out + pix_off(m) + n0 + kg * 32 + 8 * h;
+        *reinterpret_cast<u32x4*>(o) = lo;
+        *reinterpret_cast<u32x4*>(o + 16) = hi;
+      }
     }
   }
+  if (!direct) {
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < ITERS; k++) {
@@ -300,6 +322,7 @@ k_conv_halo(const ConvHaloArgs p) {
         bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v)),
                   load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[k])), bq);
     }
+  }
   }
   if (fuse) {
     constexpr int G = NT / C8;
