@@ -272,6 +272,12 @@ const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, int H, int W,
                                int R, int S, int stride, int pad_h, int pad_w, int transposed,
                                int in_dtype, int out_dtype, int want_stats);
 
+/* Stem im2col (iresnet.py:209 conv1 / unet.py:193 on the 3-channel image): x NCHW f32 ->
+ * out[N][P][Q][KP], k = (r*S + s)*C + c, zeros for k >= R*S*C and outside the image; the stem then
+ * runs as a 1x1 conv over KP channels with the weight reordered to [Cout][R][S][C]. */
+int msml_stem_im2col(const float* x, void* out, int N, int C, int H, int W, int P, int Q, int R,
+                     int S, int stride, int pad, int KP, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,13 @@ def conv_bn(conv_m, bn_m, x0, x1=None, prelu=None, residual=None, c1=0, res_firs
     """conv -> BatchNorm (-> PReLU) (+ residual); BN statistics come from the conv epilogue.
     Inference (eval mode, bf16, no autograd): BatchNorm / PReLU / residual are folded into the
     conv epilogue (one kernel, no intermediate tensor)."""
+    if isinstance(x0, Fh.RawImage):
+        cw = conv_m.weight
+        if (x1 is None and residual is None and conv_m.bias is None and not isinstance(conv_m, nn.ConvTranspose2d)
+                and cw.shape[1] * cw.shape[2] * cw.shape[3] <= 32 and conv_m.out_channels % 32 == 0
+                and conv_m.padding[0] == conv_m.padding[1] and cw.shape[2] == cw.shape[3]):
+            return Fh.stem_conv_bn(x0, conv_m, bn_m, prelu)
+        x0 = x0.nhwc()
     if (not bn_m.training and not torch.is_grad_enabled() and x0.dtype == torch.bfloat16
             and conv_m.bias is None and not isinstance(conv_m, nn.ConvTranspose2d)
             and conv_m.out_channels % 32 == 0):

@@ -96,7 +96,8 @@ class MSML(nn.Module):
 
     def _forward(self, x, label, ori):
         from .. import ops
-        xh = Fh.to_nhwc(x, BF16 if self.fp16 else F32)
+        # bf16: the stems unfold the raw image themselves (im2col + 1x1 conv); f32: padded NHWC
+        xh = Fh.RawImage(x.float()) if self.fp16 else Fh.to_nhwc(x, F32)
         side = ops.OSB_STREAM
         if side is None:
             seg_list = self.osb(xh)                # [seg0, seg1, seg2, seg3, seg5]

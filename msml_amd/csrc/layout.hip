@@ -233,6 +233,64 @@ extern "C" int msml_pack_weights_tiled(const long* table, const int* tile_prefix
 }
 
 
+// ---------------------------------------------------------------- stem im2col -----------------
+// The stems convolve the 3-channel image (iresnet.py:209 `conv1`, unet.py:193): as an NHWC conv
+// the 3 channels pad to 32 and the 3x3 kernel walks K = 288, 27 of which are real.  Instead the
+// image is unfolded once: out[n][oy][ox][k] = x[n][c][oy*stride - pad + r][ox*stride - pad + s]
+// with k = (r*S + s)*C + c < R*S*C <= KP (zeros above), and the stem becomes a 1x1 conv over
+// KP = 32 channels (9x fewer MFMAs and operand bytes; its weight gradient likewise).
+// CC / RR / SS > 0: compile-time channel and kernel sizes (the k -> (tap, c) decode is integer
+// division: with run-time divisors the kernel was VALU-bound at 1.3 TB/s)
+template <typename T, int CC, int RR, int SS>
+__global__ void __launch_bounds__(256) k_stem_im2col(const float* __restrict__ x, T* __restrict__ out, int N, int C_,
+                                                     int H, int W, int P, int Q, int R_, int S_, int stride,
+                                                     int pad, int KP) {
+  const int C = CC > 0 ? CC : C_, R = RR > 0 ? RR : R_, S = SS > 0 ? SS : S_;
+  // one thread per (pixel, 8-channel chunk): consecutive threads store consecutive 16 B
+  const int K8 = KP / 8;
+  const long total = (long)N * P * Q * K8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k0 = (int)(i % K8) * 8;
+    const long pix = i / K8;
+    const int ox = (int)(pix % Q);
+    const long t = pix / Q;
+    const int oy = (int)(t % P), n = (int)(t / P);
+    const float* xn = x + (long)n * C * H * W;
+    Vec8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = k0 + j, tap = k / C, c = k - tap * C;
+      const int r = tap / S, s2 = tap - r * S;
+      const int iy = oy * stride - pad + r, ix = ox * stride - pad + s2;
+      const bool ok = (tap < R * S) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+      v.v[j] = ok ? xn[((long)c * H + iy) * W + ix] : 0.f;
+    }
+    store8<T>(out + pix * KP + k0, v);
+  }
+}
+
+extern "C" int msml_stem_im2col(const float* x, void* out, int N, int C, int H, int W, int P, int Q, int R,
+                                int S, int stride, int pad, int KP, int dtype, void* stream) {
+  MSML_CHECK(x && out && N > 0 && C > 0 && H > 0 && W > 0 && P > 0 && Q > 0 && R > 0 && S > 0 && stride > 0,
+             MSML_ERR_SHAPE, "stem_im2col: bad dims");
+  MSML_CHECK(KP % 8 == 0 && R * S * C <= KP, MSML_ERR_SHAPE, "stem_im2col: R*S*C = %d does not fit KP = %d",
+             R * S * C, KP);
+  const long total = (long)N * P * Q * (KP / 8);
+  const int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+  if (C == 3 && R == 3 && S == 3) {
+    MSML_DISPATCH_DTYPE(dtype, "stem_im2col",
+                        (k_stem_im2col<DT, 3, 3, 3>)<<<grid, 256, 0, (hipStream_t)stream>>>(x, (DT*)out, N, C, H, W, P,
+                                                                                            Q, R, S, stride, pad, KP);)
+  } else {
+    MSML_DISPATCH_DTYPE(dtype, "stem_im2col",
+                        (k_stem_im2col<DT, 0, 0, 0>)<<<grid, 256, 0, (hipStream_t)stream>>>(x, (DT*)out, N, C, H, W, P,
+                                                                                            Q, R, S, stride, pad, KP);)
+  }
+  MSML_LAUNCH_OK("stem_im2col");
+  return MSML_OK;
+}
+
+
 // ---------------------------------------------------------------- 2-D transpose ---------------
 // dst[c][r] = src[r][c] for r < R, c < C; dst rows are ld_d long and zero-filled for r in
 // [R, ld_d).  64 x 64 tiles through LDS (coalesced both ways).  Used for Wn^T of the PartialFC

@@ -583,3 +583,91 @@ def conv_bn_eval(x0, x1, conv_m, bn_m, prelu, residual, c1, res_first):
              prelu.weight if prelu is not None else None, residual, int(res_first), out, coutp,
              n, h, w, p, q, r, s, stride, ph, pw, 0)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Stems on the raw image (bf16 mode): im2col once, then a 1x1 conv over 32 channels.
+class RawImage:
+    """The NCHW f32 input image as handed to MSML.forward, for the stems' im2col path.  The padded
+    NHWC tensor the generic conv path needs is only built if somebody asks for it."""
+
+    def __init__(self, x):
+        self.raw = x
+        self.dtype = torch.bfloat16
+        self._nhwc = None
+
+    def nhwc(self):
+        if self._nhwc is None:
+            self._nhwc = to_nhwc(self.raw, BF16)
+        return self._nhwc
+
+    def record_stream(self, stream):
+        self.raw.record_stream(stream)
+
+
+def _stem_pack(conv_m):
+    """Packed [Cout][R][S][C] (K = 27 -> 32) weight of a stem conv, refreshed when the parameter changes."""
+    w = conv_m.weight
+    stamp = (w._version, ops.WEIGHT_EPOCH, w.data_ptr())
+    hit = getattr(conv_m, "_msml_stem_pack", None)
+    if hit is None or hit[0] != stamp:
+        cout, cin, r, s = w.shape
+        w2 = w.detach().permute(0, 2, 3, 1).reshape(cout, r * s * cin, 1, 1).contiguous()
+        hit = (stamp, ops.pack_weight(w2, False, r * s * cin, 0, BF16))
+        conv_m._msml_stem_pack = hit
+    return hit[1]
+
+
+class _StemConv(torch.autograd.Function):
+    """3x3 conv on the 3-channel image as im2col + 1x1 conv; only the weight gets a gradient."""
+
+    @staticmethod
+    def forward(ctx, weight, conv_m, raw):
+        cout, cin, r, s = weight.shape
+        col = ops.stem_im2col(raw, r, s, conv_m.stride[0], conv_m.padding[0])
+        wp = _stem_pack(conv_m)
+        y, stats = ops.conv2d(col, None, wp, None, cpad(cout), 1, 1, 1, 0, 0, False, want_stats=True,
+                              real=(r * s * cin, cout))
+        ctx.set_materialize_grads(False)
+        ctx.wparam = weight
+        ctx.save_for_backward(col)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        if dy is None:
+            return None, None, None
+        (col,) = ctx.saved_tensors
+        w = ctx.wparam
+        cout, cin, r, s = w.shape
+        k = r * s * cin
+        dw2 = torch.empty(cout, k, 1, 1, dtype=torch.float32, device=dy.device)
+        ops.conv_wgrad(dy.contiguous(), col, dw2, cout, k, k, 0, 1, 1, 1, 0, 0)
+        dw = dw2.view(cout, r, s, cin).permute(0, 3, 1, 2)          # back to the parameter's OIHW
+        if ops.INPLACE_GRADS and w.grad is not None:
+            w.grad.view(w.shape).add_(dw)
+            ops.grad_ready(w)
+            return None, None, None
+        return dw.contiguous(), None, None
+
+
+def stem_conv_bn(raw, conv_m, bn_m, prelu):
+    """Stem conv -> BatchNorm -> PReLU on a RawImage (training and inference)."""
+    if not bn_m.training and not torch.is_grad_enabled():
+        cout, cin, r, s = conv_m.weight.shape
+        col = ops.stem_im2col(raw.raw, r, s, conv_m.stride[0], conv_m.padding[0])
+        wp = _stem_pack(conv_m)
+        coef = _eval_bn_coef(bn_m, cpad(cout))
+        n, p, q, kp = col.shape
+        out = torch.empty(n, p, q, cpad(cout), dtype=torch.bfloat16, device=col.device)
+        name = "conv_fused"
+        if ops.PROFILE.on:
+            name = ops.conv_label("N+bn", kp, 0, cpad(cout), n, p, q, p, q, 1, 1, 1, 0, 0, 0, BF16, BF16, False)
+        with ops.PROFILE.rec(name, 2.0 * n * p * q * r * s * cin * cout):
+            call("msml_conv2d_fused", col, kp, None, 0, wp, wp.shape[0], coef[0], coef[1],
+                 prelu.weight if prelu is not None else None, None, 0, out, cpad(cout), n, p, q, p, q, 1, 1,
+                 1, 0, 0, 0)
+        return out
+    y, stats = _StemConv.apply(conv_m.weight, conv_m, raw.raw)
+    return bn_act(y, stats if stats.numel() else None, bn_m, prelu)

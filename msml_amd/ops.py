@@ -124,6 +124,17 @@ def conv_out_size(h, r, stride, pad, transposed, out_pad=0):
     return (h + 2 * pad - r) // stride + 1
 
 
+def stem_im2col(x, r, s, stride, pad, kp=32, dtype=BF16):
+    """NCHW f32 image -> [N][P][Q][kp] patches, k = (r*S + s)*C + c (msml_stem_im2col)."""
+    n, c, h, w = x.shape
+    p = conv_out_size(h, r, stride, pad, False)
+    q = conv_out_size(w, s, stride, pad, False)
+    out = torch.empty(n, p, q, kp, dtype=TORCH_DTYPE[dtype], device=x.device)
+    with PROFILE.rec("stem_im2col", 0.0, x.numel() * 4 + out.numel() * out.element_size()):
+        call("msml_stem_im2col", x.contiguous(), out, n, c, h, w, p, q, r, s, stride, pad, kp, dtype)
+    return out
+
+
 def conv_label(kind, c0p, c1p, coutp, n, h, w, p, q, r, s, stride, pad_h, pad_w, transposed, in_dtype, out_dtype,
                want_stats):
     """Profiling label of one conv launch: shape + the kernel the library picks for it."""

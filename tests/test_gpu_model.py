@@ -405,3 +405,40 @@ def test_block_function_matches_op_graph(cfg):
     assert rel_err(dx2.cpu().numpy(), dx1.cpu().numpy()) < 5e-3
     for k in g1:
         assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-2, k
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_stem_im2col_path_matches_nhwc_conv(stride):
+    """bf16 stems: im2col of the raw image + 1x1 conv (functional.RawImage) == the 3x3 conv on the
+    NHWC image padded to 32 channels -- outputs, batch statistics and the weight gradient."""
+    import copy
+    from torch import nn
+    from msml_amd.backbones import _nn
+    torch.manual_seed(7 + stride)
+    conv = nn.Conv2d(3, 64, 3, stride, 1, bias=False)
+    bn, pr = nn.BatchNorm2d(64, eps=1e-5), nn.PReLU(64)
+    nn.init.normal_(conv.weight, 0, 0.2)
+    nn.init.uniform_(pr.weight, 0.1, 0.4)
+    mods = [nn.ModuleList([conv, bn, pr]).cuda().train()]
+    mods.append(copy.deepcopy(mods[0]))
+    x = torch.randn(6, 3, 30, 22, device="cuda")
+    outs = []
+    for (c, b, a), inp in zip(mods, (Fh.RawImage(x), Fh.to_nhwc(x, 1))):
+        y = _nn.conv_bn(c, b, inp, prelu=a)
+        if not outs:
+            dy = torch.randn_like(y)
+        y.backward(dy)
+        outs.append((y.detach().float(), c.weight.grad.clone(), b.running_var.clone(), b.weight.grad.clone()))
+    (y1, g1, rv1, bg1), (y2, g2, rv2, bg2) = outs
+    assert y1.shape == y2.shape
+    assert (y1 - y2).abs().max().item() <= 2e-2 * y2.abs().max().item()
+    assert rel_err(g1.cpu().numpy(), g2.cpu().numpy()) < 1e-2
+    assert torch.allclose(rv1, rv2, rtol=1e-3)
+    assert rel_err(bg1.cpu().numpy(), bg2.cpu().numpy()) < 1e-2
+    # inference: fused epilogue on the im2col operand
+    for (c, b, a) in mods:
+        c.eval(); b.eval(); a.eval()
+    with torch.no_grad():
+        e1 = _nn.conv_bn(mods[0][0], mods[0][1], Fh.RawImage(x), prelu=mods[0][2]).float()
+        e2 = _nn.conv_bn(mods[1][0], mods[1][1], Fh.to_nhwc(x, 1), prelu=mods[1][2]).float()
+    assert (e1 - e2).abs().max().item() <= 2e-2 * e2.abs().max().item()
