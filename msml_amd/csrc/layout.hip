@@ -209,6 +209,26 @@ __global__ void __launch_bounds__(256) k_pack_tiled(const long* __restrict__ tab
   // the contiguous channel index of dst is b (forward packs) or a (transposed packs): make it the
   // fastest thread index
   const int nc = transpose ? na : nb, no = transpose ? nb : na;
+  const int cbase = transpose ? a0 : b0;               // first channel (inside the concatenated input)
+  if (nc % 8 == 0 && C1 % 8 == 0 && cbase % 8 == 0) {
+    // 8 consecutive channels per thread: one 16-B (bf16) store
+    const int n8 = nc / 8;
+    for (int i = threadIdx.x; i < no * RS * n8; i += 256) {
+      const int c8 = i % n8, rest = i / n8;
+      const int tap = rest % RS, oidx = rest / RS;
+      const int ko = transpose ? b0 + oidx : a0 + oidx;
+      const int ci = cbase + c8 * 8;
+      const int seg = ci >= C1;
+      const int c = seg ? ci - C1 : ci;
+      const int cp = seg ? C2p : C1p;
+      Vec8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        v.v[j] = transpose ? tile[(c8 * 8 + j) * pitch + oidx * RS + tap] : tile[oidx * pitch + (c8 * 8 + j) * RS + tap];
+      store8<T>(dst + (long)ko * Ktot + (seg ? K0 : 0) + tap * cp + c, v);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < no * RS * nc; i += 256) {
     const int cidx = i % nc, rest = i / nc;
     const int tap = rest % RS, oidx = rest / RS;
