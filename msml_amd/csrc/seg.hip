@@ -122,23 +122,35 @@ __global__ void __launch_bounds__(256) k_seg_sums(const float* __restrict__ logi
 __global__ void k_seg_loss(const float* __restrict__ sums, int N, float alpha, float beta,
                            float* __restrict__ loss, float* __restrict__ coef) {
   __shared__ double sh_sup[2], sh_nll[2], sh_kl[2];
+  __shared__ double red[3][2][256];
   const int t = threadIdx.x;
-  if (t < 2) {
-    double sup_tot = 0.0, nll = 0.0, kl = 0.0;
-    for (int n = 0; n < N; n++) {
-      const float* q = sums + (n * 2 + t) * 5;
+  // every thread sums its images (f64), then a fixed-order tree over the 256 threads
+  double acc[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+  for (int n = t; n < N; n += blockDim.x)
+    for (int s = 0; s < 2; s++) {
+      const float* q = sums + (n * 2 + s) * 5;
       double sup = q[0];
       if (sup > 0.0) {
         double pb0 = q[1] / sup, pb1 = q[2] / sup;
-        double pbs = t == 0 ? pb0 : pb1;
-        nll += -log(pbs);
-        kl += sup * pb0 * log(pb0) - pb0 * q[3] + sup * pb1 * log(pb1) - pb1 * q[4];
-        sup_tot += sup;
+        double pbs = s == 0 ? pb0 : pb1;
+        acc[0][s] += sup;
+        acc[1][s] += -log(pbs);
+        acc[2][s] += sup * pb0 * log(pb0) - pb0 * q[3] + sup * pb1 * log(pb1) - pb1 * q[4];
       }
     }
-    sh_sup[t] = sup_tot;
-    sh_nll[t] = nll;
-    sh_kl[t] = kl;
+  for (int a = 0; a < 3; a++)
+    for (int s = 0; s < 2; s++) red[a][s][t] = acc[a][s];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w)
+      for (int a = 0; a < 3; a++)
+        for (int s = 0; s < 2; s++) red[a][s][t] += red[a][s][t + w];
+    __syncthreads();
+  }
+  if (t < 2) {
+    sh_sup[t] = red[0][t][0];
+    sh_nll[t] = red[1][t][0];
+    sh_kl[t] = red[2][t][0];
   }
   __syncthreads();
   const int nblobs = (sh_sup[0] > 0.0) + (sh_sup[1] > 0.0);
