@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 
 bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
                             int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int ba, int bb,
-                            int ntw, int splits, int chunk, hipStream_t st);
+                            int ntw, int splits, int chunk, hipStream_t st, float* dw_direct, int A, int Breal,
+                            int Btot, int boff, int accumulate);
 
 // taps handled by one workgroup of the bf16 fast kernel (narrow V operands share the U tile)
 static int wgrad_ntw(int vp, int taps) {
@@ -321,8 +322,9 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSML_BF16 && !getenv("MSML_NO_FAST_WGRAD") &&
       msml_wgrad_fast_launch(u, up, v, vp, a.ws, N, H, W, P, Q, R, S, stride, pad_h, pad_w, ba, bb, ntw,
-                             splits, a.chunk, st)) {
+                             splits, a.chunk, st, dw, A, Breal, Btot, boff, accumulate)) {
     MSML_LAUNCH_OK("conv_wgrad(fast)");
+    if (splits == 1) return MSML_OK;                   // written straight into dw
     long total = (long)A * taps * vp;
     int rgrid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
     k_wgrad_reduce<<<rgrid, 256, 0, st>>>(a.ws, dw, splits, up, taps, vp, A, Breal, Btot, boff, accumulate);

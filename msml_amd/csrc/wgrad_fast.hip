@@ -30,6 +30,10 @@ struct WgradFastArgs {
   long Mpix;
   int chunk;                  // pixels per split (multiple of 64)
   float rcp_pq, rcp_q;
+  // splits == 1 (many output tiles, short K: the PartialFC / fc weight gradients): no slab, the
+  // tile goes straight into dW[a][boff + b][tap] (saves writing and re-reading |dW| floats)
+  float* dw;
+  int A, Breal, Btot, boff, accumulate;
 };
 
 __device__ __forceinline__ void divmodf(int m, int d, float rcp, int& q, int& r) {
@@ -192,8 +196,14 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int a = a0 + arow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (a < p.arows && b < p.vp && tap < taps)
+        if (p.dw) {
+          if (a < p.A && b < p.Breal && tap < taps) {
+            const long o = ((long)a * p.Btot + p.boff + b) * taps + tap;
+            p.dw[o] = p.accumulate ? p.dw[o] + acc[i][j][e] : acc[i][j][e];
+          }
+        } else if (a < p.arows && b < p.vp && tap < taps) {
           p.ws[(((long)split * p.arows + a) * taps + tap) * p.vp + b] = acc[i][j][e];
+        }
       }
     }
 #endif
@@ -205,7 +215,8 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
 // Returns false when the tensors are too large for 32-bit buffer offsets.
 bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
                             int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int ba, int bb,
-                            int ntw, int splits, int chunk, hipStream_t st) {
+                            int ntw, int splits, int chunk, hipStream_t st, float* dw_direct, int A, int Breal,
+                            int Btot, int boff, int accumulate) {
   const long ub = (long)N * P * Q * up * 2, vb = (long)N * H * W * vp * 2;
   if (ub >= 0x7fffff00L || vb >= 0x7fffff00L) return false;
   WgradFastArgs a;
@@ -218,6 +229,8 @@ bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float*
   a.chunk = chunk;
   a.rcp_pq = 1.0f / (float)(P * Q);
   a.rcp_q = 1.0f / (float)Q;
+  a.dw = splits == 1 ? dw_direct : nullptr;
+  a.A = A; a.Breal = Breal; a.Btot = Btot; a.boff = boff; a.accumulate = accumulate;
 #define WF(BA_, BB_, NTW_) k_wgrad_fast<BA_, BB_, NTW_><<<grid, dim3(256), 2 * 64 * (BA_ + BB_) * 2, st>>>(a)
   if (ntw == 3) {                                       // narrow V: 3 taps per workgroup
     dim3 grid(cdiv(up, ba), cdiv(R * S, 3), splits);
