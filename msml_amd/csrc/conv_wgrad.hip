@@ -268,10 +268,18 @@ static int wgrad_ntw(int vp, int taps) {
 
 static int pick_tile(int c) { return c > 64 ? 128 : 64; }
 
-// number of pixel splits: enough workgroups to fill 256 CUs a few times over, chunks >= 256 px
+// number of pixel splits: enough workgroups to fill 256 CUs a few times over, chunks >= 256 px.
+// Every workgroup writes one f32 tile (<= 64 KB) of partial sums, so the slab traffic is
+// workgroups x tile bytes whatever the layer: with few output tiles (64 / 128-channel layers,
+// |dW| of a few hundred KB) half as many workgroups win, with many tiles (512 channels) 768;
+// measured per shape with tools/bench_conv.py (MSML_WGRAD_WGS overrides).
 static int pick_splits(long mpix, int out_tiles) {
-  static const long target = getenv("MSML_WGRAD_WGS") ? atol(getenv("MSML_WGRAD_WGS")) : 1024;
+  static const long forced = getenv("MSML_WGRAD_WGS") ? atol(getenv("MSML_WGRAD_WGS")) : 0;
   static const long minchunk = getenv("MSML_WGRAD_MINCHUNK") ? atol(getenv("MSML_WGRAD_MINCHUNK")) : 256;
+  long target = 1024;
+  if (out_tiles <= 9 && mpix <= (1L << 20)) target = 512;
+  else if (out_tiles > 48) target = 768;
+  if (forced > 0) target = forced;
   long want = (target + out_tiles - 1) / out_tiles;
   long max_by_chunk = (mpix + minchunk - 1) / minchunk;
   long s = want < max_by_chunk ? want : max_by_chunk;
@@ -283,9 +291,12 @@ static int pick_splits(long mpix, int out_tiles) {
 extern "C" long msml_conv_wgrad_workspace(int up, int vp, int N, int P, int Q, int R, int S) {
   int ba = pick_tile(up), bb = pick_tile(vp);
   int tiles = cdiv(up, ba) * cdiv(vp, bb) * R * S;
-  int nt = wgrad_ntw(vp, R * S);                         // upper bound on splits for either dtype
-  if (nt > 1) tiles = cdiv(up, ba) * cdiv(R * S, nt);
-  int splits = pick_splits((long)N * P * Q, tiles);
+  int splits = pick_splits((long)N * P * Q, tiles);      // upper bound over both dtypes' tilings
+  int nt = wgrad_ntw(vp, R * S);
+  if (nt > 1) {
+    int s2 = pick_splits((long)N * P * Q, cdiv(up, ba) * cdiv(R * S, nt));
+    if (s2 > splits) splits = s2;
+  }
   return (long)splits * up * R * S * vp * (long)sizeof(float);
 }
 
