@@ -8,6 +8,8 @@
 // HBM-bound streaming kernels; per-channel reductions are two-level: every workgroup reduces
 // its pixel slab in registers -> LDS -> one partial row in a workspace (plain stores), and a
 // tiny finalize kernel sums the rows in f64 in a fixed order (deterministic; no float atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define RED_ROWS_MAX 1024      // partial rows produced by the standalone reduction kernels
@@ -232,8 +234,9 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd(const T* __restrict__ x, con
 }
 
 static inline int ew_grid(long n8) {
+  static const long cap = getenv("MSML_EW_GRID") ? atol(getenv("MSML_EW_GRID")) : 1024;
   long b = (n8 + 255) / 256;
-  return (int)(b < 2048 ? b : 2048);
+  return (int)(b < cap ? b : cap);
 }
 // grid whose total thread count is a multiple of C8 (C8 <= 256 or a multiple of 256)
 static inline int ew_grid_c(long n8, int C8) {
