@@ -263,7 +263,12 @@ bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float*
 // taps handled by one workgroup of the bf16 fast kernel (narrow V operands share the U tile)
 static int wgrad_ntw(int vp, int taps) {
   static const bool off = getenv("MSML_WGRAD_NO_MULTITAP") != nullptr;
-  return (!off && vp <= 64 && taps >= 3) ? 3 : 1;
+  // 128-channel layers: 3 taps x one 64-channel chunk per workgroup (125 -> 93 us at 128->128@28x28);
+  // neutral from 256 channels on (the wider tile's slab traffic eats the fill saving)
+  static const int wide = getenv("MSML_WGRAD_MULTITAP_WIDE") ? atoi(getenv("MSML_WGRAD_MULTITAP_WIDE")) : 128;
+  if (off || taps < 3) return 1;
+  if (vp <= 64) return 3;
+  return (wide && vp % 64 == 0 && vp <= wide) ? 3 : 1;     // 3 taps x one 64-channel chunk per workgroup
 }
 
 static int pick_tile(int c) { return c > 64 ? 128 : 64; }
@@ -294,7 +299,7 @@ extern "C" long msml_conv_wgrad_workspace(int up, int vp, int N, int P, int Q, i
   int splits = pick_splits((long)N * P * Q, tiles);      // upper bound over both dtypes' tilings
   int nt = wgrad_ntw(vp, R * S);
   if (nt > 1) {
-    int s2 = pick_splits((long)N * P * Q, cdiv(up, ba) * cdiv(R * S, nt));
+    int s2 = pick_splits((long)N * P * Q, cdiv(up, ba) * cdiv(R * S, nt) * cdiv(vp, 64));
     if (s2 > splits) splits = s2;
   }
   return (long)splits * up * R * S * vp * (long)sizeof(float);
@@ -327,7 +332,7 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   const int ba = pick_tile(up), bb = pick_tile(vp);
   const int atiles = cdiv(up, ba), btiles = cdiv(vp, bb), taps = R * S;
   const int ntw = dtype == MSML_BF16 ? wgrad_ntw(vp, taps) : 1;
-  const int splits = pick_splits(a.Mpix, ntw > 1 ? atiles * cdiv(taps, ntw) : atiles * btiles * taps);
+  const int splits = pick_splits(a.Mpix, ntw > 1 ? atiles * cdiv(taps, ntw) * cdiv(vp, 64) : atiles * btiles * taps);
   a.chunk = (int)(((a.Mpix + splits - 1) / splits + 63) / 64 * 64);
   dim3 grid(atiles, btiles * taps, splits);
   hipStream_t st = (hipStream_t)stream;

@@ -56,9 +56,9 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int btiles = NTW > 1 ? 1 : (p.vp + BB - 1) / BB;
+  const int btiles = NTW > 1 ? (p.vp + 63) / 64 : (p.vp + BB - 1) / BB;   // NTW > 1: 64-channel chunks
   const int a0 = blockIdx.x * BA;
-  const int tap0 = (blockIdx.y / btiles) * NTW, b0 = (blockIdx.y % btiles) * BB;
+  const int tap0 = (blockIdx.y / btiles) * NTW, b0 = (blockIdx.y % btiles) * (NTW > 1 ? 64 : BB);
   const int taps = p.R * p.S;
   const int split = blockIdx.z;
   const long k_begin = (long)split * p.chunk;
@@ -233,7 +233,7 @@ bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float*
   a.A = A; a.Breal = Breal; a.Btot = Btot; a.boff = boff; a.accumulate = accumulate;
 #define WF(BA_, BB_, NTW_) k_wgrad_fast<BA_, BB_, NTW_><<<grid, dim3(256), 2 * 64 * (BA_ + BB_) * 2, st>>>(a)
   if (ntw == 3) {                                       // narrow V: 3 taps per workgroup
-    dim3 grid(cdiv(up, ba), cdiv(R * S, 3), splits);
+    dim3 grid(cdiv(up, ba), cdiv(R * S, 3) * cdiv(vp, 64), splits);
     if (ba == 128) WF(128, 192, 3);
     else WF(64, 192, 3);
     return true;
