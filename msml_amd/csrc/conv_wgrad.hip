@@ -260,6 +260,11 @@ bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float*
                             int ntw, int splits, int chunk, hipStream_t st, float* dw_direct, int A, int Breal,
                             int Btot, int boff, int accumulate);
 
+int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
+                           int stride, int pad_h, int pad_w);
+bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
+                            int splits, hipStream_t st);
+
 // taps handled by one workgroup of the bf16 fast kernel (narrow V operands share the U tile)
 static int wgrad_ntw(int vp, int taps) {
   static const bool off = getenv("MSML_WGRAD_NO_MULTITAP") != nullptr;
@@ -302,6 +307,11 @@ extern "C" long msml_conv_wgrad_workspace(int up, int vp, int N, int P, int Q, i
     int s2 = pick_splits((long)N * P * Q, cdiv(up, ba) * cdiv(R * S, nt) * cdiv(vp, 64));
     if (s2 > splits) splits = s2;
   }
+  // the halo kernel (wgrad_halo.hip) may use up to one split per CU-resident workgroup
+  if (R == 3 && S == 3 && splits < 512) {
+    int hs = msml_wgrad_halo_splits(up, vp, up, vp, N, P, Q, P, Q, 3, 3, 1, 1, 1);
+    if (hs > splits) splits = hs;
+  }
   return (long)splits * up * R * S * vp * (long)sizeof(float);
 }
 
@@ -336,6 +346,17 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   a.chunk = (int)(((a.Mpix + splits - 1) / splits + 63) / 64 * 64);
   dim3 grid(atiles, btiles * taps, splits);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == MSML_BF16) {
+    const int hs = msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w);
+    if (hs > 0 && msml_wgrad_halo_launch(u, up, v, vp, a.ws, N, H, W, hs, st)) {
+      MSML_LAUNCH_OK("conv_wgrad(halo)");
+      long total = (long)A * taps * vp;
+      int rgrid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
+      k_wgrad_reduce<<<rgrid, 256, 0, st>>>(a.ws, dw, hs, up, taps, vp, A, Breal, Btot, boff, accumulate);
+      MSML_LAUNCH_OK("conv_wgrad_reduce");
+      return MSML_OK;
+    }
+  }
   if (dtype == MSML_BF16 && !getenv("MSML_NO_FAST_WGRAD") &&
       msml_wgrad_fast_launch(u, up, v, vp, a.ws, N, H, W, P, Q, R, S, stride, pad_h, pad_w, ba, bb, ntw,
                              splits, a.chunk, st, dw, A, Breal, Btot, boff, accumulate)) {

@@ -1,0 +1,203 @@
+// Weight gradient of 3x3 / stride-1 / pad-1 convs for bf16 NHWC tensors with Cout % 128 == 0 and
+// Cin % 64 == 0 (the 28x28 / 14x14 stages of IResNet and of the OSB encoder,
+// backbones/frb/iresnet.py:40-67) -- same math and slab format as wgrad_fast.hip /
+// conv_wgrad.hip:   dW[a][tap][b] = sum_pixels dY[p][a] * X[p + tap][b].
+//
+// wgrad_fast gathers X once per tap (im2col) and is bound by the L2 -> LDS fill rate like the
+// im2col conv.  Here a workgroup owns a 128 (Cout) x 64 (Cin) block of dW for ALL 9 taps and walks
+// over strips of 7 x 14 output pixels: the dY strip (7 rows x 16-pixel pitch, the 2 padding
+// pixels of a row are zero) and the X strip WITH its halo (9 rows x 16) go to LDS once and serve
+// the 9 taps -- 48 KB of fill per 16.5 MFLOP (the im2col kernel: 32 KB per 2.1 MFLOP).  A k-step is
+// one strip row (16 pixels); tap (r, s) reads the X image r rows down and s pixels right, which
+// is a per-lane offset in the blocked image [row][32-channel group][16 px][64 B] (the layout
+// whose transposing ds_read_b64_tr_b16 blocks are conflict-free, see wgrad_fast.hip).
+// 8 waves: wave = (32-row Cout tile, 32-column Cin half), 9 accumulator tiles (one per tap).
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define WH_OOB 0x78000000u
+
+struct WgradHaloArgs {
+  const unsigned short* u; int up; unsigned int u_bytes;     // dY [N][H][W][up]
+  const unsigned short* v; int vp; unsigned int v_bytes;     // X  [N][H][W][vp]
+  int N, H, W, spy, spx;      // strips per image column / row (7 rows x 14 columns each)
+  int nstrips, chunk;         // total strips, strips per split
+  float* ws;                  // [split][up][9][vp]
+};
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wgrad_halo(const WgradHaloArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int UB = 7 * 4 * 1024, VB = 10 * 2 * 1024, STAGE = UB + VB;   // dY strip, X strip + halo (+ 1 row)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int mi = wave & 3, nh = wave >> 2;             // Cout tile (32 rows), Cin half (32 columns)
+  const int a0 = blockIdx.x * 128, b0 = blockIdx.y * 64, split = blockIdx.z;
+  const int s_begin = split * p.chunk;
+  int s_end = s_begin + p.chunk;
+  if (s_end > p.nstrips) s_end = p.nstrips;
+  const int spi = p.spy * p.spx;
+
+  __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, (int)p.u_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)p.v, 0, (int)p.v_bytes, 0x00020000);
+
+  // DMA slot of a lane inside a 1-KB block [16 px][64 B]: pixel lane / 4, 16-B chunk lane % 4
+  const int lp = lane >> 2, lc = lane & 3;
+  auto issue = [&](int strip, int buf) {
+    const int n = strip / spi, rem = strip - n * spi, sy = rem / p.spx;
+    const int y0 = sy * 7, x0 = (rem - sy * p.spx) * 14;
+    char* ub = smem + buf * STAGE;
+    char* vb = ub + UB;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int blk = wave + 8 * i;                    // 28 dY blocks, then 20 X blocks
+      if (blk < 28) {
+        const int j = blk >> 2, g = blk & 3;
+        const int y = y0 + j, x = x0 + lp;
+        const bool ok = (lp < 14) & (x < p.W) & (y < p.H);
+        const unsigned int off = ok ? (unsigned int)((n * p.H + y) * p.W + x) * (unsigned int)(p.up * 2) +
+                                          (unsigned int)(a0 + g * 32 + lc * 8) * 2u
+                                    : WH_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lptr_t)(ub + blk * 1024), 16, off, 0, 0, 0);
+      } else {
+        const int bb = blk - 28, hr = bb >> 1, g = bb & 1;
+        const int y = y0 + hr - 1, x = x0 + lp - 1;
+        const bool ok = (hr < 9) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
+        const unsigned int off = ok ? (unsigned int)((n * p.H + y) * p.W + x) * (unsigned int)(p.vp * 2) +
+                                          (unsigned int)(b0 + g * 32 + lc * 8) * 2u
+                                    : WH_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lptr_t)(vb + bb * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+
+  // transposing fragment read (wgrad_fast.hip): the lane addresses pixel px = 8 (g4 >> 1) + q4 (the
+  // second read 4 pixels on), 4 channels pp of a 16-channel half g4 & 1
+  const int g4 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+  const int px = 8 * (g4 >> 1) + q4;
+  const int chan = (2 * (g4 & 1) + (pp >> 1)) * 16 + (pp & 1) * 8;
+  const int aofs = mi * 1024 + px * 64 + chan;         // + row * 4096 (+ 256 for the second read)
+  // X: pixel px + s of halo row (row + r); past pixel 15 it continues in the next row's block
+  int vlo[3], vhi[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    const int p0 = px + s, p1 = px + 4 + s;
+    vlo[s] = nh * 1024 + (p0 >> 4) * 2048 + (p0 & 15) * 64 + chan;
+    vhi[s] = nh * 1024 + (p1 >> 4) * 2048 + (p1 & 15) * 64 + chan;
+  }
+  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+  auto tr2 = [&](const char* lo, const char* hi) -> s16x8 {
+    s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(lo));
+    s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(hi));
+    s16x8 o;
+    o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = l[3];
+    o[4] = h[0]; o[5] = h[1]; o[6] = h[2]; o[7] = h[3];
+    return o;
+  };
+
+  if (s_begin < s_end) issue(s_begin, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int strip = s_begin; strip < s_end; strip++) {
+#ifndef WH_ABLATE_LOADS
+    if (strip + 1 < s_end) issue(strip + 1, cur ^ 1);
+#endif
+    const char* ub = smem + cur * STAGE + aofs;
+    const char* vb = smem + cur * STAGE + UB;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {                      // k-step = strip row j (16 pixels)
+      const s16x8 a = tr2(ub + j * 4096, ub + j * 4096 + 256);
+      // the X fragments of tap t + 2 are requested while tap t runs (ring of 3)
+      s16x8 b[3];
+      b[0] = tr2(vb + j * 2048 + vlo[0], vb + j * 2048 + vhi[0]);
+      b[1] = tr2(vb + j * 2048 + vlo[1], vb + j * 2048 + vhi[1]);
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        if (tap + 2 < 9) {
+          const int r = (tap + 2) / 3, s = (tap + 2) % 3;
+          b[(tap + 2) % 3] = tr2(vb + (j + r) * 2048 + vlo[s], vb + (j + r) * 2048 + vhi[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                           __builtin_bit_cast(bf16x8, b[tap % 3]), acc[tap], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#ifdef WH_ABLATE_EPI
+  if (p.N >= 0) return;
+#endif
+  // slab [split][a][tap][b] (k_wgrad_reduce sums the splits in a fixed order)
+  const int h = lane >> 5, c32 = lane & 31;
+  const int b = b0 + nh * 32 + c32;
+#pragma unroll
+  for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int a = a0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      p.ws[(((long)split * p.up + a) * 9 + tap) * p.vp + b] = acc[tap][e];
+    }
+#endif
+}
+
+static int wh_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+  }
+  return n;
+}
+
+// splits for a shape (0 = shape not covered by this kernel)
+int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
+                           int stride, int pad_h, int pad_w) {
+  static const bool off = getenv("MSML_NO_HALO_WGRAD") != nullptr;
+  if (off) return 0;
+  if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return 0;
+  if (up % 128 != 0 || vp % 64 != 0 || A != up || Breal != vp) return 0;
+  const long strips = (long)N * cdiv(H, 7) * cdiv(W, 14);
+  if ((long)N * H * W * 10 < strips * 112 * 7) return 0;           // < 70 % real k-values
+  if ((long)N * H * W * up * 2 >= 0x70000000L || (long)N * H * W * vp * 2 >= 0x70000000L) return 0;
+  const int tiles = (up / 128) * (vp / 64);
+  long splits = wh_cus() / tiles;                      // one resident workgroup per CU
+  if (splits < 1) splits = 1;
+  if (splits > strips) splits = strips;
+  if (splits > 512) splits = 512;
+  return (int)splits;
+}
+
+bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
+                            int splits, hipStream_t st) {
+  WgradHaloArgs a;
+  a.u = (const unsigned short*)u; a.up = up; a.u_bytes = (unsigned int)((long)N * H * W * up * 2);
+  a.v = (const unsigned short*)v; a.vp = vp; a.v_bytes = (unsigned int)((long)N * H * W * vp * 2);
+  a.N = N; a.H = H; a.W = W; a.spy = cdiv(H, 7); a.spx = cdiv(W, 14);
+  a.nstrips = N * a.spy * a.spx;
+  a.chunk = cdiv(a.nstrips, splits);
+  a.ws = ws;
+  const size_t lds = 2 * (7 * 4 + 10 * 2) * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  k_wgrad_halo<<<dim3(up / 128, vp / 64, splits), dim3(512), lds, st>>>(a);
+  return true;
+}

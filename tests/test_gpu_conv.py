@@ -374,3 +374,25 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, with_alpha):
         assert (dx.float() - ref).abs().max().item() <= 1e-2 * scale
         for i in range(3 if with_alpha else 2):
             assert torch.allclose(pg[i], want_pg[i], rtol=1e-3, atol=1e-3 * want_pg[i].abs().max().item())
+
+
+# (N, Cin, Cout, H, W): weight gradients routed to the strip / halo kernel (wgrad_halo.hip):
+# Cout % 128 == 0, Cin % 64 == 0, 3x3 s1 p1
+WGRAD_HALO = [(6, 64, 128, 14, 14), (5, 128, 128, 21, 28), (4, 128, 256, 13, 27), (40, 64, 128, 28, 28)]
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("shape", WGRAD_HALO)
+def test_conv_wgrad_halo(shape, accumulate):
+    n, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w_, generator=g).bfloat16().float()
+    dy = torch.randn(n, cout, h, w_, generator=g).bfloat16().float()
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.double, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1).backward(dy.double())
+    ref = w.grad.float()
+    dw = torch.full((cout, cin, 3, 3), 2.0, device="cuda")
+    ops.conv_wgrad(ops.to_nhwc(dy.cuda(), _lib.BF16), ops.to_nhwc(x.cuda(), _lib.BF16), dw, cout, cin, cin, 0,
+                   3, 3, 1, 1, 1, accumulate=accumulate)
+    want = ref + (2.0 if accumulate else 0.0)
+    assert (dw.cpu() - want).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
