@@ -11,8 +11,14 @@
 // one strip row (16 pixels); tap (r, s) reads the X image r rows down and s pixels right, which
 // is a per-lane offset in the blocked image [row][32-channel group][16 px][64 B] (the layout
 // whose transposing ds_read_b64_tr_b16 blocks are conflict-free, see wgrad_fast.hip).
-// 8 waves: wave = (32-row Cout tile, 32-column Cin half), 9 accumulator tiles (one per tap).
+// 8 waves: wave = (pair of 32-row Cout tiles, 32-column Cin half, tap group {0-4} / {5-8}): 10 or 8
+// accumulator tiles; per k-step 2 dY fragments + 5 (4) X fragments feed 10 (8) MFMAs -- 1.4 LDS
+// fragment reads per MFMA (one Cout tile x 9 taps per wave needed 2.2 and was LDS-read bound).
+// Waves w and w + 4 share a SIMD and carry one tap group each, so every SIMD runs 18 MFMAs per
+// k-step.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -36,7 +42,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int mi = wave & 3, nh = wave >> 2;             // Cout tile (32 rows), Cin half (32 columns)
+  const int mp = wave & 1, nh = (wave >> 1) & 1, tg = wave >> 2;   // Cout tile pair, Cin half, tap group
   const int a0 = blockIdx.x * 128, b0 = blockIdx.y * 64, split = blockIdx.z;
   const int s_begin = split * p.chunk;
   int s_end = s_begin + p.chunk;
@@ -76,18 +82,20 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 
-  f32x16 acc[9];
+  f32x16 acc[2][5];                                    // [Cout tile of the pair][tap of the group]
 #pragma unroll
-  for (int i = 0; i < 9; i++)
+  for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+    for (int k = 0; k < 5; k++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][k][e] = 0.f;
 
   // transposing fragment read (wgrad_fast.hip): the lane addresses pixel px = 8 (g4 >> 1) + q4 (the
   // second read 4 pixels on), 4 channels pp of a 16-channel half g4 & 1
   const int g4 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
   const int px = 8 * (g4 >> 1) + q4;
   const int chan = (2 * (g4 & 1) + (pp >> 1)) * 16 + (pp & 1) * 8;
-  const int aofs = mi * 1024 + px * 64 + chan;         // + row * 4096 (+ 256 for the second read)
+  const int aofs = mp * 2048 + px * 64 + chan;         // + row * 4096, + 1024 for the pair's second tile (+ 256: second read)
   // X: pixel px + s of halo row (row + r); past pixel 15 it continues in the next row's block
   int vlo[3], vhi[3];
 #pragma unroll
@@ -95,6 +103,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int p0 = px + s, p1 = px + 4 + s;
     vlo[s] = nh * 1024 + (p0 >> 4) * 2048 + (p0 & 15) * 64 + chan;
     vhi[s] = nh * 1024 + (p1 >> 4) * 2048 + (p1 & 15) * 64 + chan;
+  }
+  // offsets of this wave's taps (wave-uniform choice among the three column shifts, row shift folded in)
+  const int ntaps = tg == 0 ? 5 : 4, tap0 = tg * 5;
+  int vlok[5], vhik[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const int tp = tap0 + k, r = tp / 3, sft = tp - r * 3;
+    vlok[k] = r * 2048 + (sft == 0 ? vlo[0] : (sft == 1 ? vlo[1] : vlo[2]));
+    vhik[k] = r * 2048 + (sft == 0 ? vhi[0] : (sft == 1 ? vhi[1] : vhi[2]));
   }
   typedef __attribute__((address_space(3))) s16x4* tr_ptr;
   auto tr2 = [&](const char* lo, const char* hi) -> s16x8 {
@@ -109,30 +126,45 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   if (s_begin < s_end) issue(s_begin, 0);
   __syncthreads();
   int cur = 0;
+  s16x8 fa[2][2], fb5[2][5];
   for (int strip = s_begin; strip < s_end; strip++) {
 #ifndef WH_ABLATE_LOADS
     if (strip + 1 < s_end) issue(strip + 1, cur ^ 1);
 #endif
     const char* ub = smem + cur * STAGE + aofs;
     const char* vb = smem + cur * STAGE + UB;
+    // taps tap0 + k, k < ntaps, of this wave's group.  All fragments of k-step j + 1 are requested
+    // before the MFMAs of k-step j (register double buffer); the fences keep hipcc from sinking the
+    // reads next to their MFMAs.
+    auto fetch = [&](int j, int fb) {
+      fa[fb][0] = tr2(ub + j * 4096, ub + j * 4096 + 256);
+      fa[fb][1] = tr2(ub + j * 4096 + 1024, ub + j * 4096 + 1024 + 256);
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+        if (k < ntaps) fb5[fb][k] = tr2(vb + j * 2048 + vlok[k], vb + j * 2048 + vhik[k]);
+    };
+#ifdef WH_ABLATE_READS
+    if (strip == s_begin)
+#endif
+    fetch(0, 0);
 #pragma unroll
     for (int j = 0; j < 7; j++) {                      // k-step = strip row j (16 pixels)
-      const s16x8 a = tr2(ub + j * 4096, ub + j * 4096 + 256);
-      // the X fragments of tap t + 2 are requested while tap t runs (ring of 3)
-      s16x8 b[3];
-      b[0] = tr2(vb + j * 2048 + vlo[0], vb + j * 2048 + vhi[0]);
-      b[1] = tr2(vb + j * 2048 + vlo[1], vb + j * 2048 + vhi[1]);
+      const int fb = j & 1;
+#ifdef WH_ABLATE_READS
+      if (j == 0 && strip == s_begin) fetch(1, 1);
+#else
+      if (j + 1 < 7) fetch(j + 1, fb ^ 1);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
-        if (tap + 2 < 9) {
-          const int r = (tap + 2) / 3, s = (tap + 2) % 3;
-          b[(tap + 2) % 3] = tr2(vb + (j + r) * 2048 + vlo[s], vb + (j + r) * 2048 + vhi[s]);
+      for (int k = 0; k < 5; k++)
+        if (k < ntaps) {
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+            acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[fb][i]),
+                                                                __builtin_bit_cast(bf16x8, fb5[fb][k]), acc[i][k], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                           __builtin_bit_cast(bf16x8, b[tap % 3]), acc[tap], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     cur ^= 1;
@@ -145,11 +177,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int h = lane >> 5, c32 = lane & 31;
   const int b = b0 + nh * 32 + c32;
 #pragma unroll
-  for (int tap = 0; tap < 9; tap++)
+  for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const int a = a0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      p.ws[(((long)split * p.up + a) * 9 + tap) * p.vp + b] = acc[tap][e];
+    for (int k = 0; k < 5; k++) {
+      if (k >= ntaps) continue;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int a = a0 + (mp * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        p.ws[(((long)split * p.up + a) * 9 + tap0 + k) * p.vp + b] = acc[i][k][e];
+      }
     }
 #endif
 }
