@@ -13,11 +13,19 @@ order of the fixed-order reductions), which stays the path for f32 parity mode a
 import torch
 
 from . import ops
+from . import _lib
 from ._lib import BF16, call
 from .ops import cpad
 
 
-def _bn_fwd(x, stats, bn, alpha, residual):
+def _bn_pack(bn):
+    """(weight, bias, running_mean, running_var, momentum, eps, module): nn.Module attribute
+    lookups go through __getattr__ (~2 us each); the blocks read them ~25 times per step."""
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1 if bn.momentum is None else bn.momentum,
+            bn.eps, bn)
+
+
+def _bn_fwd(x, stats, bnp, alpha, residual):
     """Training-mode BatchNorm (+PReLU) (+residual after it) on raw NHWC tensors.
     Returns (y, coef[4][C] = scale, shift, mean, invstd)."""
     c = x.shape[-1]
@@ -28,38 +36,40 @@ def _bn_fwd(x, stats, bn, alpha, residual):
         stats = torch.empty(rows, 2, c, dtype=torch.float32, device=x.device)
         with ops.PROFILE.rec("bn_stats", 0.0, x.numel() * x.element_size()):
             call("msml_bn_stats", x, m, c, stats, BF16)
-    call("msml_bn_finalize", stats, stats.shape[0], c, float(m), bn.weight, bn.bias, bn.running_mean,
-         bn.running_var, 0.1 if bn.momentum is None else bn.momentum, bn.eps, coef[0], coef[1], coef[2],
-         coef[3])
+    call("msml_bn_finalize", stats, stats.shape[0], c, float(m), bnp[0], bnp[1], bnp[2], bnp[3], bnp[4], bnp[5],
+         coef[0], coef[1], coef[2], coef[3])
     y = torch.empty_like(x)
     with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
         call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, 0, y, m, c, BF16)
-    ops.bn_counter(bn)
+    ops.bn_counter(bnp[6])
     return y, coef
 
 
-def _conv_fwd(x, cm):
+def _conv_pack(cm):
     w = cm.weight
-    cout, cin, r, s = w.shape
+    return (w, tuple(w.shape), cm.stride[0], cm.padding[0], cm.padding[1])
+
+
+def _conv_fwd(x, cp):
+    w, (cout, cin, r, s), stride, ph, pw = cp
     wp = ops.PACKS.get(w, False, 0, cout, 0, cin, cin, 0, BF16)
-    return ops.conv2d(x, None, wp, None, cpad(cout), r, s, cm.stride[0], cm.padding[0], cm.padding[1], False,
-                      want_stats=True, real=(cin, cout))
+    return ops.conv2d(x, None, wp, None, cpad(cout), r, s, stride, ph, pw, False, want_stats=True,
+                      real=(cin, cout))
 
 
-def _wgrad(dy, x, wparam, cm):
-    """dW of conv `cm` from its output gradient and input; in-place into the flat gradient arena
+def _wgrad(dy, x, cp):
+    """dW of a conv from its output gradient and input; in-place into the flat gradient arena
     (on the weight-gradient stream) when FlatSGD owns .grad, else a fresh tensor."""
-    cout, cin, r, s = wparam.shape
+    wparam, (cout, cin, r, s), stride, ph, pw = cp
     inplace = ops.INPLACE_GRADS and wparam.grad is not None
     dw = wparam.grad.view(wparam.shape) if inplace else torch.empty_like(wparam)
     side = ops.WGRAD_STREAM if inplace else None
-    args = (dy, x, dw, cout, cin, cin, 0, r, s, cm.stride[0], cm.padding[0], cm.padding[1])
+    args = (dy, x, dw, cout, cin, cin, 0, r, s, stride, ph, pw)
     if side is not None:
-        side.wait_stream(torch.cuda.current_stream())
+        side.wait_stream(_lib.current_stream())
         dy.record_stream(side)             # both operands may be freed (by this stream's allocator
         x.record_stream(side)              # pool) while the side stream still reads them
-        with torch.cuda.stream(side):
-            ops.conv_wgrad(*args, accumulate=True)
+        ops.conv_wgrad(*args, accumulate=True, stream=side)
     else:
         ops.conv_wgrad(*args, accumulate=inplace)
     if inplace:
@@ -68,12 +78,11 @@ def _wgrad(dy, x, wparam, cm):
     return dw
 
 
-def _dgrad(dy, wparam, cm, h, w, bn_x=None, coef=None, alpha=None):
-    """dX of conv `cm`; with bn_x / coef the epilogue also reduces the backward sums of the
+def _dgrad(dy, cp, h, w, bn_x=None, coef=None, alpha=None):
+    """dX of a conv; with bn_x / coef the epilogue also reduces the backward sums of the
     BatchNorm that produced the conv input.  Returns (dx, partial or None)."""
-    cout, cin, r, s = wparam.shape
-    wp = ops.PACKS.get(wparam.detach(), True, 0, cout, 0, cin, cout, 0, BF16)
-    stride, ph, pw = cm.stride[0], cm.padding[0], cm.padding[1]
+    wparam, (cout, cin, r, s), stride, ph, pw = cp
+    wp = ops.PACKS.get(wparam, True, 0, cout, 0, cin, cout, 0, BF16)
     if bn_x is not None and ops.FUSE_BN_BWD:
         got = ops.conv_dgrad_bnbwd(dy, wp, cpad(cin), r, s, stride, ph, pw, h, w, bn_x, coef, alpha,
                                    real=(cout, cin))
@@ -127,56 +136,67 @@ def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None):
     return dx
 
 
+def _block_pack(blk):
+    """Per-block tuple of everything forward / backward read from the module (built once)."""
+    ds = blk.downsample
+    return {
+        "bn1": _bn_pack(blk.bn1), "bn2": _bn_pack(blk.bn2), "bn3": _bn_pack(blk.bn3),
+        "c1": _conv_pack(blk.conv1), "c2": _conv_pack(blk.conv2), "alpha": blk.prelu.weight,
+        "ds": None if ds is None else (_conv_pack(ds[0]), _bn_pack(ds[1])),
+    }
+
+
 class _IBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, blk, *params):
+    def forward(ctx, x, bp, *params):
         # params (for autograd bookkeeping only): conv1.w, conv2.w, [down.w], bn1 g/b, bn2 g/b, prelu,
-        # bn3 g/b, [down bn g/b] -- the arithmetic reads them from the module
-        ds = blk.downsample
-        o1, k1 = _bn_fwd(x, None, blk.bn1, None, None)
-        c1, st1 = _conv_fwd(o1, blk.conv1)
-        o2, k2 = _bn_fwd(c1, st1, blk.bn2, blk.prelu.weight, None)
-        c2, st2 = _conv_fwd(o2, blk.conv2)
+        # bn3 g/b, [down bn g/b] -- the arithmetic reads them from the cached pack
+        ds = bp["ds"]
+        o1, k1 = _bn_fwd(x, None, bp["bn1"], None, None)
+        c1, st1 = _conv_fwd(o1, bp["c1"])
+        o2, k2 = _bn_fwd(c1, st1, bp["bn2"], bp["alpha"], None)
+        c2, st2 = _conv_fwd(o2, bp["c2"])
         if ds is not None:
             d, std = _conv_fwd(x, ds[0])
             idn, kd = _bn_fwd(d, std, ds[1], None, None)
         else:
             d, kd, idn = None, None, x
-        out, k3 = _bn_fwd(c2, st2, blk.bn3, None, idn)
-        ctx.blk = blk
+        out, k3 = _bn_fwd(c2, st2, bp["bn3"], None, idn)
+        ctx.bp = bp
         ctx.save_for_backward(x, o1, c1, o2, c2, d, k1, k2, k3, kd)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, o1, c1, o2, c2, d, k1, k2, k3, kd = ctx.saved_tensors
-        blk = ctx.blk
-        ds = blk.downsample
+        bp = ctx.bp
+        ds = bp["ds"]
         dev = x.device
         dout = dout.contiguous()
         n, h, w, _ = x.shape
+        bn1, bn2, bn3, alpha = bp["bn1"], bp["bn2"], bp["bn3"], bp["alpha"]
         # bn3 (its dy is the block output gradient, which also flows to the identity path)
-        g3 = _ParamGrads((blk.bn3.weight, blk.bn3.bias, None), c2.shape[-1], dev)
+        g3 = _ParamGrads((bn3[0], bn3[1], None), c2.shape[-1], dev)
         dc2 = _bn_bwd(dout, c2, k3, None, g3)
         # conv2: dW beside, dX with bn2's backward sums from the epilogue
-        dw2 = _wgrad(dc2, o2, blk.conv2.weight, blk.conv2)
-        do2, part2 = _dgrad(dc2, blk.conv2.weight, blk.conv2, c1.shape[1], c1.shape[2], c1, k2, blk.prelu.weight)
-        g2 = _ParamGrads((blk.bn2.weight, blk.bn2.bias, blk.prelu.weight), c1.shape[-1], dev)
-        dc1 = _bn_bwd(do2, c1, k2, blk.prelu.weight, g2, part2)
+        dw2 = _wgrad(dc2, o2, bp["c2"])
+        do2, part2 = _dgrad(dc2, bp["c2"], c1.shape[1], c1.shape[2], c1, k2, alpha)
+        g2 = _ParamGrads((bn2[0], bn2[1], alpha), c1.shape[-1], dev)
+        dc1 = _bn_bwd(do2, c1, k2, alpha, g2, part2)
         # conv1
-        dw1 = _wgrad(dc1, o1, blk.conv1.weight, blk.conv1)
-        do1, part1 = _dgrad(dc1, blk.conv1.weight, blk.conv1, h, w, x, k1, None)
+        dw1 = _wgrad(dc1, o1, bp["c1"])
+        do1, part1 = _dgrad(dc1, bp["c1"], h, w, x, k1, None)
         # identity / downsample path
         dwd, gd = None, None
         if ds is not None:
-            gd = _ParamGrads((ds[1].weight, ds[1].bias, None), d.shape[-1], dev)
+            gd = _ParamGrads((ds[1][0], ds[1][1], None), d.shape[-1], dev)
             dd = _bn_bwd(dout, d, kd, None, gd)
-            dwd = _wgrad(dd, x, ds[0].weight, ds[0])
-            join, _ = _dgrad(dd, ds[0].weight, ds[0], h, w)
+            dwd = _wgrad(dd, x, ds[0])
+            join, _ = _dgrad(dd, ds[0], h, w)
         else:
             join = dout
         # bn1: dx = bn1 path + joined gradient in one kernel
-        g1 = _ParamGrads((blk.bn1.weight, blk.bn1.bias, None), x.shape[-1], dev)
+        g1 = _ParamGrads((bn1[0], bn1[1], None), x.shape[-1], dev)
         dx = _bn_bwd(do1, x, k1, None, g1, part1, add=join)
         grads = [dw1, dw2] + ([dwd] if ds is not None else [])
         grads += [g1.out(0), g1.out(1), g2.out(0), g2.out(1), g2.out(2), g3.out(0), g3.out(1)]
@@ -187,10 +207,16 @@ class _IBlock(torch.autograd.Function):
 
 def iblock(blk, x):
     """Run IBasicBlock `blk` (training mode, bf16 NHWC input) as one autograd node."""
-    ds = blk.downsample
-    params = [blk.conv1.weight, blk.conv2.weight] + ([ds[0].weight] if ds is not None else [])
-    params += [blk.bn1.weight, blk.bn1.bias, blk.bn2.weight, blk.bn2.bias, blk.prelu.weight,
-               blk.bn3.weight, blk.bn3.bias]
-    if ds is not None:
-        params += [ds[1].weight, ds[1].bias]
-    return _IBlock.apply(x, blk, *params)
+    bp = blk.__dict__.get("_msml_pack")
+    # (buffers are replaced by Module.to() / .cuda(): rebuild the cached tuple when that happened)
+    if bp is None or bp["bn1"][2] is not blk.bn1._buffers["running_mean"]:
+        bp = _block_pack(blk)
+        ds = blk.downsample
+        params = [blk.conv1.weight, blk.conv2.weight] + ([ds[0].weight] if ds is not None else [])
+        params += [blk.bn1.weight, blk.bn1.bias, blk.bn2.weight, blk.bn2.bias, blk.prelu.weight,
+                   blk.bn3.weight, blk.bn3.bias]
+        if ds is not None:
+            params += [ds[1].weight, ds[1].bias]
+        bp["params"] = tuple(params)
+        blk.__dict__["_msml_pack"] = bp       # (plain attribute: not a module / parameter registration)
+    return _IBlock.apply(x, bp, *bp["params"])

@@ -7,7 +7,7 @@ passes torch's current stream explicitly.
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import BF16, DTYPE_OF, F32, TORCH_DTYPE, call
 from .ops import cpad
 
@@ -98,24 +98,20 @@ class _Conv(torch.autograd.Function):
             dw = ctx.wparam.grad.view(w.shape) if inplace else torch.empty_like(w)
             side = ops.WGRAD_STREAM if inplace else None
             if side is not None:                       # dW has no consumer before the optimizer
-                side.wait_stream(torch.cuda.current_stream())
+                side.wait_stream(_lib.current_stream())
                 dy.record_stream(side)
                 for xs in (x0, x1):                    # saved activations are freed after this node
                     if xs is not None:
                         xs.record_stream(side)
-                ctxm = torch.cuda.stream(side)
-                ctxm.__enter__()
             for x, off, ci in ((x0, 0, c0), (x1, c0, c1)):
                 if x is None:
                     continue
                 if deconv:
                     ops.conv_wgrad(x, dy, dw[off:off + ci], ci, cout, cout, 0, r, s, stride, ph, pw,
-                                   accumulate=inplace)
+                                   accumulate=inplace, stream=side)
                 else:
                     ops.conv_wgrad(dy, x, dw, cout, ci, c0 + c1, off, r, s, stride, ph, pw,
-                                   accumulate=inplace)
-            if side is not None:
-                ctxm.__exit__(None, None, None)
+                                   accumulate=inplace, stream=side)
             if inplace:
                 dw = None
                 ops.grad_ready(ctx.wparam)

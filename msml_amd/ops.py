@@ -22,6 +22,8 @@ class _Profile:
         self.on = True
 
     def rec(self, name, flops=0.0, nbytes=0.0):
+        if not self.on:
+            return _NO_REC             # shared no-op context: ~1500 launches per step pass through here
         return _Rec(self, name, flops, nbytes)
 
     def stop(self):
@@ -36,6 +38,17 @@ class _Profile:
             d["bytes"] += nbytes
         self.recs = []
         return out
+
+
+class _NoRec:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_REC = _NoRec()
 
 
 class _Rec:
@@ -199,11 +212,11 @@ def conv_dgrad_bnbwd(dy, wp, coutp, r, s, stride, pad_h, pad_w, p, q, bn_x, coef
 _WS = {}
 
 
-def workspace(nbytes, device, tag="main"):
+def workspace(nbytes, device, tag="main", raw_stream=None):
     """Grow-only scratch buffer per (device, tag, current stream): reuse is ordered by the stream,
     and kernels of different streams (weight-gradient stream, OSB stream, whose backward runs
     beside the FRB backward) never share scratch memory."""
-    key = (device, tag, torch.cuda.current_stream().cuda_stream)
+    key = (device, tag, raw_stream if raw_stream is not None else _lib.raw_stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -271,18 +284,30 @@ def wgrad_stream_join():
         cur.wait_stream(WGRAD_STREAM)
 
 
-def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accumulate=False):
-    """dw[a][boff+b][r][s] = sum_pix u[pix][a] * v[shift(pix, r, s)][b] (see msml_conv_wgrad)."""
+_WGRAD_WS_NEED = {}
+
+
+def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accumulate=False, stream=None):
+    """dw[a][boff+b][r][s] = sum_pix u[pix][a] * v[shift(pix, r, s)][b] (see msml_conv_wgrad).
+    stream: enqueue on this torch stream instead of the current one (the weight-gradient stream,
+    without the Python cost of a stream context per launch)."""
     n, p, q, up = u.shape
     _, h, w, vp = v.shape
-    need = _lib.value("msml_conv_wgrad_workspace", up, vp, n, p, q, r, s)
-    ws = workspace(need, u.device, "wgrad" if WGRAD_STREAM is not None else "main")
+    key = (up, vp, n, p, q, r, s)
+    need = _WGRAD_WS_NEED.get(key)
+    if need is None:
+        need = _WGRAD_WS_NEED[key] = _lib.value("msml_conv_wgrad_workspace", *key)
+    raw = stream.cuda_stream if stream is not None else _lib.raw_stream()
+    ws = workspace(need, u.device, "wgrad", raw)
     name = "conv_wgrad"
-    if PROFILE.on:
+    if PROFILE.on and stream is None:
         name = "wgrad u%d v%d %dx%d k%dx%d s%d n%d" % (up, vp, p, q, r, s, stride, n)
-    with PROFILE.rec(name, 2.0 * n * p * q * a * breal * r * s):
-        call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
-             pad_h, pad_w, int(accumulate), ws, ws.numel(), DTYPE_OF[u.dtype])
+        with PROFILE.rec(name, 2.0 * n * p * q * a * breal * r * s):
+            call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
+                 pad_h, pad_w, int(accumulate), ws, ws.numel(), DTYPE_OF[u.dtype], raw)
+        return dw
+    call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
+         pad_h, pad_w, int(accumulate), ws, ws.numel(), DTYPE_OF[u.dtype], raw)
     return dw
 
 
