@@ -36,14 +36,17 @@ struct WgradHaloArgs {
   float* ws;                  // [split][up][9][vp]
 };
 
+// CO = Cout rows per workgroup: 128 (a wave carries a pair of 32-row tiles) or 64 (one tile)
+template <int CO>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wgrad_halo(const WgradHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int UB = 7 * 4 * 1024, VB = 10 * 2 * 1024, STAGE = UB + VB;   // dY strip, X strip + halo (+ 1 row)
+  constexpr int GU = CO / 32, NI = CO / 64, UBLK = 7 * GU, NBLK = UBLK + 20, NISS = (NBLK + 7) / 8;
+  constexpr int UB = UBLK * 1024, VB = 10 * 2 * 1024, STAGE = UB + VB;    // dY strip, X strip + halo (+ 1 row)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int mp = wave & 1, nh = (wave >> 1) & 1, tg = wave >> 2;   // Cout tile pair, Cin half, tap group
-  const int a0 = blockIdx.x * 128, b0 = blockIdx.y * 64, split = blockIdx.z;
+  const int a0 = blockIdx.x * CO, b0 = blockIdx.y * 64, split = blockIdx.z;
   const int s_begin = split * p.chunk;
   int s_end = s_begin + p.chunk;
   if (s_end > p.nstrips) s_end = p.nstrips;
@@ -60,10 +63,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     char* ub = smem + buf * STAGE;
     char* vb = ub + UB;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const int blk = wave + 8 * i;                    // 28 dY blocks, then 20 X blocks
-      if (blk < 28) {
-        const int j = blk >> 2, g = blk & 3;
+    for (int i = 0; i < NISS; i++) {
+      const int blk = wave + 8 * i;                    // 7 GU dY blocks, then 20 X blocks
+      if (blk >= NBLK) break;
+      if (blk < UBLK) {
+        const int j = blk / GU, g = blk % GU;
         const int y = y0 + j, x = x0 + lp;
         const bool ok = (lp < 14) & (x < p.W) & (y < p.H);
         const unsigned int off = ok ? (unsigned int)((n * p.H + y) * p.W + x) * (unsigned int)(p.up * 2) +
@@ -71,7 +75,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                                     : WH_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lptr_t)(ub + blk * 1024), 16, off, 0, 0, 0);
       } else {
-        const int bb = blk - 28, hr = bb >> 1, g = bb & 1;
+        const int bb = blk - UBLK, hr = bb >> 1, g = bb & 1;
         const int y = y0 + hr - 1, x = x0 + lp - 1;
         const bool ok = (hr < 9) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
         const unsigned int off = ok ? (unsigned int)((n * p.H + y) * p.W + x) * (unsigned int)(p.vp * 2) +
@@ -82,9 +86,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 
-  f32x16 acc[2][5];                                    // [Cout tile of the pair][tap of the group]
+  f32x16 acc[NI][5];                                   // [Cout tile of the wave][tap of the group]
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < NI; i++)
 #pragma unroll
     for (int k = 0; k < 5; k++)
 #pragma unroll
@@ -95,7 +99,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int g4 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
   const int px = 8 * (g4 >> 1) + q4;
   const int chan = (2 * (g4 & 1) + (pp >> 1)) * 16 + (pp & 1) * 8;
-  const int aofs = mp * 2048 + px * 64 + chan;         // + row * 4096, + 1024 for the pair's second tile (+ 256: second read)
+  const int aofs = mp * NI * 1024 + px * 64 + chan;    // + row * GU KB, + 1024 for a pair's second tile (+ 256: second read)
   // X: pixel px + s of halo row (row + r); past pixel 15 it continues in the next row's block
   int vlo[3], vhi[3];
 #pragma unroll
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   if (s_begin < s_end) issue(s_begin, 0);
   __syncthreads();
   int cur = 0;
-  s16x8 fa[2][2], fb5[2][5];
+  s16x8 fa[2][NI], fb5[2][5];
   for (int strip = s_begin; strip < s_end; strip++) {
 #ifndef WH_ABLATE_LOADS
     if (strip + 1 < s_end) issue(strip + 1, cur ^ 1);
@@ -137,8 +141,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // before the MFMAs of k-step j (register double buffer); the fences keep hipcc from sinking the
     // reads next to their MFMAs.
     auto fetch = [&](int j, int fb) {
-      fa[fb][0] = tr2(ub + j * 4096, ub + j * 4096 + 256);
-      fa[fb][1] = tr2(ub + j * 4096 + 1024, ub + j * 4096 + 1024 + 256);
+#pragma unroll
+      for (int i = 0; i < NI; i++)
+        fa[fb][i] = tr2(ub + j * (GU * 1024) + i * 1024, ub + j * (GU * 1024) + i * 1024 + 256);
 #pragma unroll
       for (int k = 0; k < 5; k++)
         if (k < ntaps) fb5[fb][k] = tr2(vb + j * 2048 + vlok[k], vb + j * 2048 + vhik[k]);
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       for (int k = 0; k < 5; k++)
         if (k < ntaps) {
 #pragma unroll
-          for (int i = 0; i < 2; i++)
+          for (int i = 0; i < NI; i++)
             acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[fb][i]),
                                                                 __builtin_bit_cast(bf16x8, fb5[fb][k]), acc[i][k], 0, 0, 0);
         }
@@ -177,13 +182,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int h = lane >> 5, c32 = lane & 31;
   const int b = b0 + nh * 32 + c32;
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < NI; i++)
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       if (k >= ntaps) continue;
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        const int a = a0 + (mp * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int a = a0 + (mp * NI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         p.ws[(((long)split * p.up + a) * 9 + tap0 + k) * p.vp + b] = acc[i][k][e];
       }
     }
@@ -206,11 +211,11 @@ int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W
   static const bool off = getenv("MSML_NO_HALO_WGRAD") != nullptr;
   if (off) return 0;
   if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return 0;
-  if (up % 128 != 0 || vp % 64 != 0 || A != up || Breal != vp) return 0;
+  if (up % 64 != 0 || vp % 64 != 0 || A != up || Breal != vp) return 0;
   const long strips = (long)N * cdiv(H, 7) * cdiv(W, 14);
   if ((long)N * H * W * 10 < strips * 112 * 7) return 0;           // < 70 % real k-values
   if ((long)N * H * W * up * 2 >= 0x70000000L || (long)N * H * W * vp * 2 >= 0x70000000L) return 0;
-  const int tiles = (up / 128) * (vp / 64);
+  const int tiles = (up % 128 == 0 ? up / 128 : up / 64) * (vp / 64);
   long splits = wh_cus() / tiles;                      // one resident workgroup per CU
   if (splits < 1) splits = 1;
   if (splits > strips) splits = strips;
@@ -227,13 +232,24 @@ bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float*
   a.nstrips = N * a.spy * a.spx;
   a.chunk = cdiv(a.nstrips, splits);
   a.ws = ws;
-  const size_t lds = 2 * (7 * 4 + 10 * 2) * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
+  if (up % 128 == 0) {
+    const size_t lds = 2 * (7 * 4 + 10 * 2) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<128>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    k_wgrad_halo<128><<<dim3(up / 128, vp / 64, splits), dim3(512), lds, st>>>(a);
+  } else {
+    const size_t lds = 2 * (7 * 2 + 10 * 2) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    k_wgrad_halo<64><<<dim3(up / 64, vp / 64, splits), dim3(512), lds, st>>>(a);
   }
-  k_wgrad_halo<<<dim3(up / 128, vp / 64, splits), dim3(512), lds, st>>>(a);
   return true;
 }

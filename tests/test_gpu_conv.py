@@ -378,7 +378,7 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, with_alpha):
 
 # (N, Cin, Cout, H, W): weight gradients routed to the strip / halo kernel (wgrad_halo.hip):
 # Cout % 128 == 0, Cin % 64 == 0, 3x3 s1 p1
-WGRAD_HALO = [(6, 64, 128, 14, 14), (5, 128, 128, 21, 28), (4, 128, 256, 13, 27), (40, 64, 128, 28, 28)]
+WGRAD_HALO = [(6, 64, 64, 14, 14), (9, 128, 64, 28, 28), (6, 64, 128, 14, 14), (5, 128, 128, 21, 28), (4, 128, 256, 13, 27), (40, 64, 128, 28, 28)]
 
 
 @pytest.mark.parametrize("accumulate", [False, True])
