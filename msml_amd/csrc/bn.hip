@@ -94,19 +94,23 @@ extern "C" int msml_bn_stats(const void* x, long M, int C, float* partial, int d
 // partial: [rows][2][C] (sum, sumsq).  rows == 0 -> eval mode: coefficients from running stats.
 // Training also updates the running statistics exactly like nn.BatchNorm (momentum, unbiased
 // variance) and stores mean / invstd for the backward.
-// One workgroup per 32 channels: 32 row-lanes x 32 channels, f64 accumulation, fixed-order
-// LDS tree (deterministic).  Rows go up to M/128 (6272 at 64x112x112, batch 256).
-#define FIN_LANES 32
+// One workgroup per FIN_CPB = 8 channels: 128 row-lanes x 8 channels (these kernels are chains of
+// dependent loads on a few KB of partial rows -- latency, not bandwidth: with 32 channels x 32
+// row-lanes per workgroup a 512-row reduce took 10-30 us and the 266 finalize launches of a step
+// 2.6 ms), f64 accumulation, fixed-order two-level LDS tree (deterministic).
+#define FIN_CPB 8
+#define FIN_LANES (1024 / FIN_CPB)
 template <int NQ>
 __device__ __forceinline__ void fin_reduce(const float* __restrict__ partial, int rows, int C, int c,
                                            bool cok, double (&out)[NQ]) {
-  __shared__ double red[FIN_LANES][NQ][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  __shared__ double red[FIN_LANES][NQ][FIN_CPB + 1];
+  __shared__ double red2[16][NQ][FIN_CPB + 1];
+  const int cx = threadIdx.x & (FIN_CPB - 1), ry = threadIdx.x / FIN_CPB;
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = 0.0;
   if (cok) {
-    // four independent load streams per thread (the loop is latency-bound: up to 6272 rows)
+    // four independent load streams per thread
     double a1[NQ], a2[NQ], a3[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) a1[q] = a2[q] = a3[q] = 0.0;
@@ -128,11 +132,22 @@ __device__ __forceinline__ void fin_reduce(const float* __restrict__ partial, in
 #pragma unroll
   for (int q = 0; q < NQ; q++) red[ry][q][cx] = acc[q];
   __syncthreads();
+  if (ry < 16) {                                       // 16 groups of FIN_LANES / 16 row-lanes
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      double s = 0.0;
+#pragma unroll
+      for (int y = 0; y < FIN_LANES / 16; y++) s += red[ry * (FIN_LANES / 16) + y][q][cx];
+      red2[ry][q][cx] = s;
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
     double s = 0.0;
     if (ry == 0)
-      for (int y = 0; y < FIN_LANES; y++) s += red[y][q][cx];
+#pragma unroll
+      for (int y = 0; y < 16; y++) s += red2[y][q][cx];
     out[q] = s;
   }
 }
@@ -142,13 +157,13 @@ __global__ void __launch_bounds__(1024) k_bn_finalize(const float* __restrict__ 
                               float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                               float eps, float* __restrict__ scale, float* __restrict__ shift,
                               float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
   const bool cok = c < C;
   float mean = 0.f, invstd = 1.f;
   if (rows > 0) {
     double s[2];
     fin_reduce<2>(partial, rows, C, c, cok, s);
-    if (threadIdx.x >= 32 || !cok) return;
+    if (threadIdx.x >= FIN_CPB || !cok) return;
     double m = s[0] / count;
     double var = s[1] / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -160,7 +175,7 @@ __global__ void __launch_bounds__(1024) k_bn_finalize(const float* __restrict__ 
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
     }
   } else {
-    if (threadIdx.x >= 32 || !cok) return;
+    if (threadIdx.x >= FIN_CPB || !cok) return;
     mean = rmean[c];
     invstd = 1.0f / sqrtf(rvar[c] + eps);
   }
@@ -180,7 +195,7 @@ extern "C" int msml_bn_finalize(const float* partial, int rows, int C, double co
   MSML_CHECK(C > 0 && scale && shift && rows >= 0, MSML_ERR_SHAPE, "bn_finalize: bad args");
   MSML_CHECK(rows > 0 ? (partial && count > 0) : (running_mean && running_var), MSML_ERR_SHAPE,
              "bn_finalize: train needs partials, eval needs running stats");
-  k_bn_finalize<<<cdiv(C, 32), 1024, 0, (hipStream_t)stream>>>(
+  k_bn_finalize<<<cdiv(C, FIN_CPB), 1024, 0, (hipStream_t)stream>>>(
       partial, rows, C, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
       save_mean, save_invstd);
   MSML_LAUNCH_OK("bn_finalize");
@@ -311,7 +326,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy,
 template <int NQ>
 __global__ void __launch_bounds__(1024) k_fold_rows(const float* __restrict__ partial, int rows, int C,
                                                     float* __restrict__ out) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
   const bool cok = c < C;
   const int chunk = (rows + FOLD_ROWS - 1) / FOLD_ROWS;
   const int r0 = blockIdx.y * chunk;
@@ -320,7 +335,7 @@ __global__ void __launch_bounds__(1024) k_fold_rows(const float* __restrict__ pa
   if (nr < 0) nr = 0;
   double s[NQ];
   fin_reduce<NQ>(partial + (long)r0 * NQ * C, nr, C, c, cok, s);
-  if (threadIdx.x >= 32 || !cok) return;
+  if (threadIdx.x >= FIN_CPB || !cok) return;
 #pragma unroll
   for (int q = 0; q < NQ; q++) out[((long)blockIdx.y * NQ + q) * C + c] = (float)s[q];
 }
@@ -328,11 +343,11 @@ __global__ void __launch_bounds__(1024) k_fold_rows(const float* __restrict__ pa
 __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restrict__ partial, int rows, int C, double count,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   float* __restrict__ dalpha, float* __restrict__ coef, int accumulate) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
   const bool cok = c < C;
   double s[3];
   fin_reduce<3>(partial, rows, C, c, cok, s);
-  if (threadIdx.x >= 32 || !cok) return;
+  if (threadIdx.x >= FIN_CPB || !cok) return;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s[0];
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s[1];
   if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + (float)s[2];
@@ -403,7 +418,7 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
                                                             alpha, save_mean, save_invstd,
                                                             (const DT*)residual_first, M, C, partial);
       MSML_LAUNCH_OK("bn_bwd_reduce");
-      k_bn_bwd_finalize<<<cdiv(C, 32), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef, accumulate);
+      k_bn_bwd_finalize<<<cdiv(C, FIN_CPB), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef, accumulate);
       MSML_LAUNCH_OK("bn_bwd_finalize");
       k_bn_bwd_apply<DT><<<ew_grid_c(n8, C / 8), 256, 0, st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
                                                      save_mean, save_invstd, coef, (const DT*)residual_first,
@@ -427,12 +442,12 @@ extern "C" int msml_bn_act_bwd_apply(const void* dy, const void* x, const float*
   long n8 = M * (C / 8);
   if (rows > FOLD_MIN_ROWS) {
     float* folded = coef_ws + 2 * C;
-    k_fold_rows<3><<<dim3(cdiv(C, 32), FOLD_ROWS), 1024, 0, st>>>(partial, rows, C, folded);
+    k_fold_rows<3><<<dim3(cdiv(C, FIN_CPB), FOLD_ROWS), 1024, 0, st>>>(partial, rows, C, folded);
     MSML_LAUNCH_OK("bn_bwd_fold");
     partial = folded;
     rows = FOLD_ROWS;
   }
-  k_bn_bwd_finalize<<<cdiv(C, 32), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef_ws, accumulate);
+  k_bn_bwd_finalize<<<cdiv(C, FIN_CPB), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef_ws, accumulate);
   MSML_LAUNCH_OK("bn_bwd_finalize");
   MSML_DISPATCH_DTYPE(
       dtype, "bn_act_bwd_apply",
@@ -448,18 +463,19 @@ extern "C" int msml_bn_act_bwd_apply(const void* dy, const void* x, const float*
 __global__ void __launch_bounds__(1024) k_colsum_finalize(const float* __restrict__ partial, int rows, int C,
                                                           int stride_q, float* __restrict__ out, int Creal,
                                                           int accumulate) {
+  constexpr int CS_LANES = 32;                         // 32 row-lanes x 32 channels
   // rows of [stride_q][C]; quantity 0 is the column sum.  Same 32 x 32 layout as fin_reduce.
-  __shared__ double red[FIN_LANES][33];
+  __shared__ double red[CS_LANES][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   double acc = 0.0;
   if (c < Creal)
-    for (int r = ry; r < rows; r += FIN_LANES) acc += (double)partial[(long)r * stride_q * C + c];
+    for (int r = ry; r < rows; r += CS_LANES) acc += (double)partial[(long)r * stride_q * C + c];
   red[ry][cx] = acc;
   __syncthreads();
   if (ry == 0 && c < Creal) {
     double s = 0.0;
-    for (int y = 0; y < FIN_LANES; y++) s += red[y][cx];
+    for (int y = 0; y < CS_LANES; y++) s += red[y][cx];
     out[c] = (accumulate ? out[c] : 0.f) + (float)s;
   }
 }
