@@ -54,7 +54,9 @@ __device__ __forceinline__ void slab_reduce(long M, int C, float* __restrict__ p
 
 static inline int red_rows(long M, int C) {
   int py = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
-  long rows = (M + (long)py * 16 - 1) / ((long)py * 16);     // >= 16 pixels per thread
+  static const long ppt = getenv("MSML_RED_PPT") ? atol(getenv("MSML_RED_PPT")) : 16;
+  long rows = (M + (long)py * ppt - 1) / ((long)py * ppt);     // >= ppt pixels per thread (4 / 8 measured
+  // slower end to end: more partial rows for the finalize)
   if (rows < 1) rows = 1;
   if (rows > RED_ROWS_MAX) rows = RED_ROWS_MAX;
   return (int)rows;
