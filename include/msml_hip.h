@@ -145,6 +145,13 @@ int msml_bn_finalize(const float* partial, int rows, int C, double count, const 
 int msml_bn_act_fwd(const void* x, const float* scale, const float* shift, const float* alpha,
                     const void* residual, int res_first, void* y, long M, int C, int dtype,
                     void* stream);
+/* msml_bn_act_fwd that also emits (sum, sumsq) partial rows of its OUTPUT (as stored), in the row
+ * format of msml_bn_stats: the statistics of the next IBasicBlock's leading BatchNorm
+ * (iresnet.py:57 bn1 on the previous block's output) without re-reading the tensor. */
+int msml_bn_act_fwd_stats_rows(long M, int C);
+int msml_bn_act_fwd_stats(const void* x, const float* scale, const float* shift, const float* alpha,
+                          const void* residual, int res_first, void* y, long M, int C,
+                          float* stats, int dtype, void* stream);
 int msml_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
                     const float* alpha, const float* save_mean, const float* save_invstd,
                     const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,

@@ -60,6 +60,8 @@ def make_layer(block, inplanes, planes, blocks, stride):
                                    nn.BatchNorm2d(planes * block.expansion, eps=1e-05))
     layers = [block(inplanes, planes, stride, downsample)]
     layers += [block(planes * block.expansion, planes) for _ in range(1, blocks)]
+    for blk in layers[:-1]:
+        blk.emit_stats = True          # its output feeds another block's bn1 (blocks.py)
     return nn.Sequential(*layers)
 
 

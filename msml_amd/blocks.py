@@ -25,9 +25,9 @@ def _bn_pack(bn):
             bn.eps, bn)
 
 
-def _bn_fwd(x, stats, bnp, alpha, residual):
+def _bn_fwd(x, stats, bnp, alpha, residual, emit_stats=False):
     """Training-mode BatchNorm (+PReLU) (+residual after it) on raw NHWC tensors.
-    Returns (y, coef[4][C] = scale, shift, mean, invstd)."""
+    Returns (y, coef[4][C] = scale, shift, mean, invstd[, partial statistics of y])."""
     c = x.shape[-1]
     m = x.numel() // c
     coef = torch.empty(4, c, dtype=torch.float32, device=x.device)
@@ -40,8 +40,15 @@ def _bn_fwd(x, stats, bnp, alpha, residual):
          coef[0], coef[1], coef[2], coef[3])
     y = torch.empty_like(x)
     with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
-        call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, 0, y, m, c, BF16)
+        if emit_stats:
+            ystats = torch.empty(_lib.value("msml_bn_act_fwd_stats_rows", m, c), 2, c, dtype=torch.float32,
+                                 device=x.device)
+            call("msml_bn_act_fwd_stats", x, coef[0], coef[1], alpha, residual, 0, y, m, c, ystats, BF16)
+        else:
+            call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, 0, y, m, c, BF16)
     ops.bn_counter(bnp[6])
+    if emit_stats:
+        return y, coef, ystats
     return y, coef
 
 
@@ -143,16 +150,19 @@ def _block_pack(blk):
         "bn1": _bn_pack(blk.bn1), "bn2": _bn_pack(blk.bn2), "bn3": _bn_pack(blk.bn3),
         "c1": _conv_pack(blk.conv1), "c2": _conv_pack(blk.conv2), "alpha": blk.prelu.weight,
         "ds": None if ds is None else (_conv_pack(ds[0]), _bn_pack(ds[1])),
+        # the next module is another IBasicBlock (set by make_layer): bn3's kernel also emits the
+        # statistics of the block output for that block's bn1
+        "emit_stats": bool(getattr(blk, "emit_stats", False)),
     }
 
 
 class _IBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bp, *params):
+    def forward(ctx, x, bp, xstats, *params):
         # params (for autograd bookkeeping only): conv1.w, conv2.w, [down.w], bn1 g/b, bn2 g/b, prelu,
         # bn3 g/b, [down bn g/b] -- the arithmetic reads them from the cached pack
         ds = bp["ds"]
-        o1, k1 = _bn_fwd(x, None, bp["bn1"], None, None)
+        o1, k1 = _bn_fwd(x, xstats, bp["bn1"], None, None)   # xstats: from the previous block's bn3 kernel
         c1, st1 = _conv_fwd(o1, bp["c1"])
         o2, k2 = _bn_fwd(c1, st1, bp["bn2"], bp["alpha"], None)
         c2, st2 = _conv_fwd(o2, bp["c2"])
@@ -161,13 +171,19 @@ class _IBlock(torch.autograd.Function):
             idn, kd = _bn_fwd(d, std, ds[1], None, None)
         else:
             d, kd, idn = None, None, x
-        out, k3 = _bn_fwd(c2, st2, bp["bn3"], None, idn)
+        if bp["emit_stats"] and 256 % (c2.shape[-1] // 8) == 0:
+            out, k3, ostats = _bn_fwd(c2, st2, bp["bn3"], None, idn, emit_stats=True)
+        else:
+            out, k3 = _bn_fwd(c2, st2, bp["bn3"], None, idn)
+            ostats = out.new_empty(0)
         ctx.bp = bp
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, o1, c1, o2, c2, d, k1, k2, k3, kd)
-        return out
+        ctx.mark_non_differentiable(ostats)
+        return out, ostats
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dstats):
         x, o1, c1, o2, c2, d, k1, k2, k3, kd = ctx.saved_tensors
         bp = ctx.bp
         ds = bp["ds"]
@@ -202,7 +218,7 @@ class _IBlock(torch.autograd.Function):
         grads += [g1.out(0), g1.out(1), g2.out(0), g2.out(1), g2.out(2), g3.out(0), g3.out(1)]
         if ds is not None:
             grads += [gd.out(0), gd.out(1)]
-        return (dx, None) + tuple(grads)
+        return (dx, None, None) + tuple(grads)
 
 
 def iblock(blk, x):
@@ -219,4 +235,8 @@ def iblock(blk, x):
             params += [ds[1].weight, ds[1].bias]
         bp["params"] = tuple(params)
         blk.__dict__["_msml_pack"] = bp       # (plain attribute: not a module / parameter registration)
-    return _IBlock.apply(x, bp, *bp["params"])
+    xstats = x.__dict__.get("_msml_stats") if hasattr(x, "__dict__") else None
+    out, ostats = _IBlock.apply(x, bp, xstats, *bp["params"])
+    if ostats.numel():
+        out._msml_stats = ostats           # read by the next block (same tensor object in nn.Sequential)
+    return out

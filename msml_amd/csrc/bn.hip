@@ -225,15 +225,21 @@ __device__ __forceinline__ Coef8 ldc8(const float* p, int c0, float dflt) {
   return r;
 }
 
-template <typename T>
+// STATS: also emit per-channel (sum, sumsq) partial rows of the (storage-rounded) OUTPUT, one row
+// pair per workgroup -- the statistics the next block's leading BatchNorm needs (the block output
+// is otherwise re-read by a k_bn_stats pass).  Needs C8 | 256.
+template <typename T, bool STATS>
 __global__ void __launch_bounds__(256) k_bn_act_fwd(const T* __restrict__ x, const float* __restrict__ scale,
                                                     const float* __restrict__ shift,
                                                     const float* __restrict__ alpha,
                                                     const T* __restrict__ residual, int res_first,
-                                                    T* __restrict__ y, long n8, int C8) {
+                                                    T* __restrict__ y, long n8, int C8, float* __restrict__ stats) {
   const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const int c0 = (int)(tid % C8) * 8;
   const Coef8 sc = ldc8(scale, c0, 1.f), sh = ldc8(shift, c0, 0.f), al = ldc8(alpha, c0, 1.f);
+  float q1[8], q2[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) q1[j] = q2[j] = 0.f;
   for (long i = tid; i < n8; i += (long)gridDim.x * blockDim.x) {
     Vec8 v = load8<T>(x + i * 8);
     Vec8 r;
@@ -247,6 +253,31 @@ __global__ void __launch_bounds__(256) k_bn_act_fwd(const T* __restrict__ x, con
       v.v[j] = z;
     }
     store8<T>(y + i * 8, v);
+    if (STATS) {
+      const Vec8 vr = round8<T>(v);                    // what the consumer will read back
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        q1[j] += vr.v[j];
+        q2[j] += vr.v[j] * vr.v[j];
+      }
+    }
+  }
+  if (STATS) {
+    // threads t, t + C8, ... of the block share a channel chunk: fixed-order sum through LDS
+    __shared__ float red[2][256][9];
+    const int t = threadIdx.x, C = C8 * 8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      red[0][t][j] = q1[j];
+      red[1][t][j] = q2[j];
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * C; i += 256) {
+      const int which = i / C, c = i % C, cx = c >> 3, j = c & 7;
+      float sum = 0.f;
+      for (int k = cx; k < 256; k += C8) sum += red[which][k][j];
+      stats[((long)blockIdx.x * 2 + which) * C + c] = sum;
+    }
   }
 }
 
@@ -274,10 +305,29 @@ extern "C" int msml_bn_act_fwd(const void* x, const float* scale, const float* s
              "bn_act_fwd: C/8 = %d must divide 256 or be a multiple of it", C / 8);
   long n8 = M * (C / 8);
   MSML_DISPATCH_DTYPE(dtype, "bn_act_fwd",
-                      k_bn_act_fwd<DT><<<ew_grid_c(n8, C / 8), 256, 0, (hipStream_t)stream>>>(
+                      (k_bn_act_fwd<DT, false>)<<<ew_grid_c(n8, C / 8), 256, 0, (hipStream_t)stream>>>(
                           (const DT*)x, scale, shift, alpha, (const DT*)residual, res_first, (DT*)y, n8,
-                          C / 8);)
+                          C / 8, nullptr);)
   MSML_LAUNCH_OK("bn_act_fwd");
+  return MSML_OK;
+}
+
+// Same, plus the (sum, sumsq) partial rows of the output: stats[msml_bn_act_fwd_stats_rows(M, C)][2][C]
+// in the row format of msml_bn_stats (feed it to msml_bn_finalize of the next BatchNorm).
+extern "C" int msml_bn_act_fwd_stats_rows(long M, int C) { return ew_grid_c(M * (C / 8), C / 8); }
+
+extern "C" int msml_bn_act_fwd_stats(const void* x, const float* scale, const float* shift, const float* alpha,
+                                     const void* residual, int res_first, void* y, long M, int C,
+                                     float* stats, int dtype, void* stream) {
+  MSML_CHECK(x && y && scale && shift && stats && M > 0 && C > 0 && C % 8 == 0, MSML_ERR_SHAPE,
+             "bn_act_fwd_stats: bad shape M=%ld C=%d", M, C);
+  MSML_CHECK(256 % (C / 8) == 0, MSML_ERR_UNSUPPORTED, "bn_act_fwd_stats: C/8 = %d must divide 256", C / 8);
+  long n8 = M * (C / 8);
+  MSML_DISPATCH_DTYPE(dtype, "bn_act_fwd_stats",
+                      (k_bn_act_fwd<DT, true>)<<<ew_grid_c(n8, C / 8), 256, 0, (hipStream_t)stream>>>(
+                          (const DT*)x, scale, shift, alpha, (const DT*)residual, res_first, (DT*)y, n8,
+                          C / 8, stats);)
+  MSML_LAUNCH_OK("bn_act_fwd_stats");
   return MSML_OK;
 }
 

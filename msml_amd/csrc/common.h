@@ -138,6 +138,19 @@ __device__ __forceinline__ float wave_max(float v) {
   }
 
 
+// value of a Vec8 after a round trip through storage type T
+template <typename T>
+__device__ __forceinline__ Vec8 round8(const Vec8& v);
+template <>
+__device__ __forceinline__ Vec8 round8<float>(const Vec8& v) { return v; }
+template <>
+__device__ __forceinline__ Vec8 round8<unsigned short>(const Vec8& v) {
+  Vec8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r.v[j] = bf2f(f2bf(v.v[j]));
+  return r;
+}
+
 // ---- BatchNorm backward-reduce fused into a backward-data conv epilogue ---------------------
 // The conv's output dX is the gradient dy of a training-mode BatchNorm(+PReLU) output; the conv
 // epilogue accumulates that BatchNorm's backward sums from the bf16-rounded dX it stores and the

@@ -442,3 +442,47 @@ def test_stem_im2col_path_matches_nhwc_conv(stride):
         e1 = _nn.conv_bn(mods[0][0], mods[0][1], Fh.RawImage(x), prelu=mods[0][2]).float()
         e2 = _nn.conv_bn(mods[1][0], mods[1][1], Fh.to_nhwc(x, 1), prelu=mods[1][2]).float()
     assert (e1 - e2).abs().max().item() <= 2e-2 * e2.abs().max().item()
+
+
+def test_block_chain_statistics_hand_off():
+    """make_layer marks every block but the last `emit_stats`: bn3's kernel then also emits the
+    statistics of the block output, which the next block's bn1 uses instead of a k_bn_stats pass.
+    The chain must equal the op-by-op graph (forward bits, running statistics, gradients)."""
+    import copy
+    from msml_amd import ops
+    from msml_amd.backbones.frb.iresnet import IBasicBlock, make_layer
+    torch.manual_seed(11)
+    layer = make_layer(IBasicBlock, 64, 128, 3, 2)
+    for p in layer.parameters():
+        if p.dim() == 1:
+            torch.nn.init.uniform_(p, 0.5, 1.5)
+        else:
+            torch.nn.init.normal_(p, 0, (1.0 / (p.shape[1] * 9)) ** 0.5)
+    layer = layer.cuda().train()
+    assert layer[0].emit_stats and layer[1].emit_stats and not getattr(layer[2], "emit_stats", False)
+    x0 = ops.to_nhwc(torch.randn(6, 64, 28, 28).cuda(), 1)
+    res, dout = [], None
+    for use_fn in (False, True):
+        m = copy.deepcopy(layer)
+        x = x0.clone().requires_grad_(True)
+        old = ops.BLOCK_FUNCTION
+        ops.BLOCK_FUNCTION = use_fn
+        try:
+            y = m(x)
+            if dout is None:
+                dout = torch.randn_like(y)
+            y.backward(dout)
+        finally:
+            ops.BLOCK_FUNCTION = old
+        res.append((y.detach().float(), x.grad.float(), {k: v.clone() for k, v in m.named_buffers()},
+                    {k: v.grad.float() for k, v in m.named_parameters()}))
+    (y1, dx1, b1, g1), (y2, dx2, b2, g2) = res
+    # the handed-over statistics are summed in another order (f32 partial rows): a few outputs move
+    # by one bf16 ulp
+    assert rel_err(y2.cpu().numpy(), y1.cpu().numpy()) < 3e-3
+    assert (y1 - y2).abs().max().item() <= 2e-2 * y1.abs().max().item()
+    for k in b1:
+        assert torch.allclose(b1[k].float(), b2[k].float(), rtol=1e-4, atol=1e-5), k
+    assert rel_err(dx2.cpu().numpy(), dx1.cpu().numpy()) < 1.5e-2     # three bf16 blocks deep
+    for k in g1:
+        assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-2, k
