@@ -285,6 +285,18 @@ const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, int H, int W,
 int msml_stem_im2col(const float* x, void* out, int N, int C, int H, int W, int P, int Q, int R,
                      int S, int stride, int pad, int KP, int dtype, void* stream);
 
+/* msml_bn_act_bwd_apply that also reduces the backward sums of the activation-free BatchNorm whose
+ * output gradient the written dx is (chained IBasicBlocks: block i+1's bn1 input gradient is block
+ * i's output gradient, i.e. the dy of block i's bn3, iresnet.py:65): next_x = that BatchNorm's
+ * saved input, next_partial[msml_bn_act_bwd_apply_rows(M, C)][3][C]. */
+int msml_bn_act_bwd_apply_rows(long M, int C);
+int msml_bn_act_bwd_apply_next(const void* dy, const void* x, const float* scale, const float* shift,
+                               const float* alpha, const float* save_mean, const float* save_invstd,
+                               const float* partial, int rows, const void* add, void* dx,
+                               float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
+                               int C, float* coef_ws, const void* next_x, const float* next_mean,
+                               const float* next_invstd, float* next_partial, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

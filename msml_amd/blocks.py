@@ -121,8 +121,10 @@ class _ParamGrads:
         return self.tg[i] if (self.want[i] and not self.inplace) else None
 
 
-def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None):
-    """BatchNorm(+PReLU) backward.  partial: sums already reduced by the producing conv."""
+def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None):
+    """BatchNorm(+PReLU) backward.  partial: sums already reduced by the producer of dy.
+    nxt = (x_n, coef_n): the dx written here is the output gradient of the activation-free
+    BatchNorm with saved input x_n; its backward sums are reduced in the same pass and returned."""
     c = x.shape[-1]
     m = x.numel() // c
     dx = torch.empty_like(x)
@@ -136,10 +138,21 @@ def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None):
             call("msml_add", dx, add, dx, dx.numel(), BF16)
     else:
         cw = torch.empty(98 * c, dtype=torch.float32, device=x.device)
+        if nxt is not None and 256 % (c // 8) == 0:
+            npart = torch.empty(_lib.value("msml_bn_act_bwd_apply_rows", m, c), 3, c, dtype=torch.float32,
+                                device=x.device)
+            with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (5 if add is not None else 4)):
+                call("msml_bn_act_bwd_apply_next", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial,
+                     partial.shape[0], add, dx, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, cw,
+                     nxt[0], nxt[1][2], nxt[1][3], npart, BF16)
+            pgr.done()
+            return dx, npart
         with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (4 if add is not None else 3)):
             call("msml_bn_act_bwd_apply", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial,
                  partial.shape[0], add, dx, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, cw, BF16)
     pgr.done()
+    if nxt is not None:
+        return dx, None
     return dx
 
 
@@ -158,7 +171,7 @@ def _block_pack(blk):
 
 class _IBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bp, xstats, *params):
+    def forward(ctx, x, bp, xstats, pc2, pk3, *params):
         # params (for autograd bookkeeping only): conv1.w, conv2.w, [down.w], bn1 g/b, bn2 g/b, prelu,
         # bn3 g/b, [down bn g/b] -- the arithmetic reads them from the cached pack
         ds = bp["ds"]
@@ -178,13 +191,14 @@ class _IBlock(torch.autograd.Function):
             ostats = out.new_empty(0)
         ctx.bp = bp
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(x, o1, c1, o2, c2, d, k1, k2, k3, kd)
+        bp["_last_bn3"] = (c2, k3) if bp["emit_stats"] else None   # handed to the next block by iblock()
+        ctx.save_for_backward(x, o1, c1, o2, c2, d, k1, k2, k3, kd, pc2, pk3)
         ctx.mark_non_differentiable(ostats)
         return out, ostats
 
     @staticmethod
     def backward(ctx, dout, _dstats):
-        x, o1, c1, o2, c2, d, k1, k2, k3, kd = ctx.saved_tensors
+        x, o1, c1, o2, c2, d, k1, k2, k3, kd, pc2, pk3 = ctx.saved_tensors
         bp = ctx.bp
         ds = bp["ds"]
         dev = x.device
@@ -193,7 +207,9 @@ class _IBlock(torch.autograd.Function):
         bn1, bn2, bn3, alpha = bp["bn1"], bp["bn2"], bp["bn3"], bp["alpha"]
         # bn3 (its dy is the block output gradient, which also flows to the identity path)
         g3 = _ParamGrads((bn3[0], bn3[1], None), c2.shape[-1], dev)
-        dc2 = _bn_bwd(dout, c2, k3, None, g3)
+        # (its sums may already have been reduced by the next block's bn1 kernel, which wrote dout)
+        part3 = ops.BN3_PARTIALS.pop(dout.data_ptr(), None) if bp["emit_stats"] else None
+        dc2 = _bn_bwd(dout, c2, k3, None, g3, part3)
         # conv2: dW beside, dX with bn2's backward sums from the epilogue
         dw2 = _wgrad(dc2, o2, bp["c2"])
         do2, part2 = _dgrad(dc2, bp["c2"], c1.shape[1], c1.shape[2], c1, k2, alpha)
@@ -213,12 +229,18 @@ class _IBlock(torch.autograd.Function):
             join = dout
         # bn1: dx = bn1 path + joined gradient in one kernel
         g1 = _ParamGrads((bn1[0], bn1[1], None), x.shape[-1], dev)
-        dx = _bn_bwd(do1, x, k1, None, g1, part1, add=join)
+        if pc2 is not None and part1 is not None and ops.FUSE_BN_BWD:
+            # x is the previous block's output: reduce its bn3 sums while writing its output gradient
+            dx, pprev = _bn_bwd(do1, x, k1, None, g1, part1, add=join, nxt=(pc2, pk3))
+            if pprev is not None:
+                ops.BN3_PARTIALS[dx.data_ptr()] = pprev
+        else:
+            dx = _bn_bwd(do1, x, k1, None, g1, part1, add=join)
         grads = [dw1, dw2] + ([dwd] if ds is not None else [])
         grads += [g1.out(0), g1.out(1), g2.out(0), g2.out(1), g2.out(2), g3.out(0), g3.out(1)]
         if ds is not None:
             grads += [gd.out(0), gd.out(1)]
-        return (dx, None, None) + tuple(grads)
+        return (dx, None, None, None, None) + tuple(grads)
 
 
 def iblock(blk, x):
@@ -235,8 +257,11 @@ def iblock(blk, x):
             params += [ds[1].weight, ds[1].bias]
         bp["params"] = tuple(params)
         blk.__dict__["_msml_pack"] = bp       # (plain attribute: not a module / parameter registration)
-    xstats = x.__dict__.get("_msml_stats") if hasattr(x, "__dict__") else None
-    out, ostats = _IBlock.apply(x, bp, xstats, *bp["params"])
+    xd = x.__dict__ if hasattr(x, "__dict__") else {}
+    xstats, prev = xd.get("_msml_stats"), xd.get("_msml_bn3")
+    out, ostats = _IBlock.apply(x, bp, xstats, prev[0] if prev else None, prev[1] if prev else None, *bp["params"])
+    last = bp.pop("_last_bn3", None)
     if ostats.numel():
         out._msml_stats = ostats           # read by the next block (same tensor object in nn.Sequential)
+        out._msml_bn3 = last
     return out

@@ -407,7 +407,11 @@ __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restric
   coef[C + c] = (float)(s[1] / count);
 }
 
-template <typename T>
+// NEXT: the dx this kernel writes is the dy of ANOTHER BatchNorm without activation (the previous
+// IBasicBlock's bn3, whose output was this BatchNorm's input); its backward sums
+// (sum dx, sum dx * xhat_n, 0) are accumulated here from the stored dx and that BatchNorm's saved
+// input nx -- one partial row [3][C] per workgroup, no separate reduce pass over dx.
+template <typename T, bool NEXT>
 __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift,
@@ -417,13 +421,20 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
                                                       const float* __restrict__ coef,
                                                       const T* __restrict__ res, const T* __restrict__ add,
                                                       T* __restrict__ dx, T* __restrict__ dres, long n8,
-                                                      int C8) {
+                                                      int C8, const T* __restrict__ nx,
+                                                      const float* __restrict__ nmean,
+                                                      const float* __restrict__ ninvstd,
+                                                      float* __restrict__ npartial) {
   const int C = C8 * 8;
   const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const int c0 = (int)(tid % C8) * 8;
   const Coef8 sc = ldc8(scale, c0, 1.f), sh = ldc8(shift, c0, 0.f), al = ldc8(alpha, c0, 1.f);
   const Coef8 mu = ldc8(mean, c0, 0.f), is = ldc8(invstd, c0, 1.f);
   const Coef8 k1 = ldc8(coef, c0, 0.f), k2 = ldc8(coef + C, c0, 0.f);
+  const Coef8 nmu = ldc8(NEXT ? nmean : nullptr, c0, 0.f), nis = ldc8(NEXT ? ninvstd : nullptr, c0, 1.f);
+  float nq0[8], nq1[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) nq0[j] = nq1[j] = 0.f;
   for (long i = tid; i < n8; i += (long)gridDim.x * blockDim.x) {
     Vec8 g = load8<T>(dy + i * 8);
     Vec8 v = load8<T>(x + i * 8);
@@ -446,6 +457,31 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
     }
     store8<T>(dx + i * 8, v);
     if (dres) store8<T>(dres + i * 8, g);
+    if (NEXT) {
+      const Vec8 o = round8<T>(v), xn = load8<T>(nx + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        nq0[j] += o.v[j];
+        nq1[j] += o.v[j] * ((xn.v[j] - nmu.v[j]) * nis.v[j]);
+      }
+    }
+  }
+  if (NEXT) {
+    __shared__ float red[2][256][9];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      red[0][t][j] = nq0[j];
+      red[1][t][j] = nq1[j];
+    }
+    __syncthreads();
+    for (int i = t; i < 3 * C; i += 256) {
+      const int q = i / C, c = i % C, cx = c >> 3, j = c & 7;
+      float sum = 0.f;
+      if (q < 2)
+        for (int k = cx; k < 256; k += C8) sum += red[q][k][j];
+      npartial[((long)blockIdx.x * 3 + q) * C + c] = sum;
+    }
   }
 }
 
@@ -472,9 +508,10 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
       MSML_LAUNCH_OK("bn_bwd_reduce");
       k_bn_bwd_finalize<<<cdiv(C, FIN_CPB), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef, accumulate);
       MSML_LAUNCH_OK("bn_bwd_finalize");
-      k_bn_bwd_apply<DT><<<ew_grid_c(n8, C / 8), 256, 0, st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
-                                                     save_mean, save_invstd, coef, (const DT*)residual_first,
-                                                     (const DT*)nullptr, (DT*)dx, (DT*)dres, n8, C / 8);)
+      (k_bn_bwd_apply<DT, false>)<<<ew_grid_c(n8, C / 8), 256, 0, st>>>(
+          (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, coef,
+          (const DT*)residual_first, (const DT*)nullptr, (DT*)dx, (DT*)dres, n8, C / 8, (const DT*)nullptr,
+          nullptr, nullptr, nullptr);)
   MSML_LAUNCH_OK("bn_bwd_apply");
   return MSML_OK;
 }
@@ -482,11 +519,12 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
 // Second half of msml_bn_act_bwd for callers that already hold the partial sums (a backward-data
 // conv with the fused reduce, msml_conv2d_bnbwd): finalize + apply, with an optional tensor
 // `add` summed into dx (the other gradient path that joins at the BatchNorm input).
-extern "C" int msml_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
-                                     const float* alpha, const float* save_mean, const float* save_invstd,
-                                     const float* partial, int rows, const void* add, void* dx,
-                                     float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
-                                     int C, float* coef_ws, int dtype, void* stream) {
+static int bn_bwd_apply_impl(const void* dy, const void* x, const float* scale, const float* shift,
+                             const float* alpha, const float* save_mean, const float* save_invstd,
+                             const float* partial, int rows, const void* add, void* dx, float* dgamma,
+                             float* dbeta, float* dalpha, int accumulate, long M, int C, float* coef_ws,
+                             const void* next_x, const float* next_mean, const float* next_invstd,
+                             float* next_partial, int dtype, void* stream) {
   MSML_CHECK(dy && x && dx && scale && shift && save_mean && save_invstd && partial && coef_ws && rows > 0 &&
                  M > 0 && C > 0 && C % 8 == 0 && C <= 2048,
              MSML_ERR_SHAPE, "bn_act_bwd_apply: bad args M=%ld C=%d rows=%d", M, C, rows);
@@ -501,13 +539,55 @@ extern "C" int msml_bn_act_bwd_apply(const void* dy, const void* x, const float*
   }
   k_bn_bwd_finalize<<<cdiv(C, FIN_CPB), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef_ws, accumulate);
   MSML_LAUNCH_OK("bn_bwd_finalize");
-  MSML_DISPATCH_DTYPE(
-      dtype, "bn_act_bwd_apply",
-      k_bn_bwd_apply<DT><<<ew_grid_c(n8, C / 8), 256, 0, st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
-                                                     save_mean, save_invstd, coef_ws, (const DT*)nullptr,
-                                                     (const DT*)add, (DT*)dx, (DT*)nullptr, n8, C / 8);)
+  if (next_partial) {
+    MSML_CHECK(next_x && next_mean && next_invstd && 256 % (C / 8) == 0, MSML_ERR_SHAPE,
+               "bn_act_bwd_apply_next: bad args C=%d", C);
+    MSML_DISPATCH_DTYPE(
+        dtype, "bn_act_bwd_apply_next",
+        (k_bn_bwd_apply<DT, true>)<<<ew_grid_c(n8, C / 8), 256, 0, st>>>(
+            (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, coef_ws, (const DT*)nullptr,
+            (const DT*)add, (DT*)dx, (DT*)nullptr, n8, C / 8, (const DT*)next_x, next_mean, next_invstd,
+            next_partial);)
+  } else {
+    MSML_DISPATCH_DTYPE(
+        dtype, "bn_act_bwd_apply",
+        (k_bn_bwd_apply<DT, false>)<<<ew_grid_c(n8, C / 8), 256, 0, st>>>(
+            (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, coef_ws, (const DT*)nullptr,
+            (const DT*)add, (DT*)dx, (DT*)nullptr, n8, C / 8, (const DT*)nullptr, nullptr, nullptr, nullptr);)
+  }
   MSML_LAUNCH_OK("bn_bwd_apply");
   return MSML_OK;
+}
+
+// Second half of msml_bn_act_bwd for callers that already hold the partial sums (a backward-data
+// conv with the fused reduce, msml_conv2d_bnbwd): finalize + apply, with an optional tensor
+// `add` summed into dx (the other gradient path that joins at the BatchNorm input).
+extern "C" int msml_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
+                                     const float* alpha, const float* save_mean, const float* save_invstd,
+                                     const float* partial, int rows, const void* add, void* dx,
+                                     float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
+                                     int C, float* coef_ws, int dtype, void* stream) {
+  return bn_bwd_apply_impl(dy, x, scale, shift, alpha, save_mean, save_invstd, partial, rows, add, dx, dgamma,
+                           dbeta, dalpha, accumulate, M, C, coef_ws, nullptr, nullptr, nullptr, nullptr, dtype,
+                           stream);
+}
+
+// ... and, in the same pass, the backward sums of the activation-free BatchNorm whose OUTPUT
+// gradient this dx is (next_x = that BatchNorm's saved input): next_partial[rows][3][C] with
+// rows = msml_bn_act_bwd_apply_rows(M, C), ready for msml_bn_act_bwd_apply of that BatchNorm.
+extern "C" int msml_bn_act_bwd_apply_rows(long M, int C) { return ew_grid_c(M * (C / 8), C / 8); }
+
+extern "C" int msml_bn_act_bwd_apply_next(const void* dy, const void* x, const float* scale, const float* shift,
+                                          const float* alpha, const float* save_mean, const float* save_invstd,
+                                          const float* partial, int rows, const void* add, void* dx,
+                                          float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
+                                          int C, float* coef_ws, const void* next_x, const float* next_mean,
+                                          const float* next_invstd, float* next_partial, int dtype,
+                                          void* stream) {
+  MSML_CHECK(next_partial, MSML_ERR_SHAPE, "bn_act_bwd_apply_next: next_partial is null");
+  return bn_bwd_apply_impl(dy, x, scale, shift, alpha, save_mean, save_invstd, partial, rows, add, dx, dgamma,
+                           dbeta, dalpha, accumulate, M, C, coef_ws, next_x, next_mean, next_invstd,
+                           next_partial, dtype, stream);
 }
 
 // ------------------------------------------------------------------ bias gradient ------------

@@ -241,6 +241,10 @@ FUSE_BN_BWD = os.environ.get("MSML_NO_FUSE_BN_BWD") is None
 
 # nn.BatchNorm's num_batches_tracked += 1 is one tiny kernel per BatchNorm per step; MSML.forward
 # defers them and bumps all counters with one foreach add.
+# partial backward sums of a block's bn3 produced by the NEXT block's bn1 kernel, keyed by the data
+# pointer of the gradient tensor that kernel wrote (popped by the block's backward; cleared per forward)
+BN3_PARTIALS = {}
+
 DEFER_BN_COUNTERS = False
 _PENDING_COUNTERS = []
 
