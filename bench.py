@@ -275,7 +275,15 @@ def main():
         dist.all_reduce(flag, dist.ReduceOp.MIN)
         use_graph = bool(flag.item() > 0.5)
     if not use_graph:
+        # drop the probe graph NOW: destroying it (and returning its private memory pool, ~20 GB of
+        # hipFree) otherwise happens whenever Python's cycle collector next runs -- measured as one
+        # 0.5-0.8 s step inside the timed loop
         graph = None
+        static = None
+        out = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         eager_mode(True)
 
     def one_step():
@@ -286,13 +294,41 @@ def main():
         graph.replay()
         return out
 
-    one_step()
+    # The host issues an eager step faster than the GPU runs it; left alone it runs many steps
+    # ahead, and every step in flight pins its ~10 GB of activations (tensors handed to the side
+    # streams cannot be recycled before those streams have passed them), until the caching
+    # allocator starts freeing / re-allocating device memory (measured: 36 -> 60+ ms/step on hosts
+    # that issue a step in 20 ms).  Keep at most two steps in flight, as a training loop that reads
+    # its loss or waits for its data loader does.
+    inflight = []
+    step_events = []
+
+    def throttled_step():
+        if len(inflight) >= 2:
+            inflight.pop(0).synchronize()
+        r = one_step()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        inflight.append(ev)
+        step_events.append(ev)
+        return r
+
+    throttled_step()
     barrier()
+    inflight.clear()
+    import gc
+    gc.collect()
+    gc.disable()                  # no collector pauses inside the timed region (nothing is skipped)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = one_step()
+        out = throttled_step()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("MSML_BENCH_STEP_TIMES"):
+        evs = step_events[-(args.steps + 1):]
+        print("step ms:", " ".join("%.0f" % evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)),
+              "| reserved GB %.1f" % (torch.cuda.memory_reserved() / 2 ** 30), file=sys.stderr)
     # roofline pass: the same step, eagerly, with a HIP-event pair around every instrumented
     # launch (events cannot be recorded inside a graph replay); kernel durations are unaffected
     prof = {}

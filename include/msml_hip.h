@@ -229,7 +229,9 @@ int msml_gemm_splitk(const void* a, int M, int K, const void* wp, int kop, float
 int msml_pack_weights_batched(const long* table, int count, int dtype, void* stream);
 /* Same packing through LDS tiles (coalesced on both sides; the per-step refresh).  Only the real
  * elements are written: dst must carry its zero padding already (R*S <= 49).  tile_prefix: device
- * array [count] with the exclusive prefix sum of msml_pack_tiles(A, B, R, S) over the entries. */
+ * array [count + 1] = the exclusive prefix sum of msml_pack_tiles(A, B, R, S) over the entries
+ * followed by the total; optionally [count] = -1 followed by total_tiles entry indices (tile -> entry),
+ * which saves the per-block binary search. */
 int msml_pack_tiles(int A, int B, int R, int S);
 int msml_pack_weights_tiled(const long* table, const int* tile_prefix, int count, int total_tiles,
                             int dtype, void* stream);

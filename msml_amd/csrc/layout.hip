@@ -180,11 +180,17 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_pack_tiled(const long* __restrict__ table, const int* __restrict__ prefix,
                                                     int count) {
   extern __shared__ float tile[];                      // [32][BT * RS + 1]
-  // entry of this block: last e with prefix[e] <= blockIdx.x
+  // entry of this block: last e with prefix[e] <= blockIdx.x.  prefix[count + t] (when the caller
+  // appended it) is that entry for tile t directly -- the binary search is a chain of ~8 dependent
+  // loads in front of a 10 us block
   int lo = 0, hi = count - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  if (prefix[count] == -1) {
+    lo = prefix[count + 1 + blockIdx.x];
+  } else {
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
   }
   const long* d = table + (long)lo * 16;
   const float* w = reinterpret_cast<const float*>(d[0]);

@@ -394,8 +394,9 @@ class PackCache:
             pre = [0]
             for n_ in tiles[:-1]:
                 pre.append(pre[-1] + n_)
-            self.prefix = torch.tensor(pre, dtype=torch.int32, device=dev)
             self.total_tiles = pre[-1] + tiles[-1]
+            tmap = [i for i, n_ in enumerate(tiles) for _ in range(n_)]          # tile -> entry
+            self.prefix = torch.tensor(pre + [-1] + tmap, dtype=torch.int32, device=dev)
             self.order = ptrs
         if any(DTYPE_OF[e["dst"].dtype] != dtype for e in ents):
             for e in ents:       # mixed precisions: fall back to lazy per-entry packing
