@@ -106,6 +106,8 @@ class Trainer:
         fn = Fh.normalize(feature)
         x_grad, loss_v = self.pfc.forward_backward(label, fn, None)
         seg_loss = self.seg_crit(final_seg, msk, msk)
+        # (one engine call: the OSB nodes, created first, run last; issuing the OSB backward first
+        # as its own call measured 1 % slower -- the host spends 4 ms on it before the FRB starts)
         torch.autograd.backward([fn, seg_loss], [x_grad, None])
         self.opt.all_reduce_grads(self.world)
         self.opt.step()

@@ -278,8 +278,12 @@ class _Dap(torch.autograd.Function):
     def backward(ctx, dseg):
         shape, dt = ctx.meta
         dx = torch.empty(shape, dtype=dt, device=dseg.device)
-        call("msml_dap_bwd", dseg.contiguous().float(), dx, shape[0], shape[1], shape[2], shape[3],
-             DTYPE_OF[dt])
+        dseg = dseg.contiguous().float()
+        # boundary of the OSB graph: this node runs on the OSB stream, its incoming gradient was
+        # produced (and is freed) by the loss on the main stream -- keep the allocator from handing
+        # the block to the FRB backward while this stream still reads it
+        dseg.record_stream(_lib.current_stream())
+        call("msml_dap_bwd", dseg, dx, shape[0], shape[1], shape[2], shape[3], DTYPE_OF[dt])
         return dx
 
 

@@ -212,14 +212,21 @@ def conv_dgrad_bnbwd(dy, wp, coutp, r, s, stride, pad_h, pad_w, p, q, bn_x, coef
 _WS = {}
 
 
-def workspace(nbytes, device, tag="main", raw_stream=None):
-    """Grow-only scratch buffer per (device, tag, current stream): reuse is ordered by the stream,
-    and kernels of different streams (weight-gradient stream, OSB stream, whose backward runs
-    beside the FRB backward) never share scratch memory."""
-    key = (device, tag, raw_stream if raw_stream is not None else _lib.raw_stream())
+def workspace(nbytes, device, tag="main", stream=None):
+    """Grow-only scratch buffer per (device, tag, stream): reuse is ordered by the stream, and
+    kernels of different streams (weight-gradient stream, OSB stream, whose backward runs beside
+    the FRB backward) never share scratch memory.  stream: the torch stream the buffer will be used
+    on when that is not the current one -- the buffer is then allocated FROM that stream's pool, so
+    that a buffer dropped on growth is not handed to another stream while kernels still use it
+    (this bit: NaN gradients in the first steps after the side streams were switched on)."""
+    key = (device, tag, stream.cuda_stream if stream is not None else _lib.raw_stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        else:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
 
@@ -302,7 +309,7 @@ def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accum
     if need is None:
         need = _WGRAD_WS_NEED[key] = _lib.value("msml_conv_wgrad_workspace", *key)
     raw = stream.cuda_stream if stream is not None else _lib.raw_stream()
-    ws = workspace(need, u.device, "wgrad", raw)
+    ws = workspace(need, u.device, "wgrad", stream)
     name = "conv_wgrad"
     if PROFILE.on and stream is None:
         name = "wgrad u%d v%d %dx%d k%dx%d s%d n%d" % (up, vp, p, q, r, s, stride, n)
