@@ -310,6 +310,42 @@ def test_side_streams_match_serial():
     assert torch.equal(a, b)
 
 
+def test_side_streams_switched_on_mid_run():
+    """Serial steps first, then the side streams are switched on (what bench.py does): the scratch
+    workspaces grow during the first multi-stream steps, and a buffer dropped on growth must not be
+    recycled under kernels of the weight-gradient stream (it once was: NaN gradients).  The OSB
+    backward is issued first here (its own backward call), the order that exposed it."""
+    from msml_amd import ops
+    from msml_amd.optim import FlatSGD, reference_param_groups
+    x, msk = eval_inputs(8)
+    label = synthetic.labels(8, 50, seed=1)
+
+    def run(streams_after):
+        ops._WS.clear()
+        m = hip_msml("iresnet18", 50, fp16=True).train()
+        opt = FlatSGD(reference_param_groups(m, 8, 1), 0.9, 5e-4, 5.0)
+        try:
+            for it in range(4):
+                if it == streams_after:
+                    ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
+                opt.zero_grad()
+                cls, seg, _ = m(x.cuda(), label.cuda())
+                seg_loss = StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
+                seg_loss.backward()
+                torch.nn.functional.cross_entropy(cls, label.cuda()).backward()
+                ops.wgrad_stream_join()
+                opt.step()
+            torch.cuda.synchronize()
+            return opt.flat_w.clone()
+        finally:
+            ops.WGRAD_STREAM = None
+            ops.OSB_STREAM = None
+    a = run(99)
+    b = run(2)
+    assert torch.isfinite(b).all()
+    assert torch.equal(a, b)
+
+
 def test_overlapped_allreduce_one_rank():
     """Bucketed gradient all-reduce overlapped with backward (RCCL, one-rank communicator):
     every bucket fires exactly once and the gradients equal the non-overlapped path."""
