@@ -276,6 +276,29 @@ int msml_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, con
                           float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
                           int C, float* coef_ws, int dtype, void* stream);
 
+/* Training-mode BatchNorm(+PReLU) in FRONT of a 3x3 / stride-1 / pad-1 conv (IBasicBlock:
+ * bn1 -> conv1, bn2 -> prelu -> conv2, backbones/frb/iresnet.py:58-63, backbones/osb/unet.py:82-87)
+ * applied while the conv's input image sits in LDS: the conv reads the BatchNorm's INPUT in0 and
+ * computes on X = bf16(PReLU(in0 * in_scale + in_shift)) (in_alpha NULL: no PReLU; scale / shift
+ * from msml_bn_finalize), zero padding applied to X as in the unfused graph, so the result equals
+ * msml_bn_act_fwd followed by msml_conv2d bit for bit while X is never written to HBM.
+ * msml_conv_wgrad_bnin is the matching weight gradient (u = dY, v = the BatchNorm input).
+ * bf16 only, and only the shapes of the halo-tile kernels (the *_applies queries return 1);
+ * MSML_ERR_UNSUPPORTED otherwise -- callers then materialise X with msml_bn_act_fwd. */
+int msml_conv2d_bnin_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                             int stride, int pad_h, int pad_w, int want_stats);
+int msml_conv2d_bnin(const void* in0, int c0p, const float* in_scale, const float* in_shift,
+                     const float* in_alpha, const void* wp, int kop, void* out, int coutp,
+                     float* stats, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                     int pad_h, int pad_w, void* stream);
+int msml_conv_wgrad_bnin_applies(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q,
+                                 int R, int S, int stride, int pad_h, int pad_w);
+int msml_conv_wgrad_bnin(const void* u, int up, const void* v, int vp, const float* x_scale,
+                         const float* x_shift, const float* x_alpha, float* dw, int A, int Breal,
+                         int Btot, int boff, int N, int H, int W, int P, int Q, int R, int S,
+                         int stride, int pad_h, int pad_w, int accumulate, void* workspace,
+                         long ws_bytes, void* stream);
+
 /* Name of the kernel the conv entry points launch for a shape (profiling labels only). */
 const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, int H, int W, int P, int Q,
                                int R, int S, int stride, int pad_h, int pad_w, int transposed,

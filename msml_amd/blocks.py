@@ -25,9 +25,9 @@ def _bn_pack(bn):
             bn.eps, bn)
 
 
-def _bn_fwd(x, stats, bnp, alpha, residual, emit_stats=False):
-    """Training-mode BatchNorm (+PReLU) (+residual after it) on raw NHWC tensors.
-    Returns (y, coef[4][C] = scale, shift, mean, invstd[, partial statistics of y])."""
+def _bn_coef(x, stats, bnp):
+    """Batch statistics -> coef[4][C] = scale, shift, mean, invstd of a training-mode BatchNorm
+    (running statistics updated); stats: partial rows from the producer of x, or None."""
     c = x.shape[-1]
     m = x.numel() // c
     coef = torch.empty(4, c, dtype=torch.float32, device=x.device)
@@ -38,18 +38,33 @@ def _bn_fwd(x, stats, bnp, alpha, residual, emit_stats=False):
             call("msml_bn_stats", x, m, c, stats, BF16)
     call("msml_bn_finalize", stats, stats.shape[0], c, float(m), bnp[0], bnp[1], bnp[2], bnp[3], bnp[4], bnp[5],
          coef[0], coef[1], coef[2], coef[3])
+    ops.bn_counter(bnp[6])
+    return coef
+
+
+def _bn_apply(x, coef, alpha, residual, emit_stats=False):
+    """y = PReLU(x * scale + shift) (+ residual) [, partial statistics of y]."""
+    c = x.shape[-1]
+    m = x.numel() // c
     y = torch.empty_like(x)
     with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
         if emit_stats:
             ystats = torch.empty(_lib.value("msml_bn_act_fwd_stats_rows", m, c), 2, c, dtype=torch.float32,
                                  device=x.device)
             call("msml_bn_act_fwd_stats", x, coef[0], coef[1], alpha, residual, 0, y, m, c, ystats, BF16)
-        else:
-            call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, 0, y, m, c, BF16)
-    ops.bn_counter(bnp[6])
+            return y, ystats
+        call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, 0, y, m, c, BF16)
+    return y
+
+
+def _bn_fwd(x, stats, bnp, alpha, residual, emit_stats=False):
+    """Training-mode BatchNorm (+PReLU) (+residual after it) on raw NHWC tensors.
+    Returns (y, coef[4][C] = scale, shift, mean, invstd[, partial statistics of y])."""
+    coef = _bn_coef(x, stats, bnp)
     if emit_stats:
+        y, ystats = _bn_apply(x, coef, alpha, residual, True)
         return y, coef, ystats
-    return y, coef
+    return _bn_apply(x, coef, alpha, residual), coef
 
 
 def _conv_pack(cm):
@@ -64,21 +79,42 @@ def _conv_fwd(x, cp):
                       real=(cin, cout))
 
 
-def _wgrad(dy, x, cp):
+def _bn_conv_fwd(x, stats, bnp, alpha, cp):
+    """BatchNorm(+PReLU) -> conv.  When the conv's kernels can take the BatchNorm as an input
+    transform (ops.bnin_applies) the normalised activation is never written: returns
+    (None, coef, conv out, conv out statistics), else (activation, coef, conv out, statistics)."""
+    coef = _bn_coef(x, stats, bnp)
+    w, (cout, cin, r, s), stride, ph, pw = cp
+    n, h, wd, cp_in = x.shape
+    if r == 3 and s == 3 and stride == 1 and ph == 1 and pw == 1 and \
+            ops.bnin_applies(n, h, wd, cp_in, cpad(cout), cout, cin):
+        wp = ops.PACKS.get(w, False, 0, cout, 0, cin, cin, 0, BF16)
+        y, st = ops.conv2d_bnin(x, coef, alpha, wp, cpad(cout), real=(cin, cout))
+        return None, coef, y, st
+    o = _bn_apply(x, coef, alpha, None)
+    y, st = _conv_fwd(o, cp)
+    return o, coef, y, st
+
+
+def _wgrad(dy, x, cp, xin=None):
     """dW of a conv from its output gradient and input; in-place into the flat gradient arena
-    (on the weight-gradient stream) when FlatSGD owns .grad, else a fresh tensor."""
+    (on the weight-gradient stream) when FlatSGD owns .grad, else a fresh tensor.
+    xin = (coef, alpha): x is the INPUT of the BatchNorm(+PReLU) in front of the conv (the
+    activation was not materialised, see _bn_conv_fwd)."""
     wparam, (cout, cin, r, s), stride, ph, pw = cp
     inplace = ops.INPLACE_GRADS and wparam.grad is not None
     dw = wparam.grad.view(wparam.shape) if inplace else torch.empty_like(wparam)
     side = ops.WGRAD_STREAM if inplace else None
-    args = (dy, x, dw, cout, cin, cin, 0, r, s, stride, ph, pw)
     if side is not None:
         side.wait_stream(_lib.current_stream())
         dy.record_stream(side)             # both operands may be freed (by this stream's allocator
         x.record_stream(side)              # pool) while the side stream still reads them
-        ops.conv_wgrad(*args, accumulate=True, stream=side)
+        if xin is not None:
+            xin[0].record_stream(side)
+    if xin is not None:
+        ops.conv_wgrad_bnin(dy, x, xin[0], xin[1], dw, cout, cin, cin, 0, accumulate=inplace, stream=side)
     else:
-        ops.conv_wgrad(*args, accumulate=inplace)
+        ops.conv_wgrad(dy, x, dw, cout, cin, cin, 0, r, s, stride, ph, pw, accumulate=inplace, stream=side)
     if inplace:
         ops.grad_ready(wparam)
         return None
@@ -175,10 +211,10 @@ class _IBlock(torch.autograd.Function):
         # params (for autograd bookkeeping only): conv1.w, conv2.w, [down.w], bn1 g/b, bn2 g/b, prelu,
         # bn3 g/b, [down bn g/b] -- the arithmetic reads them from the cached pack
         ds = bp["ds"]
-        o1, k1 = _bn_fwd(x, xstats, bp["bn1"], None, None)   # xstats: from the previous block's bn3 kernel
-        c1, st1 = _conv_fwd(o1, bp["c1"])
-        o2, k2 = _bn_fwd(c1, st1, bp["bn2"], bp["alpha"], None)
-        c2, st2 = _conv_fwd(o2, bp["c2"])
+        # (xstats: from the previous block's bn3 kernel; o1 / o2 are None when the BatchNorm was
+        # applied inside the conv kernels)
+        o1, k1, c1, st1 = _bn_conv_fwd(x, xstats, bp["bn1"], None, bp["c1"])
+        o2, k2, c2, st2 = _bn_conv_fwd(c1, st1, bp["bn2"], bp["alpha"], bp["c2"])
         if ds is not None:
             d, std = _conv_fwd(x, ds[0])
             idn, kd = _bn_fwd(d, std, ds[1], None, None)
@@ -211,12 +247,12 @@ class _IBlock(torch.autograd.Function):
         part3 = ops.BN3_PARTIALS.pop(dout.data_ptr(), None) if bp["emit_stats"] else None
         dc2 = _bn_bwd(dout, c2, k3, None, g3, part3)
         # conv2: dW beside, dX with bn2's backward sums from the epilogue
-        dw2 = _wgrad(dc2, o2, bp["c2"])
+        dw2 = _wgrad(dc2, o2, bp["c2"]) if o2 is not None else _wgrad(dc2, c1, bp["c2"], (k2, alpha))
         do2, part2 = _dgrad(dc2, bp["c2"], c1.shape[1], c1.shape[2], c1, k2, alpha)
         g2 = _ParamGrads((bn2[0], bn2[1], alpha), c1.shape[-1], dev)
         dc1 = _bn_bwd(do2, c1, k2, alpha, g2, part2)
         # conv1
-        dw1 = _wgrad(dc1, o1, bp["c1"])
+        dw1 = _wgrad(dc1, o1, bp["c1"]) if o1 is not None else _wgrad(dc1, x, bp["c1"], (k1, None))
         do1, part1 = _dgrad(dc1, bp["c1"], h, w, x, k1, None)
         # identity / downsample path
         dwd, gd = None, None

@@ -151,6 +151,47 @@ __device__ __forceinline__ Vec8 round8<unsigned short>(const Vec8& v) {
   return r;
 }
 
+// ---- BatchNorm(+PReLU) applied to a conv operand while it sits in LDS ----------------------------
+// The halo kernels (conv_halo / conv_ws / wgrad_halo) keep the input image in LDS for all 9 taps, so
+// a training-mode BatchNorm in front of the conv can be applied there (each wave transforms the 16-B
+// chunks it DMA'd itself, right after its own vmcnt wait) and the normalised activation is never
+// written to HBM.  Zero-padding pixels are skipped: padding applies AFTER the BatchNorm.
+// Arithmetic and rounding are those of k_bn_act_fwd (bn.hip): y = bf16(PReLU(x * scale + shift)).
+struct BnIn {
+  const float* scale;      // nullptr: no input transform
+  const float* shift;
+  const float* alpha;      // nullptr: no PReLU
+};
+// tab: LDS table [3][C] (scale, shift, alpha) filled by bn_in_fill
+__device__ __forceinline__ void bn_in_fill(const BnIn& f, float* tab, int c0, int C, int t, int nt) {
+  for (int i = t; i < C; i += nt) {
+    tab[i] = f.scale[c0 + i];
+    tab[C + i] = f.shift[c0 + i];
+    tab[2 * C + i] = f.alpha ? f.alpha[c0 + i] : 1.f;
+  }
+}
+__device__ __forceinline__ void bn_in_chunk(char* lds16, const float* tab, int C, int ch, bool has_alpha) {
+  // two halves of 4 channels, not unrolled: the callers sit at their register limit
+#pragma unroll 1
+  for (int hf = 0; hf < 2; hf++) {
+    u32x2 raw = *reinterpret_cast<const u32x2*>(lds16 + hf * 8);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + ch + hf * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(tab + C + ch + hf * 4);
+    const f32x4 al = *reinterpret_cast<const f32x4*>(tab + 2 * C + ch + hf * 4);
+    float z[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float x = (j & 1) ? __uint_as_float(raw[j >> 1] & 0xffff0000u) : __uint_as_float(raw[j >> 1] << 16);
+      float y = x * sc[j] + sh[j];
+      if (has_alpha) y = y > 0.f ? y : y * al[j];
+      z[j] = y;
+    }
+    raw[0] = (unsigned int)f2bf(z[0]) | ((unsigned int)f2bf(z[1]) << 16);
+    raw[1] = (unsigned int)f2bf(z[2]) | ((unsigned int)f2bf(z[3]) << 16);
+    *reinterpret_cast<u32x2*>(lds16 + hf * 8) = raw;
+  }
+}
+
 // ---- BatchNorm backward-reduce fused into a backward-data conv epilogue ---------------------
 // The conv's output dX is the gradient dy of a training-mode BatchNorm(+PReLU) output; the conv
 // epilogue accumulates that BatchNorm's backward sums from the bf16-rounded dX it stores and the

@@ -42,6 +42,7 @@ struct ConvHaloArgs {
   float* stats;
   int stats_rows;
   BnBwdFuse bnb;      // bnb.partial != nullptr: fused BatchNorm backward-reduce (common.h)
+  BnIn xin;           // xin.scale != nullptr: BatchNorm(+PReLU) applied to the input image in LDS (common.h)
 };
 
 #define HALO_OOB 0x78000000u
@@ -53,7 +54,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // BN output channels per workgroup, NWM wave groups along the pixel rows: (256, 1) = 8 waves x
 // 7 accumulator tiles, (128, 2) = 4 channel groups x {4, 3} tiles -- waves w and w + 4 share a SIMD,
 // so every SIMD still carries 7 tiles.
-template <int BN, int NWM, bool FUSE>
+// XF: forward launch whose input is PReLU(in * xin.scale + xin.shift), applied per slab in LDS.
+template <int BN, int NWM, bool FUSE, bool XF = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo(const ConvHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -68,6 +70,7 @@ k_conv_halo(const ConvHaloArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                                     // [2][HPX][128 B]
   char* Bs = smem + 2 * ABYTES;                        // [NW][2][32][128 B]
+  float* xtab = reinterpret_cast<float*>(smem + 2 * ABYTES + NW * 8192);   // XF: [3][C] scale, shift, alpha
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // scalar: LDS-DMA bases go to M0
@@ -116,6 +119,20 @@ k_conv_halo(const ConvHaloArgs p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(a + j * 1024), 16, aoff[i] + cs * 128u, 0, 0, 0);
     }
   };
+  // XF: every wave normalises the chunks it DMA'd itself (ordered by its own vmcnt wait); the
+  // zero padding stays zero
+  auto xform = [&](int cs, int buf) {
+    char* a = As + buf * ABYTES;
+    const bool has_alpha = p.xin.alpha != nullptr;
+#pragma unroll
+    for (int i = 0; i < NAI; i++) {
+      const int j = wave + i * NW;
+      const int hp = j * 8 + (lane >> 3);
+      const int logical = (lane & 7) ^ ((hp >> 1) & 7);
+      if (j < NAJ && aoff[i] != HALO_OOB)
+        bn_in_chunk(a + j * 1024 + lane * 16, xtab, p.C, cs * 64 + logical * 8, has_alpha);
+    }
+  };
   auto issue_b = [&](int cs, int tap, int buf) {
     char* b = Bs + wave * 8192 + buf * 4096;
     const unsigned int col = (unsigned int)(tap * p.C + cs * 64) * 2u;
@@ -143,7 +160,12 @@ k_conv_halo(const ConvHaloArgs p) {
   const int nslab = p.C >> 6, nstage = nslab * 9;
   issue_a(0, 0);
   issue_b(0, 0, 0);
+  if (XF) bn_in_fill(p.xin, xtab, 0, p.C, t, NT);
   __syncthreads();                                     // (drains vmcnt first)
+  if (XF) {
+    xform(0, 0);
+    __syncthreads();
+  }
   int cs = 0, tr = 0, ts = 0;                          // slab, tap row / column of stage q
   u32x4 a[2][MTW], b[2];
   for (int q = 0; q < nstage; q++) {
@@ -159,6 +181,8 @@ k_conv_halo(const ConvHaloArgs p) {
       if ((tr | ts) == 0 && cs + 1 < nslab) issue_a(cs + 1, (cs + 1) & 1);
     }
 #endif
+    // (the image chunks requested one stage ago have landed for this wave: the wait above)
+    if (XF && tr == 0 && ts == 1 && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
 #ifndef HALO_ABLATE_COMPUTE
     const int r = p.flip ? 2 - tr : tr, s = p.flip ? 2 - ts : ts;
@@ -372,19 +396,20 @@ k_conv_halo(const ConvHaloArgs p) {
 #endif
 }
 
-template <int BN, int NWM, bool FUSE>
+template <int BN, int NWM, bool FUSE, bool XF = false>
 static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;      // two halo images + eight private weight rings
   size_t olds = (size_t)224 * (BN + 8) * 2;
   if (olds > lds) lds = olds;
+  if (XF) lds += 3 * 1024 * sizeof(float);             // coefficient table, C <= 1024
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(a.N * a.tpy * a.tpx, a.coutp / BN);
-  k_conv_halo<BN, NWM, FUSE><<<grid, dim3(512), lds, st>>>(a);
+  k_conv_halo<BN, NWM, FUSE, XF><<<grid, dim3(512), lds, st>>>(a);
 }
 
 // Shape test shared by the dispatch and by msml_conv2d_kernel (the name query).
@@ -411,10 +436,11 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
                              int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
                              const float* scale, const float* alpha, const void* residual, int res_first,
-                             const BnBwdFuse* bnb, int* bnb_rows) {
+                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin) {
   if (!msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
     return false;
   if (bnb && (bias || scale || alpha || residual || stats)) return false;
+  if (xin && (bnb || transposed || c0p > 1024)) return false;
   ConvHaloArgs a;
   a.tpy = cdiv(H, 14); a.tpx = cdiv(W, 14);
   const long tiles = (long)N * a.tpy * a.tpx;
@@ -428,9 +454,14 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   a.stats_rows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
+  a.xin = BnIn{nullptr, nullptr, nullptr};
+  if (xin) a.xin = *xin;
   if (bnb_rows) *bnb_rows = (int)tiles;
   const bool wide = coutp % 256 == 0;
-  if (bnb) {
+  if (xin) {
+    if (wide) launch_halo<256, 1, false, true>(a, st);
+    else launch_halo<128, 2, false, true>(a, st);
+  } else if (bnb) {
     if (wide) launch_halo<256, 1, true>(a, st);
     else launch_halo<128, 2, true>(a, st);
   } else {

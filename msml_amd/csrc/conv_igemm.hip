@@ -434,6 +434,54 @@ bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, in
 bool msml_conv_ws_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                           int stride, int pad_h, int pad_w, bool want_stats);
 
+// Forward conv whose input is X = PReLU(in0 * in_scale + in_shift) -- a training-mode BatchNorm
+// (+PReLU) in front of the conv -- applied to the halo image while it sits in LDS, so X is never
+// written to HBM (zero padding applies to X, as in the unfused graph).  Only the shapes of the
+// halo-tile kernels (conv_ws.hip, conv_halo.hip): 3x3 / stride 1 / pad 1, see
+// msml_conv2d_bnin_applies; MSML_ERR_UNSUPPORTED otherwise.  stats as in msml_conv2d.
+bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
+                             int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
+                             int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
+                             const float* scale, const float* alpha, const void* residual, int res_first,
+                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin);
+bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
+                           int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
+                           int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
+                           const float* scale, const float* alpha, const void* residual, int res_first,
+                           const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin);
+
+extern "C" int msml_conv2d_bnin_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                                        int stride, int pad_h, int pad_w, int want_stats) {
+  if (getenv("MSML_NO_FAST_CONV") || c0p > 1024 || (long)N * P * Q >= (1L << 24)) return 0;
+  const int bn = msml_conv_tile_n(coutp), kop = cdiv(coutp, bn) * bn;
+  return (msml_conv_ws_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0) ||
+          msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
+             ? 1 : 0;
+}
+
+extern "C" int msml_conv2d_bnin(const void* in0, int c0p, const float* in_scale, const float* in_shift,
+                                const float* in_alpha, const void* wp, int kop, void* out, int coutp,
+                                float* stats, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                                int pad_h, int pad_w, void* stream) {
+  MSML_CHECK(in0 && wp && out && in_scale && in_shift, MSML_ERR_SHAPE, "conv2d_bnin: null pointer");
+  MSML_CHECK(N > 0 && H > 0 && W > 0 && c0p > 0 && c0p % 32 == 0 && coutp > 0 && coutp % 8 == 0, MSML_ERR_SHAPE,
+             "conv2d_bnin: bad dims N=%d H=%d W=%d c0p=%d coutp=%d", N, H, W, c0p, coutp);
+  const int bn = msml_conv_tile_n(coutp);
+  MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_bnin: packed weight rows");
+  MSML_CHECK(msml_conv2d_bnin_applies(c0p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr),
+             MSML_ERR_UNSUPPORTED, "conv2d_bnin: shape not covered by the halo-tile kernels");
+  const BnIn xin{in_scale, in_shift, in_alpha};
+  hipStream_t st = (hipStream_t)stream;
+  const bool ok =
+      msml_conv_ws_dispatch(in0, c0p, wp, kop, nullptr, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h, pad_w,
+                            0, st, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &xin) ||
+      msml_conv_halo_dispatch(in0, c0p, wp, kop, nullptr, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h,
+                              pad_w, 0, st, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &xin);
+  MSML_CHECK(ok, MSML_ERR_UNSUPPORTED, "conv2d_bnin: launch refused");
+  MSML_LAUNCH_OK("conv2d_bnin");
+  return MSML_OK;
+}
+
 // Name of the kernel msml_conv2d / msml_conv2d_fused / msml_conv2d_bnbwd launches for a shape
 // (profiling labels: bench.py's roofline names the kernel it measured).
 extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, int H, int W, int P, int Q,

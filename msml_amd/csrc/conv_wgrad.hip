@@ -263,7 +263,7 @@ bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float*
 int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
                            int stride, int pad_h, int pad_w);
 bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
-                            int splits, hipStream_t st);
+                            int splits, hipStream_t st, const BnIn* xin = nullptr);
 
 // taps handled by one workgroup of the bf16 fast kernel (narrow V operands share the U tile)
 static int wgrad_ntw(int vp, int taps) {
@@ -397,6 +397,43 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
 // ---------------------------------------------------------------- split-K GEMM (head dX) -----
 bool msml_conv_fast_splitk(const void* in0, int c0p, const void* wp, int kop, float* ws, int coutp, int N,
                            int ksplits, hipStream_t st);
+
+// Weight gradient of a conv whose input was X = PReLU(v * x_scale + x_shift) (a training-mode
+// BatchNorm in front of the conv that msml_conv2d_bnin applied on the fly): the strips of v are
+// normalised in LDS, X never exists in HBM.  Only the shapes of the strip / halo kernel
+// (msml_conv_wgrad_bnin_applies); MSML_ERR_UNSUPPORTED otherwise.
+extern "C" int msml_conv_wgrad_bnin_applies(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q,
+                                            int R, int S, int stride, int pad_h, int pad_w) {
+  return msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0 ? 1 : 0;
+}
+
+extern "C" int msml_conv_wgrad_bnin(const void* u, int up, const void* v, int vp, const float* x_scale,
+                                    const float* x_shift, const float* x_alpha, float* dw, int A, int Breal,
+                                    int Btot, int boff, int N, int H, int W, int P, int Q, int R, int S,
+                                    int stride, int pad_h, int pad_w, int accumulate, void* workspace,
+                                    long ws_bytes, void* stream) {
+  MSML_CHECK(u && v && dw && workspace && x_scale && x_shift, MSML_ERR_SHAPE, "conv_wgrad_bnin: null pointer");
+  MSML_CHECK(up > 0 && up % 8 == 0 && vp > 0 && vp % 8 == 0 && A > 0 && A <= up && Breal > 0 &&
+                 Breal <= vp && boff >= 0 && boff + Breal <= Btot,
+             MSML_ERR_SHAPE, "conv_wgrad_bnin: bad channels up=%d vp=%d A=%d Breal=%d Btot=%d boff=%d", up,
+             vp, A, Breal, Btot, boff);
+  MSML_CHECK(N > 0 && H > 0 && W > 0 && P > 0 && Q > 0, MSML_ERR_SHAPE, "conv_wgrad_bnin: bad dims");
+  const int hs = msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w);
+  MSML_CHECK(hs > 0, MSML_ERR_UNSUPPORTED, "conv_wgrad_bnin: shape not covered by the strip kernel");
+  long need = msml_conv_wgrad_workspace(up, vp, N, P, Q, R, S);
+  MSML_CHECK(ws_bytes >= need, MSML_ERR_WORKSPACE, "conv_wgrad_bnin: workspace %ld < %ld bytes", ws_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  const BnIn xin{x_scale, x_shift, x_alpha};
+  MSML_CHECK(msml_wgrad_halo_launch(u, up, v, vp, (float*)workspace, N, H, W, hs, st, &xin), MSML_ERR_UNSUPPORTED,
+             "conv_wgrad_bnin: launch refused");
+  MSML_LAUNCH_OK("conv_wgrad_bnin(halo)");
+  const int taps = R * S;
+  long total = (long)A * taps * vp;
+  int rgrid = (int)((total + 63) / 64 < 8192 ? (total + 63) / 64 : 8192);
+  k_wgrad_reduce<<<rgrid, 256, 0, st>>>((const float*)workspace, dw, hs, up, taps, vp, A, Breal, Btot, boff, accumulate);
+  MSML_LAUNCH_OK("conv_wgrad_reduce");
+  return MSML_OK;
+}
 
 extern "C" long msml_gemm_splitk_workspace(int M, int coutp, int K) {
   int stages = (K / 32 + 1) / 2;

@@ -31,13 +31,15 @@ struct ConvWsArgs {
   float* stats;
   int stats_rows;
   BnBwdFuse bnb;
+  BnIn xin;           // xin.scale != nullptr: BatchNorm(+PReLU) applied to the input image in LDS (common.h)
 };
 
 #define WS_OOB 0x78000000u
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <bool FUSE>
+// XF: forward launch whose input is PReLU(in * xin.scale + xin.shift), applied to each image in LDS.
+template <bool FUSE, bool XF = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_ws(const ConvWsArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int C = 64, PL2 = 4, PITCH = 16, TW = 14, TH = 14, BM = 224, NT = 512;
@@ -48,6 +50,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ws = smem;                                     // [9 taps][64 rows][128 B]
   char* As = smem + WBYTES;                            // [2][256 px][128 B]
+  float* xtab = reinterpret_cast<float*>(smem + WBYTES + 2 * ABYTES + 512);   // XF: [3][64]
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -84,6 +87,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 
+  // XF: every wave normalises the chunks it DMA'd itself (after its own vmcnt wait); padding stays zero
+  auto xform = [&](int tile, int buf) {
+    const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+    const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
+    char* a = As + buf * ABYTES;
+    const bool has_alpha = p.xin.alpha != nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int j = wave + i * 8;
+      const int hp = j * 8 + (lane >> 3);
+      const int logical = (lane & 7) ^ ((hp >> 1) & 7);
+      const int iy = y0 + (hp >> PL2) - 1, ix = x0 + (hp & (PITCH - 1)) - 1;
+      if (((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W))
+        bn_in_chunk(a + j * 1024 + lane * 16, xtab, C, logical * 8, has_alpha);
+    }
+  };
+
   // fragment offsets (see conv_halo.hip): weights row kg * 32 + r32, pixels (i0 + i) * 32 + r32 + tap offset
   int bfr[4];
   {
@@ -116,7 +136,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   int tile = blockIdx.x;
   if (tile < p.ntiles) issue_a(tile, 0);
+  if (XF) bn_in_fill(p.xin, xtab, 0, C, t, NT);
   __syncthreads();                                     // weights + first image landed (drains vmcnt)
+  if (XF) {
+    if (tile < p.ntiles) xform(tile, 0);
+    __syncthreads();
+  }
 
   for (int it = 0; tile < p.ntiles; it++, tile += gridDim.x) {
     const int cur = it & 1;
@@ -151,6 +176,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       const int arow = r32 + s, asw = (arow >> 1) & 7;
       const char* Arow = Abase + ((r << PL2) + arow) * 128;
       const char* B = Ws + tap * 8192;
+      if (XF && tap == 4 && tile + (int)gridDim.x < p.ntiles) {      // next image: requested 4 taps ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xform(tile + gridDim.x, cur ^ 1);
+      }
 #pragma unroll
       for (int i = 0; i < 2; i++)
         if (i < nmt) a[0][i] = *reinterpret_cast<const u32x4*>(Arow + ((h ^ asw) << 4) + i * 4096);
@@ -297,17 +326,18 @@ bool msml_conv_ws_applies(int c0p, int kop, int coutp, int N, int H, int W, int 
   return (long)N * H * W * c0p * 2 < 0x70000000L && tiles < (1L << 30);
 }
 
-template <bool FUSE>
+template <bool FUSE, bool XF = false>
 static void launch_ws(ConvWsArgs& a, hipStream_t st) {
-  const size_t lds = 9 * 64 * 128 + 2 * 256 * 128 + 512;      // (+ the 2 pixels the padding rows read past an image)
+  // (+ the 2 pixels the padding rows read past an image, + the input-transform coefficient table)
+  const size_t lds = 9 * 64 * 128 + 2 * 256 * 128 + 512 + (XF ? 3 * 64 * sizeof(float) : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_ws<FUSE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_ws<FUSE, XF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int wgs = a.ntiles < ws_num_cus() ? a.ntiles : ws_num_cus();
-  k_conv_ws<FUSE><<<dim3(wgs), dim3(512), lds, st>>>(a);
+  k_conv_ws<FUSE, XF><<<dim3(wgs), dim3(512), lds, st>>>(a);
 }
 
 // Tried by msml_conv_fast_dispatch before the im2col kernel; false = shape not covered here.
@@ -315,10 +345,11 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
                            int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                            int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
                            const float* scale, const float* alpha, const void* residual, int res_first,
-                           const BnBwdFuse* bnb, int* bnb_rows) {
+                           const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin) {
   if (!msml_conv_ws_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
     return false;
   if (bnb && (bias || scale || alpha || residual || stats)) return false;
+  if (xin && (bnb || transposed)) return false;
   ConvWsArgs a;
   a.tpy = cdiv(H, 14); a.tpx = cdiv(W, 14);
   a.ntiles = N * a.tpy * a.tpx;
@@ -331,8 +362,11 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
   a.stats_rows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
+  a.xin = BnIn{nullptr, nullptr, nullptr};
+  if (xin) a.xin = *xin;
   if (bnb_rows) *bnb_rows = a.ntiles < ws_num_cus() ? a.ntiles : ws_num_cus();
-  if (bnb) launch_ws<true>(a, st);
+  if (xin) launch_ws<false, true>(a, st);
+  else if (bnb) launch_ws<true>(a, st);
   else launch_ws<false>(a, st);
   return true;
 }

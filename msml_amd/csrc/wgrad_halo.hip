@@ -34,10 +34,12 @@ struct WgradHaloArgs {
   int N, H, W, spy, spx;      // strips per image column / row (7 rows x 14 columns each)
   int nstrips, chunk;         // total strips, strips per split
   float* ws;                  // [split][up][9][vp]
+  BnIn xin;                   // xin.scale != nullptr: X is PReLU(v * scale + shift), applied in LDS (common.h)
 };
 
 // CO = Cout rows per workgroup: 128 (a wave carries a pair of 32-row tiles) or 64 (one tile)
-template <int CO>
+// XF: the conv input X is a BatchNorm(+PReLU) of the stored tensor v; the strips are normalised in LDS
+template <int CO, bool XF = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wgrad_halo(const WgradHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int GU = CO / 32, NI = CO / 64, UBLK = 7 * GU, NBLK = UBLK + 20, NISS = (NBLK + 7) / 8;
@@ -86,6 +88,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 
+  float* xtab = reinterpret_cast<float*>(smem + 2 * STAGE);    // XF: [3][64] scale, shift, alpha of channels b0 ..
+  // XF: every wave normalises the X chunks it DMA'd itself (after its own vmcnt wait); padding stays zero
+  auto xform = [&](int strip, int buf) {
+    const int n = strip / spi, rem = strip - n * spi, sy = rem / p.spx;
+    const int y0 = sy * 7, x0 = (rem - sy * p.spx) * 14;
+    char* vb = smem + buf * STAGE + UB;
+    const bool has_alpha = p.xin.alpha != nullptr;
+#pragma unroll
+    for (int i = 0; i < NISS; i++) {
+      const int blk = wave + 8 * i;
+      if (blk >= NBLK) break;
+      if (blk >= UBLK) {
+        const int bb = blk - UBLK, hr = bb >> 1, g = bb & 1;
+        const int y = y0 + hr - 1, x = x0 + lp - 1;
+        if ((hr < 9) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W))
+          bn_in_chunk(vb + bb * 1024 + lane * 16, xtab, 64, g * 32 + lc * 8, has_alpha);
+      }
+    }
+  };
+
   f32x16 acc[NI][5];                                   // [Cout tile of the wave][tap of the group]
 #pragma unroll
   for (int i = 0; i < NI; i++)
@@ -128,7 +150,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   };
 
   if (s_begin < s_end) issue(s_begin, 0);
+  if (XF) bn_in_fill(p.xin, xtab, b0, 64, t, 512);
   __syncthreads();
+  if (XF) {
+    if (s_begin < s_end) xform(s_begin, 0);
+    __syncthreads();
+  }
   int cur = 0;
   s16x8 fa[2][NI], fb5[2][5];
   for (int strip = s_begin; strip < s_end; strip++) {
@@ -170,6 +197,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                                                                 __builtin_bit_cast(bf16x8, fb5[fb][k]), acc[i][k], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
+      // next strip's X chunks (requested at the top of this strip).  The 128-row variant has no
+      // registers to spare while fragments are live, so it waits for the last k-step (the VALU
+      // work then runs in the shadow of the MFMAs just issued).
+      if (XF && j == (CO == 128 ? 6 : 2) && strip + 1 < s_end) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xform(strip + 1, cur ^ 1);
+      }
     }
     __syncthreads();
     cur ^= 1;
@@ -206,6 +240,13 @@ static int wh_cus() {
 }
 
 // splits for a shape (0 = shape not covered by this kernel)
+// 128-row dW tiles halve the operand traffic per FLOP; 64-row tiles halve the split-K slab bytes
+// (measured at 256 -> 256 @ 14x14: 97 us with 128-row tiles, 104 us with 64-row tiles)
+static bool wh_wide(int up) {
+  static const int lim = getenv("MSML_WGRAD_HALO_WIDE_MIN") ? atoi(getenv("MSML_WGRAD_HALO_WIDE_MIN")) : 128;
+  return up % 128 == 0 && up >= lim;
+}
+
 int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
                            int stride, int pad_h, int pad_w) {
   static const bool off = getenv("MSML_NO_HALO_WGRAD") != nullptr;
@@ -215,7 +256,7 @@ int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W
   const long strips = (long)N * cdiv(H, 7) * cdiv(W, 14);
   if ((long)N * H * W * 10 < strips * 112 * 7) return 0;           // < 70 % real k-values
   if ((long)N * H * W * up * 2 >= 0x70000000L || (long)N * H * W * vp * 2 >= 0x70000000L) return 0;
-  const int tiles = (up % 128 == 0 ? up / 128 : up / 64) * (vp / 64);
+  const int tiles = (wh_wide(up) ? up / 128 : up / 64) * (vp / 64);
   long splits = wh_cus() / tiles;                      // one resident workgroup per CU
   if (splits < 1) splits = 1;
   if (splits > strips) splits = strips;
@@ -223,8 +264,21 @@ int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W
   return (int)splits;
 }
 
+template <int CO, bool XF>
+static void wh_launch(const WgradHaloArgs& a, dim3 grid, hipStream_t st) {
+  // two stages of (7 dY row blocks per 32 Cout + 10 X rows x 2 channel groups) KB (+ coefficient table)
+  const size_t lds = 2 * (7 * (CO / 32) + 10 * 2) * 1024 + (XF ? 3 * 64 * sizeof(float) : 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<CO, XF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  k_wgrad_halo<CO, XF><<<grid, dim3(512), lds, st>>>(a);
+}
+
 bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
-                            int splits, hipStream_t st) {
+                            int splits, hipStream_t st, const BnIn* xin) {
   WgradHaloArgs a;
   a.u = (const unsigned short*)u; a.up = up; a.u_bytes = (unsigned int)((long)N * H * W * up * 2);
   a.v = (const unsigned short*)v; a.vp = vp; a.v_bytes = (unsigned int)((long)N * H * W * vp * 2);
@@ -232,24 +286,14 @@ bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float*
   a.nstrips = N * a.spy * a.spx;
   a.chunk = cdiv(a.nstrips, splits);
   a.ws = ws;
-  if (up % 128 == 0) {
-    const size_t lds = 2 * (7 * 4 + 10 * 2) * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<128>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
-    k_wgrad_halo<128><<<dim3(up / 128, vp / 64, splits), dim3(512), lds, st>>>(a);
+  a.xin = BnIn{nullptr, nullptr, nullptr};
+  if (xin) a.xin = *xin;
+  if (wh_wide(up)) {
+    if (xin) wh_launch<128, true>(a, dim3(up / 128, vp / 64, splits), st);
+    else wh_launch<128, false>(a, dim3(up / 128, vp / 64, splits), st);
   } else {
-    const size_t lds = 2 * (7 * 2 + 10 * 2) * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
-    k_wgrad_halo<64><<<dim3(up / 64, vp / 64, splits), dim3(512), lds, st>>>(a);
+    if (xin) wh_launch<64, true>(a, dim3(up / 64, vp / 64, splits), st);
+    else wh_launch<64, false>(a, dim3(up / 64, vp / 64, splits), st);
   }
   return true;
 }

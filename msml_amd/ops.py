@@ -184,6 +184,69 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
     return out, stats
 
 
+# BatchNorm applied to the conv operand in LDS (msml_conv2d_bnin / msml_conv_wgrad_bnin): bit-identical
+# to the materialised activation, but measured SLOWER on MI355X (the VALU work of the transform is
+# repeated by every workgroup that loads the image -- 2.6x per element in the weight gradient --
+# and sits between the MFMAs: 256->256@14x14 bn + conv + wgrad 172 -> 201 us, step 35.1 -> 36.5 ms),
+# so it is opt-in.
+FUSE_BN_IN = os.environ.get("MSML_FUSE_BN_IN") is not None
+_BNIN_OK = {}
+
+
+def bnin_applies(n, h, w, cin_p, cout_p, a_real, b_real):
+    """True when a 3x3 / stride-1 / pad-1 conv of this shape can take its leading BatchNorm as an
+    in-LDS input transform in BOTH the forward kernel and the weight-gradient kernel (then the
+    normalised activation is never materialised)."""
+    key = (n, h, w, cin_p, cout_p, a_real, b_real)
+    ok = _BNIN_OK.get(key)
+    if ok is None:
+        ok = bool(FUSE_BN_IN and
+                  _lib.value("msml_conv2d_bnin_applies", cin_p, cout_p, n, h, w, h, w, 3, 3, 1, 1, 1, 1) and
+                  _lib.value("msml_conv_wgrad_bnin_applies", cout_p, cin_p, a_real, b_real, n, h, w, h, w,
+                             3, 3, 1, 1, 1))
+        _BNIN_OK[key] = ok
+    return ok
+
+
+def conv2d_bnin(x, coef, alpha, wp, coutp, real=None):
+    """3x3 / stride-1 / pad-1 forward conv on PReLU(x * coef[0] + coef[1]) applied in LDS
+    (msml_conv2d_bnin); returns (out, statistics partial rows of out)."""
+    n, h, w, c0p = x.shape
+    out = torch.empty(n, h, w, coutp, dtype=torch.bfloat16, device=x.device)
+    tiles = (n * h * w + tile_m(coutp) - 1) // tile_m(coutp)
+    stats = torch.empty(tiles, 2, coutp, dtype=torch.float32, device=x.device)
+    cin, cout = real if real is not None else (c0p, coutp)
+    name = "conv_igemm"
+    if PROFILE.on:
+        name = conv_label("N+bnin", c0p, 0, coutp, n, h, w, h, w, 3, 3, 1, 1, 1, 0, BF16, BF16, True)
+    with PROFILE.rec(name, 2.0 * n * h * w * cin * cout * 9):
+        call("msml_conv2d_bnin", x, c0p, coef[0], coef[1], alpha, wp, wp.shape[0], out, coutp, stats, n, h, w,
+             h, w, 3, 3, 1, 1, 1)
+    return out, stats
+
+
+def conv_wgrad_bnin(u, v, coef, alpha, dw, a, breal, btot, boff, accumulate=False, stream=None):
+    """Weight gradient of a 3x3 / stride-1 / pad-1 conv whose input was PReLU(v * coef[0] + coef[1])
+    (msml_conv_wgrad_bnin); same conventions as conv_wgrad."""
+    n, p, q, up = u.shape
+    _, h, w, vp = v.shape
+    key = (up, vp, n, p, q, 3, 3)
+    need = _WGRAD_WS_NEED.get(key)
+    if need is None:
+        need = _WGRAD_WS_NEED[key] = _lib.value("msml_conv_wgrad_workspace", *key)
+    raw = stream.cuda_stream if stream is not None else _lib.raw_stream()
+    ws = workspace(need, u.device, "wgrad", stream)
+    if PROFILE.on and stream is None:
+        name = "wgrad+bnin u%d v%d %dx%d k3x3 s1 n%d" % (up, vp, p, q, n)
+        with PROFILE.rec(name, 2.0 * n * p * q * a * breal * 9):
+            call("msml_conv_wgrad_bnin", u, up, v, vp, coef[0], coef[1], alpha, dw, a, breal, btot, boff, n, h, w,
+                 p, q, 3, 3, 1, 1, 1, int(accumulate), ws, ws.numel(), raw)
+        return dw
+    call("msml_conv_wgrad_bnin", u, up, v, vp, coef[0], coef[1], alpha, dw, a, breal, btot, boff, n, h, w,
+         p, q, 3, 3, 1, 1, 1, int(accumulate), ws, ws.numel(), raw)
+    return dw
+
+
 def conv_dgrad_bnbwd(dy, wp, coutp, r, s, stride, pad_h, pad_w, p, q, bn_x, coef, alpha, real=None):
     """Backward-data conv (transposed gather) whose epilogue also reduces the backward sums of
     the BatchNorm(+PReLU) that fed the conv (msml_conv2d_bnbwd).  coef: [4][C] scale, shift,

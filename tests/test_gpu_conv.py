@@ -396,3 +396,57 @@ def test_conv_wgrad_halo(shape, accumulate):
                    3, 3, 1, 1, 1, accumulate=accumulate)
     want = ref + (2.0 if accumulate else 0.0)
     assert (dw.cpu() - want).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+
+
+# (N, Cin, Cout, H, W): BatchNorm(+PReLU) applied to the conv input inside the halo-tile kernels
+# (msml_conv2d_bnin / msml_conv_wgrad_bnin): must equal msml_bn_act_fwd -> msml_conv2d / msml_conv_wgrad
+# bit for bit (same rounding of the normalised activation, same MFMA order)
+BNIN = [
+    (22, 64, 64, 56, 56),        # weights-stationary kernel, more tiles than one pass (it needs
+    (60, 64, 64, 28, 40),        # ... ragged tile column     >= as many statistics rows as workgroups)
+    (9, 128, 128, 28, 28),       # halo kernel, 128 output channels, two slabs
+    (6, 128, 256, 28, 28),       # halo kernel, 256 output channels
+    (7, 256, 256, 14, 14),       # four slabs: the image double buffer wraps twice
+    (4, 256, 128, 13, 27),       # ragged tiles (zero padding must stay zero)
+]
+
+
+@pytest.mark.parametrize("with_alpha", [False, True])
+@pytest.mark.parametrize("shape", BNIN)
+def test_conv_bn_in_lds_matches_unfused(shape, with_alpha):
+    n, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(sum(shape) + int(with_alpha))
+    x = ops.to_nhwc(torch.randn(n, cin, h, w_, generator=g).cuda(), _lib.BF16)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).cuda()
+    coef = torch.stack([torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5]).cuda()
+    alpha = (torch.rand(cin, generator=g) * 0.3).cuda() if with_alpha else None
+    assert _lib.value("msml_conv2d_bnin_applies", cin, cout, n, h, w_, h, w_, 3, 3, 1, 1, 1, 1) == 1
+    act = torch.empty_like(x)
+    _lib.call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, None, 0, act, n * h * w_, cin, _lib.BF16)
+    wp = ops.pack_weight(w, False, cin, 0, _lib.BF16)
+    ref, rstats = ops.conv2d(act, None, wp, None, cout, 3, 3, 1, 1, 1, False, want_stats=True)
+    got, gstats = ops.conv2d_bnin(x, coef, alpha, wp, cout)
+    assert torch.equal(got, ref)
+    assert torch.equal(gstats, rstats)
+    # weight gradient
+    dy = ops.to_nhwc(torch.randn(n, cout, h, w_, generator=g).cuda(), _lib.BF16)
+    assert _lib.value("msml_conv_wgrad_bnin_applies", cout, cin, cout, cin, n, h, w_, h, w_, 3, 3, 1, 1, 1) == 1
+    dref = torch.full((cout, cin, 3, 3), 0.5, device="cuda")
+    dgot = dref.clone()
+    ops.conv_wgrad(dy, act, dref, cout, cin, cin, 0, 3, 3, 1, 1, 1, accumulate=True)
+    ops.conv_wgrad_bnin(dy, x, coef, alpha, dgot, cout, cin, cin, 0, accumulate=True)
+    assert torch.equal(dgot, dref)
+
+
+def test_conv_bn_in_lds_refuses_other_shapes():
+    # stride 2, 1x1, 7x7 maps (too few real rows per tile), 32 channels: not on the halo-tile kernels
+    for args in [(64, 64, 4, 56, 56, 28, 28, 3, 3, 2, 1, 1, 1), (64, 64, 4, 56, 56, 56, 56, 1, 1, 1, 0, 0, 1),
+                 (512, 512, 4, 7, 7, 7, 7, 3, 3, 1, 1, 1, 1), (32, 32, 4, 56, 56, 56, 56, 3, 3, 1, 1, 1, 1)]:
+        assert _lib.value("msml_conv2d_bnin_applies", *args) == 0
+    x = torch.zeros(4, 7, 7, 512, dtype=torch.bfloat16, device="cuda")
+    coef = torch.ones(2, 512, device="cuda")
+    wp = torch.zeros(512, 9 * 512, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(4, 7, 7, 512, dtype=torch.bfloat16, device="cuda")
+    rc = _lib.try_call("msml_conv2d_bnin", x, 512, coef[0], coef[1], None, wp, 512, out, 512, None, 4, 7, 7, 7, 7,
+                       3, 3, 1, 1, 1)
+    assert rc == _lib.UNSUPPORTED

@@ -443,6 +443,54 @@ def test_block_function_matches_op_graph(cfg):
         assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-2, k
 
 
+@pytest.mark.parametrize("cfg", [(22, 64, 64, 56), (5, 128, 128, 28), (7, 256, 256, 14)])
+def test_block_bn_inside_conv_is_bit_neutral(cfg):
+    """bn1 / bn2(+PReLU) applied inside conv1 / conv2 and their weight-gradient kernels
+    (ops.FUSE_BN_IN, msml_conv2d_bnin) against the same block with the activations materialised:
+    every output, gradient and running statistic bit-identical."""
+    import copy
+    from torch import nn
+    from msml_amd import ops
+    from msml_amd.backbones.frb.iresnet import IBasicBlock
+    n, cin, cout, h = cfg
+    torch.manual_seed(sum(cfg))
+    blk = IBasicBlock(cin, cout, 1, None)
+    for p in blk.parameters():
+        if p.dim() == 1:
+            nn.init.uniform_(p, 0.5, 1.5)
+        else:
+            nn.init.normal_(p, 0, (1.0 / (p.shape[1] * 9)) ** 0.5)
+    nn.init.uniform_(blk.prelu.weight, 0.1, 0.4)
+    blk = blk.cuda().train()
+    x0 = ops.to_nhwc(torch.randn(n, cin, h, h).cuda(), 1)
+    assert ops.bnin_applies(n, h, h, cin, cout, cout, cin)
+    dout = None
+    res = []
+    for fuse in (False, True):
+        b = copy.deepcopy(blk)
+        x = x0.clone().requires_grad_(True)
+        old = ops.FUSE_BN_IN
+        ops.FUSE_BN_IN = fuse
+        ops._BNIN_OK.clear()
+        try:
+            y = b(x)
+            if dout is None:
+                dout = torch.randn_like(y)
+            y.backward(dout)
+        finally:
+            ops.FUSE_BN_IN = old
+            ops._BNIN_OK.clear()
+        torch.cuda.synchronize()
+        res.append((y.detach().clone(), x.grad.clone(), {k: v.grad.clone() for k, v in b.named_parameters()},
+                    {k: v.clone() for k, v in b.named_buffers()}))
+    (y1, dx1, g1, buf1), (y2, dx2, g2, buf2) = res
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    for k in buf1:
+        assert torch.equal(buf1[k], buf2[k]), k
+
+
 @pytest.mark.parametrize("stride", [1, 2])
 def test_stem_im2col_path_matches_nhwc_conv(stride):
     """bf16 stems: im2col of the raw image + 1x1 conv (functional.RawImage) == the 3x3 conv on the
