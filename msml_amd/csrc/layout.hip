@@ -176,6 +176,92 @@ extern "C" int msml_pack_weights_batched(const long* table, int count, int dtype
 static inline int pack_bt(int RS) { return RS <= 9 ? 32 : (RS <= 16 ? 16 : 8); }
 extern "C" int msml_pack_tiles(int A, int B, int R, int S) { return cdiv(A, 32) * cdiv(B, pack_bt(R * S)); }
 
+// RSC > 0: compile-time R*S (the index decodes below divide by it; with a run-time divisor the
+// kernel spent most of its 0.41 ms on integer division)
+template <typename T, int RSC>
+__device__ __forceinline__ void pack_tile_body(const long* __restrict__ d, int lt, float* tile) {
+  const float* w = reinterpret_cast<const float*>(d[0]);
+  T* dst = reinterpret_cast<T*>(d[1]);
+  const int Bfull = (int)d[3], a_off = (int)d[4], A = (int)d[5], b_off = (int)d[6], B = (int)d[7];
+  const int transpose = (int)d[10];
+  const int C1 = (int)d[11], C1p = (int)d[12], C2 = (int)d[13], C2p = (int)d[14];
+  const int RS = RSC > 0 ? RSC : (int)d[8] * (int)d[9], BT = RS <= 9 ? 32 : (RS <= 16 ? 16 : 8);
+  const int K0 = (RS * C1p + 31) / 32 * 32;
+  const int K1 = C2 > 0 ? (RS * C2p + 31) / 32 * 32 : 0;
+  const int Ktot = K0 + K1;
+  const int tiles_b = (B + BT - 1) / BT;
+  const int a0 = (lt / tiles_b) * 32, b0 = (lt % tiles_b) * BT;
+  const int na = A - a0 < 32 ? A - a0 : 32, nb = B - b0 < BT ? B - b0 : BT;
+  const int run = nb * RS, pitch = BT * RS + 1;
+  // rows of the parameter are contiguous runs of nb * RS floats; a wave takes rows wave, wave + 4, ...
+  // With a compile-time R*S all loads of the block are issued before the first LDS store (the
+  // rolled loop waited for every load in turn: 36 dependent round trips per block)
+  if (RSC > 0) {
+    constexpr int MAXRUN = (RSC <= 9 ? 32 : (RSC <= 16 ? 16 : 8)) * (RSC > 0 ? RSC : 1), PER = (MAXRUN + 63) / 64;
+    float v[8][PER];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int a = wv + 4 * i;
+      const float* src = w + ((long)(a_off + a0 + (a < na ? a : 0)) * Bfull + b_off + b0) * RS;
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const int j = lane + 64 * k;
+        v[i][k] = (a < na && j < run) ? src[j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int a = wv + 4 * i;
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const int j = lane + 64 * k;
+        if (a < na && j < run) tile[a * pitch + j] = v[i][k];
+      }
+    }
+  } else {
+    for (int a = threadIdx.x >> 6; a < na; a += 4) {
+      const float* src = w + ((long)(a_off + a0 + a) * Bfull + b_off + b0) * RS;
+      for (int j = threadIdx.x & 63; j < run; j += 64) tile[a * pitch + j] = src[j];
+    }
+  }
+  __syncthreads();
+  // the contiguous channel index of dst is b (forward packs) or a (transposed packs): make it the
+  // fastest thread index
+  const int nc = transpose ? na : nb, no = transpose ? nb : na;
+  const int cbase = transpose ? a0 : b0;               // first channel (inside the concatenated input)
+  if (nc % 8 == 0 && C1 % 8 == 0 && cbase % 8 == 0) {
+    // 8 consecutive channels per thread: one 16-B (bf16) store
+    const int n8 = nc / 8;
+    for (int i = threadIdx.x; i < no * RS * n8; i += 256) {
+      const int c8 = i % n8, rest = i / n8;
+      const int oidx = rest / RS, tap = rest - oidx * RS;
+      const int ko = transpose ? b0 + oidx : a0 + oidx;
+      const int ci = cbase + c8 * 8;
+      const int seg = ci >= C1;
+      const int c = seg ? ci - C1 : ci;
+      const int cp = seg ? C2p : C1p;
+      Vec8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        v.v[j] = transpose ? tile[(c8 * 8 + j) * pitch + oidx * RS + tap] : tile[oidx * pitch + (c8 * 8 + j) * RS + tap];
+      store8<T>(dst + (long)ko * Ktot + (seg ? K0 : 0) + tap * cp + c, v);
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < no * RS * nc; i += 256) {
+    const int cidx = i % nc, rest = i / nc;
+    const int oidx = rest / RS, tap = rest - oidx * RS;
+    const int a = transpose ? cidx : oidx, bb = transpose ? oidx : cidx;
+    const int ko = transpose ? b0 + bb : a0 + a;       // packed row
+    const int ci = transpose ? a0 + a : b0 + bb;       // channel inside the concatenated input
+    const int seg = ci >= C1;
+    const int c = seg ? ci - C1 : ci;
+    const int cp = seg ? C2p : C1p;
+    store1<T>(dst + (long)ko * Ktot + (seg ? K0 : 0) + tap * cp + c, tile[a * pitch + bb * RS + tap]);
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_pack_tiled(const long* __restrict__ table, const int* __restrict__ prefix,
                                                     int count) {
@@ -193,59 +279,11 @@ __global__ void __launch_bounds__(256) k_pack_tiled(const long* __restrict__ tab
     }
   }
   const long* d = table + (long)lo * 16;
-  const float* w = reinterpret_cast<const float*>(d[0]);
-  T* dst = reinterpret_cast<T*>(d[1]);
-  const int Bfull = (int)d[3], a_off = (int)d[4], A = (int)d[5], b_off = (int)d[6], B = (int)d[7];
-  const int R = (int)d[8], S = (int)d[9], transpose = (int)d[10];
-  const int C1 = (int)d[11], C1p = (int)d[12], C2 = (int)d[13], C2p = (int)d[14];
-  const int RS = R * S, BT = RS <= 9 ? 32 : (RS <= 16 ? 16 : 8);
-  const int K0 = (RS * C1p + 31) / 32 * 32;
-  const int K1 = C2 > 0 ? (RS * C2p + 31) / 32 * 32 : 0;
-  const int Ktot = K0 + K1;
-  const int tiles_b = (B + BT - 1) / BT;
-  const int lt = blockIdx.x - prefix[lo];
-  const int a0 = (lt / tiles_b) * 32, b0 = (lt % tiles_b) * BT;
-  const int na = A - a0 < 32 ? A - a0 : 32, nb = B - b0 < BT ? B - b0 : BT;
-  const int run = nb * RS, pitch = BT * RS + 1;
-  for (int i = threadIdx.x; i < na * run; i += 256) {
-    const int a = i / run, j = i - a * run;
-    tile[a * pitch + j] = w[((long)(a_off + a0 + a) * Bfull + b_off + b0) * RS + j];
-  }
-  __syncthreads();
-  // the contiguous channel index of dst is b (forward packs) or a (transposed packs): make it the
-  // fastest thread index
-  const int nc = transpose ? na : nb, no = transpose ? nb : na;
-  const int cbase = transpose ? a0 : b0;               // first channel (inside the concatenated input)
-  if (nc % 8 == 0 && C1 % 8 == 0 && cbase % 8 == 0) {
-    // 8 consecutive channels per thread: one 16-B (bf16) store
-    const int n8 = nc / 8;
-    for (int i = threadIdx.x; i < no * RS * n8; i += 256) {
-      const int c8 = i % n8, rest = i / n8;
-      const int tap = rest % RS, oidx = rest / RS;
-      const int ko = transpose ? b0 + oidx : a0 + oidx;
-      const int ci = cbase + c8 * 8;
-      const int seg = ci >= C1;
-      const int c = seg ? ci - C1 : ci;
-      const int cp = seg ? C2p : C1p;
-      Vec8 v;
-#pragma unroll
-      for (int j = 0; j < 8; j++)
-        v.v[j] = transpose ? tile[(c8 * 8 + j) * pitch + oidx * RS + tap] : tile[oidx * pitch + (c8 * 8 + j) * RS + tap];
-      store8<T>(dst + (long)ko * Ktot + (seg ? K0 : 0) + tap * cp + c, v);
-    }
-    return;
-  }
-  for (int i = threadIdx.x; i < no * RS * nc; i += 256) {
-    const int cidx = i % nc, rest = i / nc;
-    const int tap = rest % RS, oidx = rest / RS;
-    const int a = transpose ? cidx : oidx, bb = transpose ? oidx : cidx;
-    const int ko = transpose ? b0 + bb : a0 + a;       // packed row
-    const int ci = transpose ? a0 + a : b0 + bb;       // channel inside the concatenated input
-    const int seg = ci >= C1;
-    const int c = seg ? ci - C1 : ci;
-    const int cp = seg ? C2p : C1p;
-    store1<T>(dst + (long)ko * Ktot + (seg ? K0 : 0) + tap * cp + c, tile[a * pitch + bb * RS + tap]);
-  }
+  const int RS = (int)d[8] * (int)d[9], lt = blockIdx.x - prefix[lo];
+  if (RS == 9) pack_tile_body<T, 9>(d, lt, tile);
+  else if (RS == 1) pack_tile_body<T, 1>(d, lt, tile);
+  else if (RS == 49) pack_tile_body<T, 49>(d, lt, tile);
+  else pack_tile_body<T, 0>(d, lt, tile);
 }
 
 extern "C" int msml_pack_weights_tiled(const long* table, const int* tile_prefix, int count, int total_tiles,
