@@ -276,6 +276,24 @@ int msml_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, con
                           float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
                           int C, float* coef_ws, int dtype, void* stream);
 
+/* msml_bn_act_bwd_apply / _next with `add` given as the COMPACT input gradient of a 1x1 / stride-2
+ * / pad-0 conv over an H x W map (downsample path of a stage's first block,
+ * backbones/frb/iresnet.py:52-54,66): add[N][ceil(H/2)][ceil(W/2)][C] is summed into the pixels
+ * with even (y, x); the dense gradient (3/4 zeros) is neither written nor re-read.  M = N*H*W < 2^24. */
+int msml_bn_act_bwd_apply_s2(const void* dy, const void* x, const float* scale, const float* shift,
+                             const float* alpha, const float* save_mean, const float* save_invstd,
+                             const float* partial, int rows, const void* add, int H, int W, void* dx,
+                             float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
+                             int C, float* coef_ws, int dtype, void* stream);
+int msml_bn_act_bwd_apply_next_s2(const void* dy, const void* x, const float* scale,
+                                  const float* shift, const float* alpha, const float* save_mean,
+                                  const float* save_invstd, const float* partial, int rows,
+                                  const void* add, int H, int W, void* dx, float* dgamma, float* dbeta,
+                                  float* dalpha, int accumulate, long M, int C, float* coef_ws,
+                                  const void* next_x, const float* next_mean,
+                                  const float* next_invstd, float* next_partial, int dtype,
+                                  void* stream);
+
 /* Training-mode BatchNorm(+PReLU) in FRONT of a 3x3 / stride-1 / pad-1 conv (IBasicBlock:
  * bn1 -> conv1, bn2 -> prelu -> conv2, backbones/frb/iresnet.py:58-63, backbones/osb/unet.py:82-87)
  * applied while the conv's input image sits in LDS: the conv reads the BatchNorm's INPUT in0 and

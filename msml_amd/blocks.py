@@ -135,6 +135,16 @@ def _dgrad(dy, cp, h, w, bn_x=None, coef=None, alpha=None):
     return dx, None
 
 
+def _dgrad_1x1_compact(dy, cp):
+    """Input gradient of a 1x1 strided conv on the OUTPUT grid: dxc[n, py, px] = W^T dy[n, py, px]
+    (the dense gradient is dxc scattered to the pixels (stride py, stride px), zero elsewhere)."""
+    wparam, (cout, cin, _, _), _, _, _ = cp
+    wp = ops.PACKS.get(wparam, True, 0, cout, 0, cin, cout, 0, BF16)
+    dxc, _ = ops.conv2d(dy, None, wp, None, cpad(cin), 1, 1, 1, 0, 0, True, p=dy.shape[1], q=dy.shape[2],
+                        real=(cout, cin))
+    return dxc
+
+
 class _ParamGrads:
     """Targets for (dgamma, dbeta, dalpha) of one BatchNorm(+PReLU): the parameters' .grad views of
     the flat arena (accumulate) or fresh rows that the function returns."""
@@ -157,13 +167,16 @@ class _ParamGrads:
         return self.tg[i] if (self.want[i] and not self.inplace) else None
 
 
-def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None):
+def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None, add_s2=False):
     """BatchNorm(+PReLU) backward.  partial: sums already reduced by the producer of dy.
     nxt = (x_n, coef_n): the dx written here is the output gradient of the activation-free
-    BatchNorm with saved input x_n; its backward sums are reduced in the same pass and returned."""
+    BatchNorm with saved input x_n; its backward sums are reduced in the same pass and returned.
+    add_s2: `add` is the compact input gradient of a 1x1 / stride-2 conv (needs `partial`)."""
     c = x.shape[-1]
     m = x.numel() // c
     dx = torch.empty_like(x)
+    s2 = (add, x.shape[1], x.shape[2]) if add_s2 else (add,)
+    sfx = "_s2" if add_s2 else ""
     if partial is None:
         rows = ops.bn_stats_rows(m, c)
         ws = ops.workspace((rows * 3 * c + 2 * c) * 4, x.device)
@@ -178,14 +191,14 @@ def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None):
             npart = torch.empty(_lib.value("msml_bn_act_bwd_apply_rows", m, c), 3, c, dtype=torch.float32,
                                 device=x.device)
             with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (5 if add is not None else 4)):
-                call("msml_bn_act_bwd_apply_next", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial,
-                     partial.shape[0], add, dx, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, cw,
+                call("msml_bn_act_bwd_apply_next" + sfx, dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial,
+                     partial.shape[0], *s2, dx, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, cw,
                      nxt[0], nxt[1][2], nxt[1][3], npart, BF16)
             pgr.done()
             return dx, npart
         with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (4 if add is not None else 3)):
-            call("msml_bn_act_bwd_apply", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial,
-                 partial.shape[0], add, dx, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, cw, BF16)
+            call("msml_bn_act_bwd_apply" + sfx, dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial,
+                 partial.shape[0], *s2, dx, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, cw, BF16)
     pgr.done()
     if nxt is not None:
         return dx, None
@@ -260,18 +273,26 @@ class _IBlock(torch.autograd.Function):
             gd = _ParamGrads((ds[1][0], ds[1][1], None), d.shape[-1], dev)
             dd = _bn_bwd(dout, d, kd, None, gd)
             dwd = _wgrad(dd, x, ds[0])
-            join, _ = _dgrad(dd, ds[0], h, w)
+            # 1x1 / stride-2 downsample: its input gradient lives on the even pixels only -- keep it
+            # compact ([N][P][Q][C], a plain 1x1 GEMM) and let bn1's apply kernel scatter-add it
+            (_, (_, _, dr, dsz), dstride, dph, dpw) = ds[0]
+            join_s2 = (ops.SPARSE_DOWNSAMPLE_GRAD and part1 is not None and dr == 1 and dsz == 1 and dstride == 2
+                       and dph == 0 and dpw == 0 and n * h * w < (1 << 24))
+            if join_s2:
+                join = _dgrad_1x1_compact(dd, ds[0])
+            else:
+                join, _ = _dgrad(dd, ds[0], h, w)
         else:
-            join = dout
+            join, join_s2 = dout, False
         # bn1: dx = bn1 path + joined gradient in one kernel
         g1 = _ParamGrads((bn1[0], bn1[1], None), x.shape[-1], dev)
         if pc2 is not None and part1 is not None and ops.FUSE_BN_BWD:
             # x is the previous block's output: reduce its bn3 sums while writing its output gradient
-            dx, pprev = _bn_bwd(do1, x, k1, None, g1, part1, add=join, nxt=(pc2, pk3))
+            dx, pprev = _bn_bwd(do1, x, k1, None, g1, part1, add=join, nxt=(pc2, pk3), add_s2=join_s2)
             if pprev is not None:
                 ops.BN3_PARTIALS[dx.data_ptr()] = pprev
         else:
-            dx = _bn_bwd(do1, x, k1, None, g1, part1, add=join)
+            dx = _bn_bwd(do1, x, k1, None, g1, part1, add=join, add_s2=join_s2)
         grads = [dw1, dw2] + ([dwd] if ds is not None else [])
         grads += [g1.out(0), g1.out(1), g2.out(0), g2.out(1), g2.out(2), g3.out(0), g3.out(1)]
         if ds is not None:

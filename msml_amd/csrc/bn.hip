@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float* __restric
 // IBasicBlock's bn3, whose output was this BatchNorm's input); its backward sums
 // (sum dx, sum dx * xhat_n, 0) are accumulated here from the stored dx and that BatchNorm's saved
 // input nx -- one partial row [3][C] per workgroup, no separate reduce pass over dx.
-template <typename T, bool NEXT>
+template <typename T, bool NEXT, bool ADD_S2 = false>
 __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift,
@@ -424,13 +424,17 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
                                                       int C8, const T* __restrict__ nx,
                                                       const float* __restrict__ nmean,
                                                       const float* __restrict__ ninvstd,
-                                                      float* __restrict__ npartial) {
+                                                      float* __restrict__ npartial, int aH, int aW) {
   const int C = C8 * 8;
   const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const int c0 = (int)(tid % C8) * 8;
   const Coef8 sc = ldc8(scale, c0, 1.f), sh = ldc8(shift, c0, 0.f), al = ldc8(alpha, c0, 1.f);
   const Coef8 mu = ldc8(mean, c0, 0.f), is = ldc8(invstd, c0, 1.f);
   const Coef8 k1 = ldc8(coef, c0, 0.f), k2 = ldc8(coef + C, c0, 0.f);
+  // ADD_S2: `add` is the COMPACT input gradient of a 1x1 / stride-2 conv, [N][ceil(H/2)][ceil(W/2)][C]:
+  // it lands on the pixels with even y and x, the other three quarters of the dense gradient are zero
+  const float rcpW = ADD_S2 ? 1.0f / (float)aW : 0.f, rcpH = ADD_S2 ? 1.0f / (float)aH : 0.f;
+  const int aPw = (aW + 1) >> 1, aPh = (aH + 1) >> 1;
   const Coef8 nmu = ldc8(NEXT ? nmean : nullptr, c0, 0.f), nis = ldc8(NEXT ? ninvstd : nullptr, c0, 1.f);
   float nq0[8], nq1[8];
 #pragma unroll
@@ -440,7 +444,19 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
     Vec8 v = load8<T>(x + i * 8);
     Vec8 rr, ad;
     if (res) rr = load8<T>(res + i * 8);
-    if (add) ad = load8<T>(add + i * 8);
+    bool has_add = add != nullptr;
+    if (ADD_S2) {
+      // pixel -> (n, y, x) with float reciprocals (exact below 2^24 pixels, checked by the host) + fix-up
+      const int pix = (int)(i / C8);
+      int row = (int)((float)pix * rcpW), xx = pix - row * aW;
+      if (xx < 0) { row--; xx += aW; } else if (xx >= aW) { row++; xx -= aW; }
+      int nn = (int)((float)row * rcpH), yy = row - nn * aH;
+      if (yy < 0) { nn--; yy += aH; } else if (yy >= aH) { nn++; yy -= aH; }
+      has_add = !((xx | yy) & 1);
+      if (has_add) ad = load8<T>(add + (((long)nn * aPh + (yy >> 1)) * aPw + (xx >> 1)) * C + c0);
+    } else if (add) {
+      ad = load8<T>(add + i * 8);
+    }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       float gg = g.v[j];
@@ -452,7 +468,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const T* __restrict__ dy, 
       float xh = (v.v[j] - mu.v[j]) * is.v[j];
       // scale[c] == gamma * invstd
       v.v[j] = sc.v[j] * (gg - k1.v[j] - xh * k2.v[j]);
-      if (add) v.v[j] += ad.v[j];
+      if (has_add) v.v[j] += ad.v[j];
       g.v[j] = gg;
     }
     store8<T>(dx + i * 8, v);
@@ -511,7 +527,7 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
       (k_bn_bwd_apply<DT, false>)<<<ew_grid_c(n8, C / 8), 256, 0, st>>>(
           (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, coef,
           (const DT*)residual_first, (const DT*)nullptr, (DT*)dx, (DT*)dres, n8, C / 8, (const DT*)nullptr,
-          nullptr, nullptr, nullptr);)
+          nullptr, nullptr, nullptr, 0, 0);)
   MSML_LAUNCH_OK("bn_bwd_apply");
   return MSML_OK;
 }
@@ -524,10 +540,13 @@ static int bn_bwd_apply_impl(const void* dy, const void* x, const float* scale, 
                              const float* partial, int rows, const void* add, void* dx, float* dgamma,
                              float* dbeta, float* dalpha, int accumulate, long M, int C, float* coef_ws,
                              const void* next_x, const float* next_mean, const float* next_invstd,
-                             float* next_partial, int dtype, void* stream) {
+                             float* next_partial, int dtype, void* stream, int add_h = 0, int add_w = 0) {
   MSML_CHECK(dy && x && dx && scale && shift && save_mean && save_invstd && partial && coef_ws && rows > 0 &&
                  M > 0 && C > 0 && C % 8 == 0 && C <= 2048,
              MSML_ERR_SHAPE, "bn_act_bwd_apply: bad args M=%ld C=%d rows=%d", M, C, rows);
+  const bool s2 = add_h > 0;
+  MSML_CHECK(!s2 || (add && add_w > 0 && M % ((long)add_h * add_w) == 0 && M < (1L << 24)), MSML_ERR_SHAPE,
+             "bn_act_bwd_apply: stride-2 add needs M = N*H*W < 2^24 (M=%ld H=%d W=%d)", M, add_h, add_w);
   hipStream_t st = (hipStream_t)stream;
   long n8 = M * (C / 8);
   if (rows > FOLD_MIN_ROWS) {
@@ -539,22 +558,22 @@ static int bn_bwd_apply_impl(const void* dy, const void* x, const float* scale, 
   }
   k_bn_bwd_finalize<<<cdiv(C, FIN_CPB), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef_ws, accumulate);
   MSML_LAUNCH_OK("bn_bwd_finalize");
+#define BN_APPLY_LAUNCH(NEXT_, S2_, NX, NM, NI, NP)                                                          \
+  (k_bn_bwd_apply<DT, NEXT_, S2_>)<<<ew_grid_c(n8, C / 8), 256, 0, st>>>(                                    \
+      (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, coef_ws, (const DT*)nullptr, \
+      (const DT*)add, (DT*)dx, (DT*)nullptr, n8, C / 8, (const DT*)(NX), NM, NI, NP, add_h, add_w);
   if (next_partial) {
     MSML_CHECK(next_x && next_mean && next_invstd && 256 % (C / 8) == 0, MSML_ERR_SHAPE,
                "bn_act_bwd_apply_next: bad args C=%d", C);
-    MSML_DISPATCH_DTYPE(
-        dtype, "bn_act_bwd_apply_next",
-        (k_bn_bwd_apply<DT, true>)<<<ew_grid_c(n8, C / 8), 256, 0, st>>>(
-            (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, coef_ws, (const DT*)nullptr,
-            (const DT*)add, (DT*)dx, (DT*)nullptr, n8, C / 8, (const DT*)next_x, next_mean, next_invstd,
-            next_partial);)
+    MSML_DISPATCH_DTYPE(dtype, "bn_act_bwd_apply_next",
+                        if (s2) { BN_APPLY_LAUNCH(true, true, next_x, next_mean, next_invstd, next_partial) }
+                        else { BN_APPLY_LAUNCH(true, false, next_x, next_mean, next_invstd, next_partial) })
   } else {
-    MSML_DISPATCH_DTYPE(
-        dtype, "bn_act_bwd_apply",
-        (k_bn_bwd_apply<DT, false>)<<<ew_grid_c(n8, C / 8), 256, 0, st>>>(
-            (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, coef_ws, (const DT*)nullptr,
-            (const DT*)add, (DT*)dx, (DT*)nullptr, n8, C / 8, (const DT*)nullptr, nullptr, nullptr, nullptr);)
+    MSML_DISPATCH_DTYPE(dtype, "bn_act_bwd_apply",
+                        if (s2) { BN_APPLY_LAUNCH(false, true, nullptr, nullptr, nullptr, nullptr) }
+                        else { BN_APPLY_LAUNCH(false, false, nullptr, nullptr, nullptr, nullptr) })
   }
+#undef BN_APPLY_LAUNCH
   MSML_LAUNCH_OK("bn_bwd_apply");
   return MSML_OK;
 }
@@ -588,6 +607,35 @@ extern "C" int msml_bn_act_bwd_apply_next(const void* dy, const void* x, const f
   return bn_bwd_apply_impl(dy, x, scale, shift, alpha, save_mean, save_invstd, partial, rows, add, dx, dgamma,
                            dbeta, dalpha, accumulate, M, C, coef_ws, next_x, next_mean, next_invstd,
                            next_partial, dtype, stream);
+}
+
+// Same two entry points with `add` given as the COMPACT input gradient of a 1x1 / stride-2 / pad-0
+// conv over an H x W map (the downsample path of the first block of a stage,
+// backbones/frb/iresnet.py:52-54,66): add[N][ceil(H/2)][ceil(W/2)][C] lands on the pixels with even
+// (y, x); the dense gradient -- three quarters zeros -- is neither written nor re-read.
+extern "C" int msml_bn_act_bwd_apply_s2(const void* dy, const void* x, const float* scale, const float* shift,
+                                        const float* alpha, const float* save_mean, const float* save_invstd,
+                                        const float* partial, int rows, const void* add, int H, int W, void* dx,
+                                        float* dgamma, float* dbeta, float* dalpha, int accumulate, long M,
+                                        int C, float* coef_ws, int dtype, void* stream) {
+  MSML_CHECK(add && H > 0 && W > 0, MSML_ERR_SHAPE, "bn_act_bwd_apply_s2: bad add H=%d W=%d", H, W);
+  return bn_bwd_apply_impl(dy, x, scale, shift, alpha, save_mean, save_invstd, partial, rows, add, dx, dgamma,
+                           dbeta, dalpha, accumulate, M, C, coef_ws, nullptr, nullptr, nullptr, nullptr, dtype,
+                           stream, H, W);
+}
+
+extern "C" int msml_bn_act_bwd_apply_next_s2(const void* dy, const void* x, const float* scale,
+                                             const float* shift, const float* alpha, const float* save_mean,
+                                             const float* save_invstd, const float* partial, int rows,
+                                             const void* add, int H, int W, void* dx, float* dgamma, float* dbeta,
+                                             float* dalpha, int accumulate, long M, int C, float* coef_ws,
+                                             const void* next_x, const float* next_mean,
+                                             const float* next_invstd, float* next_partial, int dtype,
+                                             void* stream) {
+  MSML_CHECK(add && H > 0 && W > 0 && next_partial, MSML_ERR_SHAPE, "bn_act_bwd_apply_next_s2: bad args");
+  return bn_bwd_apply_impl(dy, x, scale, shift, alpha, save_mean, save_invstd, partial, rows, add, dx, dgamma,
+                           dbeta, dalpha, accumulate, M, C, coef_ws, next_x, next_mean, next_invstd,
+                           next_partial, dtype, stream, H, W);
 }
 
 // ------------------------------------------------------------------ bias gradient ------------

@@ -308,6 +308,8 @@ OSB_STREAM = None
 # backward-reduce fused into the backward-data conv epilogue.  Switches exist for A/B tests.
 BLOCK_FUNCTION = os.environ.get("MSML_NO_BLOCK_FUNCTION") is None
 FUSE_BN_BWD = os.environ.get("MSML_NO_FUSE_BN_BWD") is None
+# 1x1 / stride-2 downsample backward kept compact and scatter-added by bn1's apply kernel
+SPARSE_DOWNSAMPLE_GRAD = os.environ.get("MSML_NO_SPARSE_DOWNSAMPLE_GRAD") is None
 
 # nn.BatchNorm's num_batches_tracked += 1 is one tiny kernel per BatchNorm per step; MSML.forward
 # defers them and bumps all counters with one foreach add.

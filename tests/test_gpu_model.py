@@ -463,7 +463,8 @@ def test_block_bn_inside_conv_is_bit_neutral(cfg):
     nn.init.uniform_(blk.prelu.weight, 0.1, 0.4)
     blk = blk.cuda().train()
     x0 = ops.to_nhwc(torch.randn(n, cin, h, h).cuda(), 1)
-    assert ops.bnin_applies(n, h, h, cin, cout, cout, cin)
+    from msml_amd import _lib
+    assert _lib.value("msml_conv2d_bnin_applies", cin, cout, n, h, h, h, h, 3, 3, 1, 1, 1, 1) == 1
     dout = None
     res = []
     for fuse in (False, True):
@@ -489,6 +490,49 @@ def test_block_bn_inside_conv_is_bit_neutral(cfg):
         assert torch.equal(g1[k], g2[k]), k
     for k in buf1:
         assert torch.equal(buf1[k], buf2[k]), k
+
+
+@pytest.mark.parametrize("cfg", [(4, 64, 128, 14), (3, 64, 64, 9), (2, 64, 64, 56), (3, 128, 256, 28)])
+def test_block_compact_downsample_gradient(cfg):
+    """First block of a stage: the input gradient of the 1x1 / stride-2 downsample conv stays compact
+    and is scatter-added by bn1's apply kernel (msml_bn_act_bwd_apply_s2) -- same bits as the dense
+    gradient + dense add (odd map sizes included)."""
+    import copy
+    from torch import nn
+    from msml_amd import ops
+    from msml_amd.backbones.frb.iresnet import IBasicBlock, conv1x1
+    n, cin, cout, h = cfg
+    torch.manual_seed(sum(cfg))
+    down = nn.Sequential(conv1x1(cin, cout, 2), nn.BatchNorm2d(cout, eps=1e-05))
+    blk = IBasicBlock(cin, cout, 2, down)
+    for p in blk.parameters():
+        if p.dim() == 1:
+            nn.init.uniform_(p, 0.5, 1.5)
+        else:
+            nn.init.normal_(p, 0, (1.0 / (p.shape[1] * 9)) ** 0.5)
+    blk = blk.cuda().train()
+    x0 = ops.to_nhwc(torch.randn(n, cin, h, h).cuda(), 1)
+    dout = None
+    res = []
+    for sparse in (False, True):
+        b = copy.deepcopy(blk)
+        x = x0.clone().requires_grad_(True)
+        old = ops.SPARSE_DOWNSAMPLE_GRAD
+        ops.SPARSE_DOWNSAMPLE_GRAD = sparse
+        try:
+            y = b(x)
+            if dout is None:
+                dout = torch.randn_like(y)
+            y.backward(dout)
+        finally:
+            ops.SPARSE_DOWNSAMPLE_GRAD = old
+        torch.cuda.synchronize()
+        res.append((x.grad.clone(), {k: v.grad.clone() for k, v in b.named_parameters()}))
+    (dx1, g1), (dx2, g2) = res
+    assert torch.isfinite(dx2.float()).all()
+    assert torch.equal(dx1, dx2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
 
 
 @pytest.mark.parametrize("stride", [1, 2])
