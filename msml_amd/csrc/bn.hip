@@ -17,9 +17,11 @@
 // ------------------------------------------------------------------ per-channel reduction ---
 // Generic slab reducer: thread (cx, py) accumulates NQ quantities x 8 channels over pixels
 // py, py+PY, ... of the block's slab, then LDS-reduces over py.  F: functor
-//   void operator()(long pix, int c8, float (&q)[NQ][8])  adds one pixel chunk's contribution.
-template <int NQ, typename F>
-__device__ __forceinline__ void slab_reduce(long M, int C, float* __restrict__ partial, F f) {
+//   D ld(long pix, int c8)                   loads one pixel chunk,
+//   void f(const D& d, float (&q)[NQ][8])    adds its contribution.
+// PIPE: four pixels per trip (see below) -- for launches with few workgroups
+template <int NQ, bool PIPE, typename L, typename F>
+__device__ __forceinline__ void slab_reduce(long M, int C, float* __restrict__ partial, L ld, F f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);            // [PY][NQ][C]
   const int C8 = C / 8;
@@ -35,8 +37,22 @@ __device__ __forceinline__ void slab_reduce(long M, int C, float* __restrict__ p
   const long beg = blockIdx.x * per;
   long end = beg + per;
   if (end > M) end = M;
-  if (py < PY)
-    for (long pix = beg + py; pix < end; pix += PY) f(pix, cx, q);
+  // PIPE: four pixels per trip, all their loads issued before the first accumulation (a rolled loop
+  // waits for every pixel's loads in turn: with fewer workgroups than ~2 per CU the launch is bound
+  // by that latency chain -- 256 x 14 x 14 x 256: 38.9 -> 36.0 us; large tensors lose occupancy to
+  // the extra registers and keep the rolled loop).  Same accumulation order (ascending pixels).
+  if (py < PY) {
+    long pix = beg + py;
+    if (PIPE)
+    for (; pix + 3 * PY < end; pix += 4 * PY) {
+      auto d0 = ld(pix, cx), d1 = ld(pix + PY, cx), d2 = ld(pix + 2 * PY, cx), d3 = ld(pix + 3 * PY, cx);
+      f(d0, q);
+      f(d1, q);
+      f(d2, q);
+      f(d3, q);
+    }
+    for (; pix < end; pix += PY) f(ld(pix, cx), q);
+  }
   // C8 may exceed 256 only if C > 2048: not supported by the launchers
   if (py < PY) {
 #pragma unroll
@@ -66,11 +82,12 @@ static inline size_t red_lds(int NQ, int C) {
   return (size_t)py * NQ * C * sizeof(float);
 }
 
-template <typename T>
+#define RED_PIPE_MAX_ROWS 512
+template <typename T, bool PIPE>
 __global__ void __launch_bounds__(256) k_bn_stats(const T* __restrict__ x, long M, int C,
                                                   float* __restrict__ partial) {
-  slab_reduce<2>(M, C, partial, [&](long pix, int c8, float(&q)[2][8]) {
-    Vec8 v = load8<T>(x + pix * C + c8 * 8);
+  slab_reduce<2, PIPE>(M, C, partial, [&](long pix, int c8) { return load8<T>(x + pix * C + c8 * 8); },
+                 [&](const Vec8& v, float(&q)[2][8]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       q[0][j] += v.v[j];
@@ -86,8 +103,10 @@ extern "C" int msml_bn_stats(const void* x, long M, int C, float* partial, int d
              "bn_stats: bad shape M=%ld C=%d", M, C);
   int rows = red_rows(M, C);
   MSML_DISPATCH_DTYPE(dtype, "bn_stats",
-                      k_bn_stats<DT><<<rows, 256, red_lds(2, C), (hipStream_t)stream>>>(
-                          (const DT*)x, M, C, partial);)
+                      if (rows <= RED_PIPE_MAX_ROWS)
+                        (k_bn_stats<DT, true>)<<<rows, 256, red_lds(2, C), (hipStream_t)stream>>>((const DT*)x, M, C, partial);
+                      else
+                        (k_bn_stats<DT, false>)<<<rows, 256, red_lds(2, C), (hipStream_t)stream>>>((const DT*)x, M, C, partial);)
   MSML_LAUNCH_OK("bn_stats");
   return MSML_OK;
 }
@@ -335,7 +354,7 @@ extern "C" int msml_bn_act_fwd_stats(const void* x, const float* scale, const fl
 // With z = x*scale + shift, g = dy * prelu'(z), xhat = (x - mean) * invstd:
 //   reduce: s1 = sum g, s2 = sum g * xhat, s3 = sum dy * min(z, 0)   (d alpha)
 //   apply:  dx = gamma * invstd * (g - s1/n - xhat * s2/n)
-template <typename T>
+template <typename T, bool PIPE>
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy, const T* __restrict__ x,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
@@ -347,11 +366,17 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy,
   const int c0h = (threadIdx.x % (C / 8)) * 8;
   const Coef8 sc = ldc8(scale, c0h, 1.f), sh = ldc8(shift, c0h, 0.f), al = ldc8(alpha, c0h, 1.f);
   const Coef8 mu = ldc8(mean, c0h, 0.f), is = ldc8(invstd, c0h, 1.f);
-  slab_reduce<3>(M, C, partial, [&](long pix, int c8, float(&q)[3][8]) {
-    Vec8 g = load8<T>(dy + pix * C + c8 * 8);
-    Vec8 v = load8<T>(x + pix * C + c8 * 8);
-    Vec8 rr;
-    if (res) rr = load8<T>(res + pix * C + c8 * 8);
+  struct Px {
+    Vec8 g, v, rr;
+  };
+  slab_reduce<3, PIPE>(M, C, partial, [&](long pix, int c8) {
+    Px d;
+    d.g = load8<T>(dy + pix * C + c8 * 8);
+    d.v = load8<T>(x + pix * C + c8 * 8);
+    if (res) d.rr = load8<T>(res + pix * C + c8 * 8);
+    return d;
+  }, [&](const Px& d, float(&q)[3][8]) {
+    const Vec8 &g = d.g, &v = d.v, &rr = d.rr;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       float gg = g.v[j];
@@ -518,9 +543,14 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
   long n8 = M * (C / 8);
   MSML_DISPATCH_DTYPE(
       dtype, "bn_act_bwd",
-      k_bn_bwd_reduce<DT><<<rows, 256, red_lds(3, C), st>>>((const DT*)dy, (const DT*)x, scale, shift,
-                                                            alpha, save_mean, save_invstd,
-                                                            (const DT*)residual_first, M, C, partial);
+      if (rows <= RED_PIPE_MAX_ROWS)
+        (k_bn_bwd_reduce<DT, true>)<<<rows, 256, red_lds(3, C), st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
+                                                                      save_mean, save_invstd,
+                                                                      (const DT*)residual_first, M, C, partial);
+      else
+        (k_bn_bwd_reduce<DT, false>)<<<rows, 256, red_lds(3, C), st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
+                                                                       save_mean, save_invstd,
+                                                                       (const DT*)residual_first, M, C, partial);
       MSML_LAUNCH_OK("bn_bwd_reduce");
       k_bn_bwd_finalize<<<cdiv(C, FIN_CPB), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef, accumulate);
       MSML_LAUNCH_OK("bn_bwd_finalize");
@@ -668,7 +698,10 @@ extern "C" int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* 
   MSML_CHECK(ws_floats >= (long)rows * 2 * Cp, MSML_ERR_WORKSPACE, "bias_grad: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   MSML_DISPATCH_DTYPE(dtype, "bias_grad",
-                      k_bn_stats<DT><<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace);)
+                      if (rows <= RED_PIPE_MAX_ROWS)
+                        (k_bn_stats<DT, true>)<<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace);
+                      else
+                        (k_bn_stats<DT, false>)<<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace);)
   MSML_LAUNCH_OK("bias_grad");
   k_colsum_finalize<<<cdiv(Creal, 32), 1024, 0, st>>>(workspace, rows, Cp, 2, db, Creal, accumulate);
   MSML_LAUNCH_OK("bias_grad_finalize");
