@@ -3,8 +3,10 @@
 FMCnn.forward (:277-311): x = same_conv(cat(yf, yo)) -> res_block -> M = act(x);
 z = arith(yf, M) + yf.  The concat is never materialised (two-segment implicit GEMM) and the
 activation + arithmetic + skip are one fused kernel (msml_fm_fuse_fwd/bwd)."""
+import torch
 import torch.nn as nn
 
+from ... import blocks, ops
 from ... import functional as Fh
 from .._nn import conv, conv_bn
 
@@ -29,6 +31,9 @@ class resblock_bottle(nn.Module):
         self.prelu3 = nn.PReLU(out_channels)
 
     def forward(self, x):
+        if self.training and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and ops.BLOCK_FUNCTION \
+                and ops.BOTTLE_FUNCTION:
+            return blocks.bottleneck(self, x)      # one autograd node, fused backward (blocks.py)
         out = conv_bn(self.conv1, self.bn1, x, prelu=self.prelu1)
         out = conv_bn(self.conv2, self.bn2, out, prelu=self.prelu2)
         # prelu3(bn3(conv3(out)) + identity)

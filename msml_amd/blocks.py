@@ -42,8 +42,9 @@ def _bn_coef(x, stats, bnp):
     return coef
 
 
-def _bn_apply(x, coef, alpha, residual, emit_stats=False):
-    """y = PReLU(x * scale + shift) (+ residual) [, partial statistics of y]."""
+def _bn_apply(x, coef, alpha, residual, emit_stats=False, res_first=0):
+    """y = PReLU(x * scale + shift) (+ residual; res_first: PReLU after the sum) [, partial
+    statistics of y]."""
     c = x.shape[-1]
     m = x.numel() // c
     y = torch.empty_like(x)
@@ -53,7 +54,7 @@ def _bn_apply(x, coef, alpha, residual, emit_stats=False):
                                  device=x.device)
             call("msml_bn_act_fwd_stats", x, coef[0], coef[1], alpha, residual, 0, y, m, c, ystats, BF16)
             return y, ystats
-        call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, 0, y, m, c, BF16)
+        call("msml_bn_act_fwd", x, coef[0], coef[1], alpha, residual, res_first, y, m, c, BF16)
     return y
 
 
@@ -322,3 +323,77 @@ def iblock(blk, x):
         out._msml_stats = ostats           # read by the next block (same tensor object in nn.Sequential)
         out._msml_bn3 = last
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# resblock_bottle of the FM operators (backbones/fm/fmoperator.py:35-68 of the reference):
+# 1x1 -> bn1 -> prelu1 -> 3x3 -> bn2 -> prelu2 -> 1x1 -> bn3 -> (+x) -> prelu3, one autograd node.
+def _bottle_pack(blk):
+    return {
+        "bn1": _bn_pack(blk.bn1), "bn2": _bn_pack(blk.bn2), "bn3": _bn_pack(blk.bn3),
+        "c1": _conv_pack(blk.conv1), "c2": _conv_pack(blk.conv2), "c3": _conv_pack(blk.conv3),
+        "a1": blk.prelu1.weight, "a2": blk.prelu2.weight, "a3": blk.prelu3.weight,
+    }
+
+
+class _Bottle(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bp, *params):
+        c1, st1 = _conv_fwd(x, bp["c1"])
+        o1, k1 = _bn_fwd(c1, st1, bp["bn1"], bp["a1"], None)
+        c2, st2 = _conv_fwd(o1, bp["c2"])
+        o2, k2 = _bn_fwd(c2, st2, bp["bn2"], bp["a2"], None)
+        c3, st3 = _conv_fwd(o2, bp["c3"])
+        k3 = _bn_coef(c3, st3, bp["bn3"])
+        out = _bn_apply(c3, k3, bp["a3"], x, res_first=1)          # prelu3(bn3(c3) + x)
+        ctx.bp = bp
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, c1, o1, c2, o2, c3, k1, k2, k3)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, c1, o1, c2, o2, c3, k1, k2, k3 = ctx.saved_tensors
+        bp = ctx.bp
+        dev = x.device
+        dout = dout.contiguous()
+        n, h, w, _ = x.shape
+        bn1, bn2, bn3 = bp["bn1"], bp["bn2"], bp["bn3"]
+        # prelu3 / residual / bn3: dy is the block output gradient -> full reduce + apply; dres is the
+        # gradient of the identity path (dout through prelu3)
+        g3 = _ParamGrads((bn3[0], bn3[1], bp["a3"]), c3.shape[-1], dev)
+        c = c3.shape[-1]
+        m = c3.numel() // c
+        dc3, dres = torch.empty_like(c3), torch.empty_like(x)
+        rows = ops.bn_stats_rows(m, c)
+        ws = ops.workspace((rows * 3 * c + 2 * c) * 4, dev)
+        with ops.PROFILE.rec("bn_act_bwd", 0.0, c3.numel() * c3.element_size() * 7):
+            call("msml_bn_act_bwd", dout, c3, k3[0], k3[1], bp["a3"], k3[2], k3[3], x, dc3, dres,
+                 g3.tg[0], g3.tg[1], g3.tg[2], int(g3.inplace), m, c, ws, ws.numel() // 4, BF16)
+        g3.done()
+        dw3 = _wgrad(dc3, o2, bp["c3"])
+        do2, part2 = _dgrad(dc3, bp["c3"], h, w, c2, k2, bp["a2"])
+        g2 = _ParamGrads((bn2[0], bn2[1], bp["a2"]), c2.shape[-1], dev)
+        dc2 = _bn_bwd(do2, c2, k2, bp["a2"], g2, part2)
+        dw2 = _wgrad(dc2, o1, bp["c2"])
+        do1, part1 = _dgrad(dc2, bp["c2"], h, w, c1, k1, bp["a1"])
+        g1 = _ParamGrads((bn1[0], bn1[1], bp["a1"]), c1.shape[-1], dev)
+        dc1 = _bn_bwd(do1, c1, k1, bp["a1"], g1, part1)
+        dw1 = _wgrad(dc1, x, bp["c1"])
+        dx, _ = _dgrad(dc1, bp["c1"], h, w)
+        call("msml_add", dx, dres, dx, dx.numel(), BF16)
+        return (dx, None, dw1, dw2, dw3, g1.out(0), g1.out(1), g1.out(2), g2.out(0), g2.out(1), g2.out(2),
+                g3.out(0), g3.out(1), g3.out(2))
+
+
+def bottleneck(blk, x):
+    """Run an FM resblock_bottle `blk` (training mode, bf16 NHWC input) as one autograd node."""
+    bp = blk.__dict__.get("_msml_pack")
+    if bp is None or bp["bn1"][2] is not blk.bn1._buffers["running_mean"]:
+        bp = _bottle_pack(blk)
+        bp["params"] = (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight,
+                        blk.bn1.weight, blk.bn1.bias, blk.prelu1.weight,
+                        blk.bn2.weight, blk.bn2.bias, blk.prelu2.weight,
+                        blk.bn3.weight, blk.bn3.bias, blk.prelu3.weight)
+        blk.__dict__["_msml_pack"] = bp
+    return _Bottle.apply(x, bp, *bp["params"])

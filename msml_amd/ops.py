@@ -307,6 +307,7 @@ OSB_STREAM = None
 # Block-level autograd function for IBasicBlock (blocks.py) and, inside it, the BatchNorm
 # backward-reduce fused into the backward-data conv epilogue.  Switches exist for A/B tests.
 BLOCK_FUNCTION = os.environ.get("MSML_NO_BLOCK_FUNCTION") is None
+BOTTLE_FUNCTION = os.environ.get("MSML_NO_BOTTLE_FUNCTION") is None       # FM resblock_bottle as one node
 FUSE_BN_BWD = os.environ.get("MSML_NO_FUSE_BN_BWD") is None
 # 1x1 / stride-2 downsample backward kept compact and scatter-added by bn1's apply kernel
 SPARSE_DOWNSAMPLE_GRAD = os.environ.get("MSML_NO_SPARSE_DOWNSAMPLE_GRAD") is None

@@ -535,6 +535,54 @@ def test_block_compact_downsample_gradient(cfg):
         assert torch.equal(g1[k], g2[k]), k
 
 
+@pytest.mark.parametrize("cfg", [(6, 64, 28), (4, 128, 14), (3, 256, 14), (5, 512, 7)])
+def test_fm_bottleneck_function_matches_op_graph(cfg):
+    """FM resblock_bottle as ONE autograd node (blocks.bottleneck: BatchNorm backward sums of bn1 / bn2
+    from the dgrad epilogues) against the op-by-op graph: same forward bits and running statistics,
+    gradients equal up to the order of the f32 partial sums."""
+    import copy
+    from torch import nn
+    from msml_amd import ops
+    from msml_amd.backbones.fm.fmoperator import resblock_bottle
+    n, ch, h = cfg
+    torch.manual_seed(sum(cfg))
+    blk = resblock_bottle(ch, ch)
+    for p in blk.parameters():
+        if p.dim() == 1:
+            nn.init.uniform_(p, 0.5, 1.5)
+        else:
+            nn.init.normal_(p, 0, (1.0 / (p.shape[1] * p.shape[2] * p.shape[3])) ** 0.5)
+    for pr in (blk.prelu1, blk.prelu2, blk.prelu3):
+        nn.init.uniform_(pr.weight, 0.1, 0.4)
+    blk = blk.cuda().train()
+    x0 = ops.to_nhwc(torch.randn(n, ch, h, h).cuda(), 1)
+    dout = None
+    res = []
+    for use_fn in (False, True):
+        b = copy.deepcopy(blk)
+        x = x0.clone().requires_grad_(True)
+        old = ops.BLOCK_FUNCTION
+        ops.BLOCK_FUNCTION = use_fn
+        try:
+            y = b(x)
+            if dout is None:
+                dout = torch.randn_like(y)
+            y.backward(dout)
+        finally:
+            ops.BLOCK_FUNCTION = old
+        torch.cuda.synchronize()
+        res.append((y.detach().float(), x.grad.float(), {k: v.grad.float() for k, v in b.named_parameters()},
+                    {k: v.clone() for k, v in b.named_buffers()}))
+    (y1, dx1, g1, buf1), (y2, dx2, g2, buf2) = res
+    assert torch.equal(y1, y2)
+    for k in buf1:
+        assert torch.equal(buf1[k], buf2[k]), k
+    assert (dx1 - dx2).abs().max().item() <= 2e-2 * dx1.abs().max().item()
+    assert rel_err(dx2.cpu().numpy(), dx1.cpu().numpy()) < 5e-3
+    for k in g1:
+        assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-2, k
+
+
 @pytest.mark.parametrize("stride", [1, 2])
 def test_stem_im2col_path_matches_nhwc_conv(stride):
     """bf16 stems: im2col of the raw image + 1x1 conv (functional.RawImage) == the 3x3 conv on the
