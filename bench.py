@@ -315,7 +315,10 @@ def main():
         step_events.append(ev)
         return r
 
-    throttled_step()
+    # settle the caching allocator in the steady two-steps-in-flight pattern before timing (the probe
+    # graph's pool has just gone back to the driver: the next steps re-grow the eager pool)
+    for _ in range(3):
+        throttled_step()
     barrier()
     inflight.clear()
     import gc
