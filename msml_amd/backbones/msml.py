@@ -88,7 +88,6 @@ class MSML(nn.Module):
         from .. import ops
         ops.PACKS.refresh_if_stale()      # one batched repack after a FlatSGD step
         ops.DEFER_BN_COUNTERS = True      # num_batches_tracked: one foreach add per forward
-        ops.BN3_PARTIALS.clear()
         try:
             return self._forward(x, label, ori)
         finally:

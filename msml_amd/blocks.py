@@ -258,7 +258,12 @@ class _IBlock(torch.autograd.Function):
         # bn3 (its dy is the block output gradient, which also flows to the identity path)
         g3 = _ParamGrads((bn3[0], bn3[1], None), c2.shape[-1], dev)
         # (its sums may already have been reduced by the next block's bn1 kernel, which wrote dout)
-        part3 = ops.BN3_PARTIALS.pop(dout.data_ptr(), None) if bp["emit_stats"] else None
+        # (attached to the gradient TENSOR OBJECT by that kernel's caller: a gradient that autograd
+        # re-materialised -- summed with another consumer's, copied by a hook -- does not carry the
+        # attribute and takes the unfused reduce below, whatever address it landed on)
+        part3 = dout.__dict__.pop("_msml_bn3_partial", None) if bp["emit_stats"] else None
+        if part3 is not None:
+            ops.COUNTERS["bn3_partial_hits"] += 1
         dc2 = _bn_bwd(dout, c2, k3, None, g3, part3)
         # conv2: dW beside, dX with bn2's backward sums from the epilogue
         dw2 = _wgrad(dc2, o2, bp["c2"]) if o2 is not None else _wgrad(dc2, c1, bp["c2"], (k2, alpha))
@@ -291,7 +296,7 @@ class _IBlock(torch.autograd.Function):
             # x is the previous block's output: reduce its bn3 sums while writing its output gradient
             dx, pprev = _bn_bwd(do1, x, k1, None, g1, part1, add=join, nxt=(pc2, pk3), add_s2=join_s2)
             if pprev is not None:
-                ops.BN3_PARTIALS[dx.data_ptr()] = pprev
+                dx._msml_bn3_partial = pprev
         else:
             dx = _bn_bwd(do1, x, k1, None, g1, part1, add=join, add_s2=join_s2)
         grads = [dw1, dw2] + ([dwd] if ds is not None else [])

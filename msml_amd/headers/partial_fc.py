@@ -3,16 +3,27 @@
 Mirrors headers/partial_fc.py of the reference: same constructor, attributes (weight,
 weight_mom, sub_weight, sub_weight_mom, index, stream), `forward_backward(label, features,
 optimizer) -> (x_grad, loss_v)`, `update()`, `save_params()`, `parameters()`, checkpoint file
-names (`rank:{r}_softmax_weight[_mom].pt`).  Differences, all forced by the reference itself:
+names (`rank:{r}_softmax_weight[_mom].pt`), negative sampling (`sample_rate < 1`, :82-94,101-104).
+Differences, all forced by the reference itself:
 
 * `margin_softmax` (no such callable exists in the reference) is a margin
   DESCRIPTOR -- `ArcMargin(s, m, a, k)` / `CosMargin(...)` below -- because the margin is fused
   into the softmax kernels (the logits are never materialised); its math restates
   AMArcFace.forward / AMCosFace.forward (margin_losses.py:390-418 / :277-303).
-* the three tiny all-reduces (row max, denominator, target prob; partial_fc.py:136,141,162)
-  become: one online (max, sumexp) local pass -> all_reduce(MAX) -> rescale -> all_reduce(SUM),
-  and the loss all-reduce; two passes over the local logits instead of three.
-* sample_rate < 1 (negative sampling, partial_fc.py:82-94) is not built.
+* collectives (partial_fc.py:106-177 has five on the critical path: labels, features, row max,
+  denominator, target prob, then the reduce-scatter):
+    - labels are gathered on the side stream `self.stream` like the reference (:107-110) -- they
+      are known before the backbone forward, `prefetch_labels()` lets a caller start it there;
+    - features: one `all_gather_into_tensor`;
+    - (row max, row sum-exp) of the local online-softmax pass travel in ONE all-gather of [N, 2]
+      pairs and are combined locally (gmax = max_r, gsum = sum_r s_r exp(m_r - gmax)) -- one
+      collective instead of the dependent MAX + SUM all-reduces (:136,141);
+    - dX: `reduce_scatter_tensor`, issued BEFORE the target-probability all-reduce (:162), which
+      only feeds the logged loss.
+  xGMI is a point-to-point mesh: these are latency-bound 8 KB - 4 MB messages, so what matters is
+  their count in front of the backbone backward (3: features, pairs, dX) and that the OSB backward,
+  which does not depend on the head, is already running meanwhile (bench.py / INTEGRATION.md issue
+  it first when world_size > 1).
 
 The distributed logic lives here; the local arithmetic is behind `self.backend`, which is the
 HIP library in the product (the only backend msml_amd ships) -- tests inject a CPU oracle
@@ -82,8 +93,10 @@ class HipBackend:
         state = (xs, wn, inv_w, cosm, kind)
         return state, rowmax, rowsum
 
-    def local_grads(self, state, sub_weight, labels, margin, gmax, gsum, n_total, eps_ls):
-        """grad = (p - y_smooth)/N through the margin; returns (ptarget, dX (N,E), dW (C,E))."""
+    def local_grads(self, state, sub_weight, labels, margin, gmax, gsum, n_total, eps_ls, dw_out=None):
+        """grad = (p - y_smooth)/N through the margin; returns (ptarget, dX (N,E), dW (C,E)).
+        dw_out: write dW there (the parameter's .grad view of a flat gradient arena) instead of a
+        fresh tensor."""
         ops, call = self.ops, self.call
         xs, wn, inv_w, cosm, kind = state
         n, cp = cosm.shape
@@ -102,7 +115,7 @@ class HipBackend:
             dx, _ = ops.conv2d(dcos, None, wnt, None, e, 1, 1, 1, 0, 0, False, out_dtype=0)
         dwn = torch.empty(c, e, dtype=torch.float32, device=dev)
         ops.conv_wgrad(dcos, xs, dwn, c, e, e, 0, 1, 1, 1, 0, 0)
-        dw = torch.empty(c, e, dtype=torch.float32, device=dev)
+        dw = dw_out if dw_out is not None else torch.empty(c, e, dtype=torch.float32, device=dev)
         call("msml_rownorm_bwd", sub_weight.detach(), inv_w, dwn, e, c, e, dw, 0)
         return ptarget, dx.reshape(n, e), dw
 
@@ -113,8 +126,6 @@ class PartialFC(Module):
                  sample_rate=1.0, embedding_size=512, prefix="./", fp16=False, backend=None,
                  device=None):
         super().__init__()
-        if int(sample_rate) != 1:
-            raise NotImplementedError("msml_amd: PartialFC negative sampling (sample_rate<1) is not built")
         if not isinstance(margin_softmax, _Margin):
             raise TypeError("margin_softmax must be msml_amd.headers.ArcMargin / CosMargin "
                             "(the margin is fused into the HIP softmax kernels)")
@@ -146,42 +157,139 @@ class PartialFC(Module):
             self.weight_mom = torch.zeros_like(self.weight)
         self.stream = torch.cuda.Stream(local_rank) if self.device.type == "cuda" else None
         self.index = None
-        self.update = lambda: 0
-        self.sub_weight = Parameter(self.weight)
-        self.sub_weight_mom = self.weight_mom
+        self.full = int(self.sample_rate) == 1
+        if self.full:
+            self.sub_weight = Parameter(self.weight)
+            self.sub_weight_mom = self.weight_mom
+        else:
+            self.sub_weight = Parameter(torch.empty((0, 0), device=self.device))
+            self.sub_weight_mom = None
         if backend is None:
             from .._lib import BF16, F32
             backend = HipBackend(BF16 if fp16 else F32)
         self.backend = backend
         self.eps_ls = 0.1
+        self._flat = None             # FlatSGD that re-homed sub_weight (adopt_flat_optimizer)
+        self._label_job = None        # (id, total_label, event, label) of a prefetched label gather
+        self.perm_fn = None           # tests: replaces torch.rand in sample()
 
+    # ---- checkpoint ----------------------------------------------------------------------------
     def save_params(self):
-        torch.save(self.weight.data, self.weight_name)
-        torch.save(self.weight_mom, self.weight_mom_name)
+        """rank:{r}_softmax_weight.pt / _mom.pt as plain tensors (partial_fc.py:73-75).  Saved from
+        the LIVE tensors: with a flat-arena optimizer the parameter and its momentum are views into
+        the arenas (clone: torch.save would otherwise serialise the whole arena storage)."""
+        if not self.full and self.index is not None:
+            self.update()
+        w = self.sub_weight.data if self.full else self.weight
+        mom = self.sub_weight_mom if self.full else self.weight_mom
+        torch.save(w.detach().clone(), self.weight_name)
+        torch.save(mom.detach().clone(), self.weight_mom_name)
 
+    def adopt_flat_optimizer(self, opt):
+        """After `opt = FlatSGD([{'params': [pfc.sub_weight], ...}])` re-homed the parameter: point
+        weight / weight_mom / sub_weight_mom at the arena views and seed the arena momentum from
+        the (possibly resumed) momentum, so that save_params() and resume see the trained state."""
+        if not self.full:
+            raise NotImplementedError("flat-arena optimizer with negative sampling: use torch.optim.SGD")
+        mview = opt.momentum_view(self.sub_weight)
+        mview.copy_(self.weight_mom)
+        if self.weight_mom.abs().sum().item() != 0:
+            opt.steps = max(opt.steps, 1)          # a resumed buffer is not the first step
+        self.weight = self.sub_weight.data
+        self.weight_mom = self.sub_weight_mom = mview
+        self._flat = opt
+
+    # ---- label mapping / negative sampling ------------------------------------------------------
     @torch.no_grad()
     def sample(self, total_label):
-        # in place like the reference (partial_fc.py:78-81) but without boolean-mask indexing,
-        # which would synchronise with the host (and cannot be captured into a hipGraph)
+        """partial_fc.py:77-94.  In place like the reference but without boolean-mask indexing or
+        torch.unique, which synchronise with the host (and cannot be captured into a hipGraph)."""
         index_positive = (self.class_start <= total_label) & (total_label < self.class_start + self.num_local)
-        total_label.copy_(torch.where(index_positive, total_label - self.class_start,
-                                      torch.full_like(total_label, -1)))
+        local = torch.where(index_positive, total_label - self.class_start, torch.full_like(total_label, -1))
+        if self.full:
+            total_label.copy_(local)
+            return
+        n = total_label.numel()
+        if self.num_sample >= min(n, self.num_local):
+            # every positive class is kept and the rest of the budget is filled with random
+            # negatives: rand -> positives forced to 2.0 -> top-k -> sorted (:84-88).  The scatter of
+            # duplicates replaces torch.unique; the result is the same index set.
+            perm = (self.perm_fn or torch.rand)(self.num_local, device=self.device)
+            hit = torch.zeros(self.num_local + 1, dtype=torch.bool, device=self.device)
+            hit[torch.where(index_positive, local, torch.full_like(local, self.num_local))] = True
+            perm = torch.where(hit[:self.num_local], torch.full_like(perm, 2.0), perm)
+            index = torch.topk(perm, k=self.num_sample)[1].sort()[0]
+        else:
+            # fewer samples than labels in the batch can mean fewer than positives: the reference
+            # then keeps exactly the positives (:89-90) -- data-dependent size, host sync
+            positive = torch.unique(local[index_positive], sorted=True)
+            if self.num_sample - positive.size(0) >= 0:
+                perm = (self.perm_fn or torch.rand)(self.num_local, device=self.device)
+                perm[positive] = 2.0
+                index = torch.topk(perm, k=self.num_sample)[1].sort()[0]
+            else:
+                index = positive
+        self.index = index
+        mapped = torch.searchsorted(index, local.clamp_min(0))
+        total_label.copy_(torch.where(index_positive, mapped, torch.full_like(total_label, -1)))
+        self.sub_weight = Parameter(self.weight[index])
+        self.sub_weight_mom = self.weight_mom[index]
+
+    @torch.no_grad()
+    def update(self):
+        """Write the sampled rows back (partial_fc.py:101-104); nothing to do at sample_rate 1."""
+        if self.full or self.index is None:
+            return 0
+        self.weight_mom[self.index] = self.sub_weight_mom
+        self.weight[self.index] = self.sub_weight.data
+        return 0
+
+    # ---- collectives ---------------------------------------------------------------------------
+    def _dist(self):
+        return self.world_size > 1 or _FORCE
 
     def _all_gather(self, x):
-        if self.world_size == 1 and not _FORCE:
+        if not self._dist():
             return x.clone()
-        out = torch.zeros((self.batch_size * self.world_size,) + tuple(x.shape[1:]), dtype=x.dtype,
-                          device=x.device)
-        dist.all_gather(list(out.chunk(self.world_size, dim=0)), x.contiguous())
+        out = torch.empty((x.shape[0] * self.world_size,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous())
         return out
 
+    def prefetch_labels(self, label):
+        """Start the label all-gather + local mapping on the side stream (partial_fc.py:107-110); call it
+        before the backbone forward -- prepare() picks the result up."""
+        label = label.to(self.device, torch.long)
+        if self.stream is None or not self._dist():
+            total = self._all_gather(label)
+            self.sample(total)
+            self._label_job = (id(label), total, None, label)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            total = self._all_gather(label)
+            self.sample(total)
+            ev = self.stream.record_event()
+        label.record_stream(self.stream)
+        self._label_job = (id(label), total, ev, label)
+
     def prepare(self, label, optimizer):
-        total_label = self._all_gather(label.to(self.device, torch.long))
-        self.sample(total_label)
+        job, self._label_job = self._label_job, None
+        if job is None or job[3].data_ptr() != label.data_ptr():
+            self.prefetch_labels(label)
+            job, self._label_job = self._label_job, None
+        _, total_label, ev, _ = job
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)       # partial_fc.py:97
+            total_label.record_stream(torch.cuda.current_stream())
         if optimizer is not None:
-            optimizer.state.pop(optimizer.param_groups[-1]["params"][0], None)
-            optimizer.param_groups[-1]["params"][0] = self.sub_weight
-            optimizer.state[self.sub_weight]["momentum_buffer"] = self.sub_weight_mom
+            from ..optim import FlatSGD
+            if isinstance(optimizer, FlatSGD):
+                if self._flat is not optimizer:
+                    self.adopt_flat_optimizer(optimizer)
+            else:
+                optimizer.state.pop(optimizer.param_groups[-1]["params"][0], None)
+                optimizer.param_groups[-1]["params"][0] = self.sub_weight
+                optimizer.state[self.sub_weight]["momentum_buffer"] = self.sub_weight_mom
         return total_label
 
     @torch.no_grad()
@@ -191,24 +299,31 @@ class PartialFC(Module):
         n_total = self.batch_size * self.world_size
         state, rowmax, rowsum = self.backend.local_stats(total_features, self.sub_weight, total_label,
                                                          self.margin_softmax)
-        if self.world_size > 1 or _FORCE:
-            gmax = rowmax.clone()
-            dist.all_reduce(gmax, dist.ReduceOp.MAX)
-            gsum = rowsum * torch.exp(rowmax - gmax)
-            dist.all_reduce(gsum, dist.ReduceOp.SUM)
+        if self._dist():
+            # ONE collective for the softmax denominator: gather every rank's (max, sum-exp) pair and
+            # combine locally (same value on every rank, fixed summation order r = 0..W-1)
+            pair = torch.stack((rowmax, rowsum), 1)                          # [N, 2]
+            allp = self._all_gather(pair).view(self.world_size, -1, 2)       # [W, N, 2]
+            gmax = allp[:, :, 0].max(0)[0]
+            gsum = (allp[:, :, 1] * torch.exp(allp[:, :, 0] - gmax)).sum(0)
         else:
             gmax, gsum = rowmax, rowsum
+        g = self.sub_weight.grad
+        dw_out = g if (self._flat is not None and g is not None and g.shape == self.sub_weight.shape
+                       and g.is_contiguous()) else None       # straight into the flat gradient arena
         ptarget, dx_total, dw = self.backend.local_grads(state, self.sub_weight, total_label,
                                                         self.margin_softmax, gmax, gsum, n_total,
-                                                        self.eps_ls)
-        if self.world_size > 1 or _FORCE:
-            dist.all_reduce(ptarget, dist.ReduceOp.SUM)
-        loss_v = ptarget.clamp_min(1e-30).log().mean() * (-1)
-        self.sub_weight.grad = dw
-        if self.world_size > 1 or _FORCE:
-            x_grad = torch.zeros_like(features, dtype=torch.float32)
-            dist.reduce_scatter(x_grad, list(dx_total.contiguous().chunk(self.world_size, dim=0)))
+                                                        self.eps_ls, dw_out=dw_out)
+        if dw_out is None:
+            self.sub_weight.grad = dw
+        if self._dist():
+            # the critical collective first: dX feeds the backbone backward
+            x_grad = torch.empty_like(features, dtype=torch.float32)
+            dist.reduce_scatter_tensor(x_grad, dx_total.contiguous())
             x_grad = x_grad * self.world_size
+            # loss: the target probability lives on exactly one rank per row -> SUM (8 KB, logged only)
+            dist.all_reduce(ptarget, dist.ReduceOp.SUM)
         else:
             x_grad = dx_total
+        loss_v = ptarget.clamp_min(1e-30).log().mean() * (-1)
         return x_grad, loss_v

@@ -59,6 +59,11 @@ class FlatSGD:
         self.norm_coef = torch.ones(2, dtype=torch.float32, device=dev)
         self.ws = torch.empty(1024, dtype=torch.float32, device=dev)
 
+    def momentum_view(self, p):
+        """The momentum buffer of parameter `p` as a view into the flat momentum arena."""
+        off = self.offsets[id(p)]
+        return self.flat_m[off:off + p.numel()].view_as(p.data)
+
     def set_lr_factor(self, factor):
         for g in self.groups:
             g["lr"] = g["base_lr"] * factor
@@ -67,6 +72,7 @@ class FlatSGD:
         from . import ops
         if ops.WGRAD_STREAM is not None:     # the side stream must see the zeroed arena
             ops.WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
+        self.train_stream = torch.cuda.current_stream()   # the stream backward kernels are issued on
         self.flat_g.zero_()
         base = self.flat_g.data_ptr()
         for p in self.params:        # re-attach the views if something replaced .grad
@@ -101,16 +107,21 @@ class FlatSGD:
         self.pending = [b[2] for b in self.buckets]
         self.fired = [False] * len(self.buckets)
         self.works = []
+        self.train_stream = torch.cuda.current_stream()     # refreshed by zero_grad()
         ops.GRAD_READY = self._grad_ready
 
     def _fire(self, bi):
         from . import ops
         self.fired[bi] = True
         s, e, _ = self.buckets[bi]
+        # A bucket may be fired from an autograd node that runs on a side stream (the OSB nodes run
+        # last, on the OSB stream): current_stream() is then NOT the stream the FRB's in-place
+        # gradient kernels were enqueued on.  Always wait for the training stream remembered by
+        # zero_grad(), the current stream and both side streams.
         cur = torch.cuda.current_stream()
         self.comm.wait_stream(cur)
-        for st in (ops.WGRAD_STREAM, ops.OSB_STREAM):
-            if st is not None:
+        for st in (getattr(self, "train_stream", None), ops.WGRAD_STREAM, ops.OSB_STREAM):
+            if st is not None and st != cur:
                 self.comm.wait_stream(st)
         with torch.cuda.stream(self.comm):
             self.works.append(dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True))

@@ -11,6 +11,7 @@ Goldens:
   g4  one full train step ires18 bs=4 (train-mode BN, reference conv init AND key fill)
   g5  AMArcFace / AMCosFace / Softmax heads incl. -1 labels
   g6  PartialFC.forward_backward under gloo, W in {1,2,4,8}, B=8, C=1003 + one SGD step
+  g6s the same with negative sampling (sample_rate 0.3 / 0.005): index, step, update()
   g7  StructureConsensuLossFunction values + input gradient
   g8  lr schedule table and param-group lr map
   fm  FMCnn x 4 stages x {sigmoid,tanh} x {add,sub,mul,div} checksums + slices
@@ -277,6 +278,81 @@ def _pfc_worker(rank, world, port, outdir):
                         wnew_pick=pick(p.sub_weight.data, 256),
                         mom_cs=checksum(p.sub_weight_mom))
     dist.destroy_process_group()
+
+
+def _pfc_sample_worker(rank, world, port, outdir, rate):
+    """PartialFC with negative sampling (partial_fc.py:82-94,101-104): sample(), the step on the
+    sampled rows and update() writing them back."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from headers.partial_fc import PartialFC
+    import headers
+
+    class _S:
+        def wait_stream(self, s):
+            pass
+    torch.cuda.current_stream = lambda *a, **k: _S()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    _rs = dist.reduce_scatter
+
+    def rs(out, inp, *a, **k):
+        with torch.no_grad():
+            return _rs(out, inp, *a, **k)
+    dist.reduce_scatter = rs
+    feat, label, w = pfc_inputs(world, rank)
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        arc = headers.AMArcFace(PFC_E, 8, None, 64.0, 0.48, 0.0, 0.0)
+    import headers.margin_losses as ml
+
+    class _PassThroughF:
+        normalize = staticmethod(lambda t: t)
+        linear = staticmethod(lambda t, w: t)
+    ml.F = _PassThroughF
+    p = PartialFC.__new__(PartialFC)
+    torch.nn.Module.__init__(p)
+    p.num_classes, p.rank, p.local_rank = PFC_C, rank, rank
+    p.device = torch.device("cpu")
+    p.world_size, p.batch_size = world, PFC_B
+    p.margin_softmax = lambda logits, lab: arc(logits, lab)
+    p.sample_rate, p.embedding_size, p.prefix = rate, PFC_E, "./"
+    p.num_local = PFC_C // world + int(rank < PFC_C % world)
+    p.class_start = PFC_C // world * rank + min(rank, PFC_C % world)
+    p.num_sample = int(rate * p.num_local)
+    p.weight = w.clone()
+    gm = torch.Generator().manual_seed(9000 + rank)
+    p.weight_mom = torch.randn(p.weight.shape, generator=gm) * 1e-3     # a momentum that has history
+    p.stream, p.index = None, None
+    p.sub_weight = torch.nn.Parameter(torch.empty((0, 0)))
+    opt = torch.optim.SGD([{"params": p.parameters()}], lr=0.1 / 512 * PFC_B * world,
+                          momentum=0.9, weight_decay=5e-4)
+    torch.manual_seed(4321 + rank)                 # the draw of sample(): torch.rand(size=[num_local])
+    x_grad, loss_v = p.forward_backward(label, feat, opt)
+    wgrad = p.sub_weight.grad.clone()
+    opt.step()
+    p.update()
+    np.savez_compressed(os.path.join(outdir, "r%d.npz" % rank), loss=np.float64(loss_v.item()),
+                        index=p.index.numpy(), x_grad=x_grad.detach().numpy(), wgrad_cs=checksum(wgrad),
+                        wgrad_pick=pick(wgrad, 256), wnew_cs=checksum(p.weight),
+                        wnew_pick=pick(p.weight, 512), mom_cs=checksum(p.weight_mom),
+                        mom_pick=pick(p.weight_mom, 512))
+    dist.destroy_process_group()
+
+
+def g6s():
+    import tempfile
+    import torch.multiprocessing as mp
+    rec = {}
+    for world, rate in ((1, 0.3), (2, 0.3), (2, 0.005)):    # last: fewer samples than positives
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_pfc_sample_worker, args=(world, 29450 + world, d, rate), nprocs=world, join=True)
+            for r in range(world):
+                z = np.load(os.path.join(d, "r%d.npz" % r))
+                for k in z.files:
+                    rec["w%d_rate%g/r%d/%s" % (world, rate, r, k)] = z[k]
+    np.savez_compressed(os.path.join(OUT, "g6s_partial_fc_sampled.npz"), **rec)
 
 
 def g6():

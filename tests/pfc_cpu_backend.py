@@ -18,7 +18,7 @@ class OracleBackend:
             rowsum = torch.exp(logits - rowmax[:, None]).sum(1)
         return (total_features,), rowmax, rowsum
 
-    def local_grads(self, state, sub_weight, labels, margin, gmax, gsum, n_total, eps_ls):
+    def local_grads(self, state, sub_weight, labels, margin, gmax, gsum, n_total, eps_ls, dw_out=None):
         (total_features,) = state
         with torch.enable_grad():
             x = total_features.detach().clone().requires_grad_(True)
@@ -38,4 +38,7 @@ class OracleBackend:
                 g[idx] -= y
                 g /= n_total
             logits.backward(g)
+        if dw_out is not None:
+            dw_out.copy_(w.grad)
+            return ptarget, x.grad.detach(), dw_out
         return ptarget, x.grad.detach(), w.grad.detach()
