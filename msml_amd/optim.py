@@ -30,6 +30,27 @@ def reference_param_groups(model, batch_size, world_size, lr=0.1):
     return [{"params": ps, "lr": glr} for ps, glr in groups.values() if ps]
 
 
+def lr_factor_ms1m(epoch):
+    """LambdaLR factor of the reference's ms1m recipe (config.py:35-39): 0.1 ** #{m in (11, 17, 22):
+    m - 1 <= epoch}, warm-up disabled (warmup_epoch = -1)."""
+    return 0.1 ** sum(1 for m in (11, 17, 22) if m - 1 <= epoch)
+
+
+class LambdaLR:
+    """torch.optim.lr_scheduler.LambdaLR for FlatSGD (train.py:193-196): step() once per epoch."""
+
+    def __init__(self, optimizer, lr_lambda, last_epoch=-1):
+        self.optimizer, self.lr_lambda, self.last_epoch = optimizer, lr_lambda, last_epoch
+        self.step()
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.set_lr_factor(self.lr_lambda(self.last_epoch))
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.groups]
+
+
 class FlatSGD:
     def __init__(self, param_groups, momentum=0.9, weight_decay=5e-4, max_norm=5.0):
         self.momentum, self.weight_decay, self.max_norm = momentum, weight_decay, max_norm

@@ -1,0 +1,307 @@
+"""Round-2 parity tests of the TIMED path and of the API corners the unchanged callers use.
+
+* the bf16 fused training step (blocks.py one-node residual blocks, BatchNorm backward sums from the
+  backward-data epilogues, side streams, FlatSGD) against the REFERENCE golden G4 -- not against the
+  repo's own op graph -- at a stated bf16 tolerance;
+* fm_layers containing 0 (FMNone), reference LR groups, PartialFC checkpoint round trip on the HIP
+  backend, negative sampling on the HIP backend, and one step under DistributedDataParallel +
+  torch.optim.SGD + GradScaler exactly as train.py:133-138,252-277 drives the model.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from msml_amd import functional as Fh
+from msml_amd import synthetic
+from msml_amd.backbones import MSML
+from msml_amd.tricks.consensus_loss import StructureConsensuLossFunction
+from oracle import model as om
+from oracle.fill import fill_module
+from oracle.inputs import eval_inputs, refinit_frb_convs
+from tests.helpers import assert_cs, load, pick, rel_err
+
+pytestmark = pytest.mark.gpu
+PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
+
+# bf16 operands (8-bit mantissa) through ~30 conv + BatchNorm layers at batch 4: relative error of the
+# picked gradients against the f32 reference.  Stated tolerances of the bf16 training step:
+BF16_LOSS_TOL = 2e-2          # seg / cls loss
+BF16_GNORM_TOL = 5e-2         # global gradient norm
+BF16_GRAD_TOL = 1.5e-1        # norm-wise error of each picked gradient
+BF16_STAT_TOL = 2e-2          # updated running statistics
+
+
+def hip_msml(frb, C=1000, fp16=False, fm_layers=(1, 1, 1, 1)):
+    torch.manual_seed(0)
+    m = MSML(frb, "unet", fm_layers, C, fp16=fp16, fm_params=(3, 2, "sigmoid", "mul"),
+             header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(PEER_OFF))
+    return fill_module(m).cuda()
+
+
+@pytest.mark.parametrize("variant", ["fill", "refinit"])
+def test_train_step_g4_bf16_fused_path(variant):
+    """The step bench.py times -- bf16, BLOCK_FUNCTION / FUSE_BN_BWD on, weight gradients and the OSB on
+    side streams, in-place gradients into FlatSGD's arena, fused clip + SGD -- against the reference's
+    one-train-step golden (losses, grad norm, 18 picked gradients, running statistics, new weights)."""
+    from msml_amd import ops
+    from msml_amd.optim import FlatSGD
+    g = load("g4_train_%s.npz" % variant)
+    assert ops.BLOCK_FUNCTION and ops.FUSE_BN_BWD and ops.BOTTLE_FUNCTION
+    m = hip_msml("iresnet18", 1000, fp16=True)
+    if variant == "refinit":
+        refinit_frb_convs(m)
+    bs = 4
+    x, msk = eval_inputs(bs)
+    label = synthetic.labels(bs, 1000, seed=1)
+    m.train()
+    # the golden's optimizer: one SGD group over all parameters, lr 0.1/512*bs (oracle/make_golden.py)
+    opt = FlatSGD([{"params": [p for p in m.parameters() if p.requires_grad], "lr": 0.1 / 512 * bs}],
+                  0.9, 5e-4, 5.0)
+    ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
+    hits0 = ops.COUNTERS["bn3_partial_hits"]
+    try:
+        opt.zero_grad()
+        final_cls, final_seg, kd = m(x.cuda(), label.cuda(), None)
+        seg_loss = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")(final_seg, msk.cuda(), msk.cuda())
+        cls_loss = torch.nn.functional.cross_entropy(final_cls, label.cuda())
+        (cls_loss + seg_loss).backward()
+        ops.wgrad_stream_join()
+        grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        opt.step()
+        torch.cuda.synchronize()
+    finally:
+        ops.WGRAD_STREAM = ops.OSB_STREAM = None
+        ops.INPLACE_GRADS = False
+    # the chained blocks really handed their bn3 sums over (ires18: one hand-off per stage, FRB + OSB)
+    assert ops.COUNTERS["bn3_partial_hits"] - hits0 >= 6
+    assert abs(seg_loss.item() - g["seg_loss"]) < BF16_LOSS_TOL * abs(g["seg_loss"])
+    assert abs(cls_loss.item() - g["cls_loss"]) < BF16_LOSS_TOL * abs(g["cls_loss"])
+    gnorm = float(opt.grad_norm())
+    assert abs(gnorm - g["grad_norm"]) < BF16_GNORM_TOL * abs(g["grad_norm"]), (gnorm, g["grad_norm"])
+    worst, report = 0.0, []
+    for key in g.files:
+        if key.startswith("grad_pick/"):
+            n = key.split("/", 1)[1]
+            got = pick(grads[n], 32)
+            if n == "frb.fc.bias":      # exact gradient is 0 (train-mode BatchNorm1d follows): noise only
+                continue
+            e = rel_err(got, g[key])
+            report.append((e, n))
+            worst = max(worst, e)
+    report.sort(reverse=True)
+    print("bf16 fused train step (%s): gnorm %.4f vs %.4f; worst picked-grad errors: %s"
+          % (variant, gnorm, g["grad_norm"], ", ".join("%s %.2e" % (n, e) for e, n in report[:5])))
+    assert worst < BF16_GRAD_TOL, report[:5]
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("stat/"):
+            n = key.split("/", 1)[1]
+            assert rel_err(sd[n].cpu().numpy(), g[key]) < BF16_STAT_TOL, n
+        if key.startswith("new_cs/"):
+            assert_cs(sd[key.split("/", 1)[1]], g[key], 1e-2, key)
+
+
+def test_eval_stage_error_growth():
+    """Per-stage error against the reference's layer*/fm* goldens in the three precision modes
+    (printed; DESIGN.md section 4 quotes it)."""
+    if not hasattr(Fh, "to_nchw_any"):
+        pytest.skip("bf16x3 mode not built")
+    g = load("g1_ires18_eval.npz")
+    x, _ = eval_inputs(4)
+    for mode in ("f32", "bf16x3", "bf16"):
+        m = hip_msml("iresnet18", fp16=mode != "f32").eval()
+        m.eval_precision = mode if mode != "f32" else m.eval_precision
+        taps = {}
+        hooks = []
+        for k in range(4):
+            hooks.append(m.frb.fm_ops[k].register_forward_hook(
+                lambda mod, inp, out, k=k: taps.__setitem__(k, Fh.to_nchw_any(out[0], mod.channel_f))))
+        with torch.no_grad():
+            feat, seg = m(x.cuda())
+        for h in hooks:
+            h.remove()
+        errs = [rel_err(pick(taps[k]), g["fm%d_pick" % k]) for k in range(4)]
+        ferr = rel_err(feat.cpu().numpy(), g["feature"])
+        bits = np.packbits(Fh.mask_index(seg).cpu().numpy().reshape(-1))
+        mism = int(np.unpackbits(bits ^ g["mask_bits"]).sum())
+        print("stage error growth %-7s fm0..3 %s | feature %.2e | mask px differing %d"
+              % (mode, " ".join("%.2e" % e for e in errs), ferr, mism))
+        if mode != "bf16":
+            assert ferr < 1e-3 and mism == 0
+
+
+def test_fm_none_layers():
+    """fm_layers=(1,0,1,0): FMNone stages are the identity (fmoperator.py:314-325); eval parity with the
+    CPU oracle built the same way (f32: embedding, masks) and a bf16 training step that runs."""
+    torch.manual_seed(0)
+    o = fill_module(om.MSML("iresnet18", "unet", (1, 0, 1, 0), 100, fm_params=(3, 2, "sigmoid", "mul"),
+                            header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0))).eval()
+    m = hip_msml("iresnet18", 100, fm_layers=(1, 0, 1, 0)).eval()
+    assert set(m.state_dict()) == set(o.state_dict())
+    x, msk = eval_inputs(2)
+    with torch.no_grad():
+        fo, so = o(x)
+        fh, sh = m(x.cuda())
+    assert rel_err(fh.cpu().numpy(), fo.numpy()) < 1e-3
+    assert torch.equal(Fh.mask_index(sh).cpu().bool(), om.mask_index(so).bool())
+    mb = hip_msml("iresnet18", 100, fp16=True, fm_layers=(1, 0, 1, 0)).train()
+    label = synthetic.labels(2, 100, seed=1)
+    cls, seg, _ = mb(x.cuda(), label.cuda())
+    loss = torch.nn.functional.cross_entropy(cls, label.cuda()) + \
+        StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in mb.parameters() if p.grad is not None)
+    assert mb.frb.fm_ops[1].__class__.__name__ == "FMNone"
+
+
+def test_partial_fc_hip_checkpoint_roundtrip(tmp_path):
+    """save_params() after FlatSGD steps -> PartialFC(resume=True): the files hold the TRAINED weight and
+    momentum (the arena views), under the reference's names, and a resumed head continues bit for bit."""
+    from msml_amd.headers import ArcMargin, PartialFC
+    from msml_amd.optim import FlatSGD
+    from oracle.inputs import PFC_B, PFC_C, PFC_E, pfc_inputs
+    feat, label, w = pfc_inputs(1, 0)
+
+    def make(resume):
+        p = PartialFC(0, 0, 1, PFC_B, resume, ArcMargin(64.0, 0.48, 0.0, 0.0), PFC_C, embedding_size=PFC_E,
+                      prefix=str(tmp_path))
+        opt = FlatSGD([{"params": [p.sub_weight], "lr": 0.05}], 0.9, 5e-4, None)
+        return p, opt
+    p, opt = make(False)
+    with torch.no_grad():
+        p.weight.copy_(w)
+        p.sub_weight.data.copy_(w)
+    w0 = p.sub_weight.data.clone()
+    for _ in range(2):
+        opt.zero_grad()
+        p.forward_backward(label.cuda(), feat.cuda(), opt)
+        opt.step()
+    assert p.sub_weight.grad.data_ptr() == opt.flat_g.data_ptr()        # dW went straight into the arena
+    assert not torch.equal(p.sub_weight.data, w0)
+    p.save_params()
+    raw_w = torch.load(os.path.join(str(tmp_path), "rank:0_softmax_weight.pt"))
+    raw_m = torch.load(os.path.join(str(tmp_path), "rank:0_softmax_weight_mom.pt"))
+    assert raw_w.shape == (PFC_C, PFC_E) and torch.equal(raw_w.cuda(), p.sub_weight.data)
+    assert raw_m.abs().sum() > 0 and torch.equal(raw_m.cuda(), opt.flat_m[:raw_m.numel()].view_as(raw_m))
+    q, optq = make(True)
+    assert torch.equal(q.sub_weight.data, p.sub_weight.data)
+    for head, o in ((p, opt), (q, optq)):
+        o.zero_grad()
+        head.forward_backward(label.cuda(), feat.cuda(), o)
+        o.step()
+    assert torch.equal(q.sub_weight.data, p.sub_weight.data)           # momentum was resumed too
+    assert torch.equal(q.sub_weight_mom, p.sub_weight_mom)
+
+
+def test_partial_fc_hip_negative_sampling():
+    """sample_rate 0.3 on the HIP backend, W = 1: with the golden's own random draw injected the sampled
+    index equals the reference's, and loss / x_grad / the updated rows match the reference golden."""
+    from msml_amd.headers import ArcMargin, PartialFC
+    from oracle.inputs import PFC_B, PFC_C, PFC_E, pfc_inputs
+    g = load("g6s_partial_fc_sampled.npz")
+    feat, label, w = pfc_inputs(1, 0)
+    p = PartialFC(0, 0, 1, PFC_B, False, ArcMargin(64.0, 0.48, 0.0, 0.0), PFC_C, sample_rate=0.3,
+                  embedding_size=PFC_E)
+    with torch.no_grad():
+        p.weight.copy_(w)
+        gm = torch.Generator().manual_seed(9000)
+        p.weight_mom.copy_(torch.randn(p.weight.shape, generator=gm) * 1e-3)
+    torch.manual_seed(4321)
+    p.perm_fn = lambda n, device: torch.rand(size=[n]).to(device)      # the reference's CPU draw
+    opt = torch.optim.SGD([{"params": p.parameters()}], lr=0.1 / 512 * PFC_B, momentum=0.9, weight_decay=5e-4)
+    x_grad, loss_v = p.forward_backward(label.cuda(), feat.cuda(), opt)
+    wgrad = p.sub_weight.grad.clone()
+    opt.step()
+    p.update()
+    pre = "w1_rate0.3/r0/"
+    assert np.array_equal(p.index.cpu().numpy(), g[pre + "index"])
+    assert abs(loss_v.item() - g[pre + "loss"]) < 1e-4 * abs(g[pre + "loss"])
+    assert rel_err(x_grad.cpu().numpy(), g[pre + "x_grad"]) < 1e-4
+    assert rel_err(pick(wgrad, 256), g[pre + "wgrad_pick"]) < 1e-4
+    assert rel_err(pick(p.weight, 512), g[pre + "wnew_pick"]) < 1e-5
+    assert rel_err(pick(p.weight_mom, 512), g[pre + "mom_pick"]) < 1e-5
+
+
+def test_ddp_sgd_gradscaler_step_as_train_py():
+    """One step exactly as the reference's live path drives the model (train.py:133-138,179-196,
+    252-277): DistributedDataParallel(find_unused_parameters=True, broadcast_buffers=False) around MSML,
+    torch.optim.SGD over the reference's LR groups, autocast + GradScaler scale/unscale_/clip/step --
+    against the same step issued without DDP / scaler (gradients are identical up to the scale
+    round trip, which is exact for a power-of-two scale)."""
+    import torch.distributed as dist
+    from torch.cuda import amp
+    from torch.nn.utils import clip_grad_norm_
+    from msml_amd.optim import reference_param_groups
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29581"
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        bs, C = 4, 64
+        x, msk = eval_inputs(bs)
+        label = synthetic.labels(bs, C, seed=1)
+
+        def step(use_ddp):
+            backbone = hip_msml("iresnet18", C, fp16=True)
+            for ps in backbone.parameters():
+                dist.broadcast(ps, 0)
+            init = {n: p.detach().clone() for n, p in backbone.named_parameters()}
+            model = backbone
+            if use_ddp:
+                model = torch.nn.parallel.DistributedDataParallel(
+                    module=backbone, broadcast_buffers=False, device_ids=[0], find_unused_parameters=True)
+            model.train()
+            opt = torch.optim.SGD(reference_param_groups(backbone, bs, 1), lr=0.1 / 512 * bs, momentum=0.9,
+                                  weight_decay=5e-4)
+            scaler = amp.GradScaler(init_scale=2.0 ** 10, growth_interval=100)
+            seg_criterion = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")
+            cls_criterion = torch.nn.CrossEntropyLoss()
+            img, lab, m_ = x.cuda(), label.cuda(), msk.cuda()
+            with amp.autocast(True):
+                final_cls, final_seg, kd = model(img, lab, None)
+                seg_loss = seg_criterion(final_seg, m_.clone(), m_)
+                cls_loss = cls_criterion(final_cls, lab)
+                total = cls_loss + 1.0 * seg_loss
+            if use_ddp:
+                scaler.scale(total).backward()
+                scaler.unscale_(opt)
+                clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
+                scaler.step(opt)
+                scaler.update()
+            else:
+                total.backward()
+                clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
+                opt.step()
+            torch.cuda.synchronize()
+            return total.item(), init, {n: p.detach().clone() for n, p in backbone.named_parameters()}
+        la, _, pa = step(False)
+        lb, p0, pb = step(True)
+        assert abs(la - lb) < 1e-6 * abs(la)
+        moved = 0
+        for n in pa:
+            assert torch.isfinite(pb[n]).all(), n
+            assert rel_err(pb[n].float().cpu().numpy(), pa[n].float().cpu().numpy()) < 1e-4, n
+            moved += int(not torch.equal(pb[n], p0[n]))
+        assert moved > 300          # the optimizer really stepped the parameters
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_param_groups_on_device_model():
+    """reference_param_groups (train.py:153-178) on the HIP model against the golden name -> lr table
+    recorded from the reference (G8): osb parameters 0.01/512*bs*W, everything else 0.1/512*bs*W."""
+    from msml_amd.optim import reference_param_groups
+    g = load("g8_lr.npz")
+    m = hip_msml("iresnet18", 10)
+    bs, world = 256, 4
+    lr_of = {}
+    for grp in reference_param_groups(m, bs, world):
+        for p in grp["params"]:
+            lr_of[id(p)] = grp["lr"]
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    want = {str(n): float(lr) for n, lr in zip(g["names"], g["lrs"])}
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert abs(lr_of[id(p)] - want[n]) < 1e-12, n
+    assert len(names) == len(lr_of)
