@@ -31,7 +31,7 @@ extern "C" {
 
 #define MSML_ABI_VERSION 1
 
-enum { MSML_F32 = 0, MSML_BF16 = 1 };
+enum { MSML_F32 = 0, MSML_BF16 = 1, MSML_BF16X3 = 2 };   /* BF16X3: split-bf16 planes, see msml_conv2d_x3 */
 
 enum {
   MSML_OK = 0,
@@ -252,6 +252,32 @@ int msml_conv2d_fused(const void* in0, int c0p, const void* in1, int c1p, const 
                       const void* residual, int res_first, void* out, int coutp, int N, int H,
                       int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
                       int transposed, void* stream);
+
+/* ---------------------------------------------------------------- split-bf16 inference ("bf16x3") ---
+ * f32-class accuracy on the bf16 MFMA (gfx950 has no TF32; exact-f32 MFMA is 1/16 of the bf16 rate):
+ * a value is stored as hi = bf16(x), lo = bf16(x - hi); a pixel of an MSML_BF16X3 tensor holds 3*C bf16
+ * channels [hi(C) | lo(C) | hi(C)], a packed weight is laid out [wh | wh | wl] along each tap's channels,
+ * so x.w ~= xh.wh + xl.wh + xh.wl is ONE implicit GEMM over 3*C input channels on the unchanged bf16 main
+ * loop.  Meets the reference's eval tolerances with fp16=True (embedding <= 1e-3, mask indices bit-exact).
+ *
+ * msml_conv2d_x3: msml_conv2d_fused on split tensors.  c0p / c1p / coutp are the LOGICAL padded channel
+ *   counts (multiples of 32); in0 / in1 / residual / out hold 3x that many bf16 channels per pixel; wp from
+ *   msml_pack_weight over the expanded weight ([wh|wh|wl] per segment, C1p = 3*c0p, C2p = 3*c1p).
+ *   out = [prelu](acc*scale + shift [+ residual]) [+ residual]; scale NULL = 1, shift NULL = 0 (plain conv
+ *   with bias: shift = bias).  Replaces the same call sites as msml_conv2d / msml_conv2d_fused in eval mode.
+ * msml_x3_bn_act_fwd / msml_x3_fm_fuse_fwd / msml_x3_add: msml_bn_act_fwd / msml_fm_fuse_fwd / msml_add on
+ *   split tensors of M pixels x C channels.  msml_x3_from_f32 / msml_x3_to_f32: [M][C] f32 <-> split. */
+int msml_conv2d_x3(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
+                   const float* scale, const float* shift, const float* alpha, const void* residual,
+                   int res_first, void* out, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                   int stride, int pad_h, int pad_w, int transposed, void* stream);
+int msml_x3_bn_act_fwd(const void* x, const float* scale, const float* shift, const float* alpha,
+                       const void* residual, int res_first, void* y, long M, int C, void* stream);
+int msml_x3_fm_fuse_fwd(const void* x, const void* yf, void* z, long M, int C, int act, int arith,
+                        void* stream);
+int msml_x3_add(const void* a, const void* b, void* out, long M, int C, void* stream);
+int msml_x3_from_f32(const float* src, void* dst, long M, int C, void* stream);
+int msml_x3_to_f32(const void* src, float* dst, long M, int C, void* stream);
 
 /* Backward-data conv fused with the backward REDUCE of the BatchNorm(+PReLU) that produced the
  * conv's input in the forward (IBasicBlock: bn1 -> conv1, bn2 -> prelu -> conv2,

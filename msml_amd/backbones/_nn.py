@@ -14,6 +14,8 @@ def conv(m, x0, x1=None, want_stats=False, c0=None, c1=0):
     if c0 is None:
         c0 = cin - c1
     assert c0 + c1 == cin
+    if isinstance(x0, Fh.SplitT):              # split-bf16 inference (functional.py, csrc/x3.hip)
+        return Fh.conv_plain_x3(m, x0, x1, c1), None
     assert m.groups == 1 and m.dilation == (1, 1) and m.stride[0] == m.stride[1]
     cfg = {"deconv": deconv, "c0": c0, "c1": c1, "cout": m.out_channels, "stride": m.stride[0],
            "pad_h": m.padding[0], "pad_w": m.padding[1], "want_stats": want_stats}
@@ -31,7 +33,11 @@ def conv_bn(conv_m, bn_m, x0, x1=None, prelu=None, residual=None, c1=0, res_firs
                 and cw.shape[1] * cw.shape[2] * cw.shape[3] <= 32 and conv_m.out_channels % 32 == 0
                 and conv_m.padding[0] == conv_m.padding[1] and cw.shape[2] == cw.shape[3]):
             return Fh.stem_conv_bn(x0, conv_m, bn_m, prelu)
+        if x0.x3:
+            raise RuntimeError("msml_amd: split-bf16 inference expects the im2col stem shape")
         x0 = x0.nhwc()
+    if isinstance(x0, Fh.SplitT):
+        return Fh.conv_bn_eval_x3(x0, x1, conv_m, bn_m, prelu, residual, c1, res_first)
     if (not bn_m.training and not torch.is_grad_enabled() and x0.dtype == torch.bfloat16
             and conv_m.bias is None and not isinstance(conv_m, nn.ConvTranspose2d)
             and conv_m.out_channels % 32 == 0):

@@ -121,8 +121,11 @@ class IResNet(nn.Module):
             raise NotImplementedError("msml_amd: dropout > 0 is not built (reference config uses 0)")
         # flatten(C,H,W) + Linear(25088, 512): skinny GEMM on the NHWC-ordered operand
         n, h, w, c = x.shape
-        wview = self.fc.weight.view(self.fc.out_features, c, h, w)
-        y = Fh.flat_fc(x, wview, self.fc.bias, self.fc.weight)
+        if isinstance(x, Fh.SplitT):
+            y = Fh.flat_fc_x3(x, self.fc)          # f32 [N,1,1,E]; BatchNorm1d below runs in f32
+        else:
+            wview = self.fc.weight.view(self.fc.out_features, c, h, w)
+            y = Fh.flat_fc(x, wview, self.fc.bias, self.fc.weight)
         y = Fh.bn_act(y, None, self.features)
         return Fh.to_vec(y, self.fc.out_features), 0.0
 

@@ -8,6 +8,8 @@ are `frb.*`, `osb.*`, `classification.*` exactly as the reference's (SURVEY sect
 the reference's fp32 results to rounding), True -> bf16 operands with f32 accumulation
 (the reference's autocast analogue; see DESIGN.md for the measured error).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -79,6 +81,11 @@ class MSML(nn.Module):
         self.fp16 = fp16
         self.classification.fp16 = fp16
         self.use_osb = use_osb
+        # Inference precision with fp16=True: "bf16x3" = split-bf16 operands (hi + lo, three bf16 MFMAs
+        # per product, csrc/x3.hip) -- embeddings within 1e-3 and mask indices bit-exact against the f32
+        # reference, the outputs the north-star tolerances are stated for; "bf16" = plain bf16 operands,
+        # ~3x the throughput at ~5e-3 embedding error.  Training with fp16=True is always bf16.
+        self.eval_precision = os.environ.get("MSML_EVAL_PRECISION", "bf16x3")
 
     def forward(self, x, label=None, ori=None):
         if not x.is_cuda:
@@ -97,7 +104,9 @@ class MSML(nn.Module):
     def _forward(self, x, label, ori):
         from .. import ops
         # bf16: the stems unfold the raw image themselves (im2col + 1x1 conv); f32: padded NHWC
-        xh = Fh.RawImage(x.float()) if self.fp16 else Fh.to_nhwc(x, F32)
+        x3 = (self.fp16 and not self.training and not torch.is_grad_enabled()
+              and self.eval_precision == "bf16x3")
+        xh = Fh.RawImage(x.float(), x3=x3) if self.fp16 else Fh.to_nhwc(x, F32)
         side = ops.OSB_STREAM
         if side is None:
             seg_list = self.osb(xh)                # [seg0, seg1, seg2, seg3, seg5]

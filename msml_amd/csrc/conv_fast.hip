@@ -18,6 +18,8 @@
 //   * bf16 results are transposed through LDS and stored as 16-B row chunks.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 struct ConvFastArgs {
@@ -72,7 +74,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // FUSE: backward-data launch with the fused BatchNorm backward-reduce epilogue (bf16 out, no
 // bias / residual / statistics); a separate instantiation so the plain kernel's register
 // allocation is not disturbed by the extra epilogue state.
-template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST, bool FUSE = false>
+// X3: split-bf16 output (x3.hip): the f32 results pass through an f32 LDS tile and leave as the three
+// planes [hi | lo | hi] of a pixel with 3 * coutp channels; `residual` is read in the same format.
+template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST, bool FUSE = false, bool X3 = false>
 __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(const ConvFastArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in the device pass only
   constexpr int NW = WGM * WGN, NT = NW * 64, RPP = NW * 8;    // waves, threads, rows per pass
@@ -346,7 +350,9 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
   TOUT* outp = reinterpret_cast<TOUT*>(p.out) + (p.ksplits > 1 ? blockIdx.z * p.split_stride : 0);
   constexpr bool VIA_LDS = sizeof(TOUT) == 2;
   constexpr int OP = BN + 8;                           // tile pitch in elements
+  constexpr int OPF = BN + 4;                          // pitch of the f32 tile (X3)
   unsigned short* otile = reinterpret_cast<unsigned short*>(smem);
+  float* otf = reinterpret_cast<float*>(smem);
   // fused BatchNorm backward-reduce: the saved BatchNorm input of this thread's copy-out chunks is
   // requested first, so the loads fly during the accumulator -> LDS transpose
   constexpr int C8 = BN / 8, ITERS = FUSE ? BM * C8 / NT : 1;
@@ -385,7 +391,8 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
         long m = m0 + row;
         float v = acc[i][j][e] * sv + bv;
         if (act_here) v = v > 0.f ? v : v * av;
-        if (VIA_LDS) otile[row * OP + lcol] = f2bf(v);
+        if constexpr (X3) otf[row * OPF + lcol] = v;
+        else if (VIA_LDS) otile[row * OP + lcol] = f2bf(v);
         if (m < Mc && cok) {
           if (!VIA_LDS) store1<TOUT>(outp + out_pixel(m) * p.coutp + col, v);
           s1 += v;
@@ -436,6 +443,33 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
         float sum = 0.f;
         for (int g = 0; g < G; g++) sum += red[(g * 3 + q) * BN + c];
         if (n0 + c < p.coutp) p.bnb.partial[(prow * 3 + q) * p.coutp + n0 + c] = sum;
+      }
+    } else if constexpr (X3) {
+      __syncthreads();
+      unsigned short* o16 = reinterpret_cast<unsigned short*>(p.out);
+      for (int idx = t; idx < BM * C8; idx += NT) {
+        const int row = idx / C8;
+        const long m = m0 + row;
+        if (m < Mc && col < p.coutp) {
+          Vec8 a = load8<float>(otf + row * OPF + c8 * 8);
+          const long o = out_pixel(m) * (3L * p.coutp) + col;
+          if (p.residual) {
+            const Vec8 rh = load8<unsigned short>(p.residual + o), rl = load8<unsigned short>(p.residual + o + p.coutp);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              float z = a.v[q] + (rh.v[q] + rl.v[q]);
+              if (p.res_first && p.alpha) z = z > 0.f ? z : z * p.alpha[col + q];
+              a.v[q] = z;
+            }
+          }
+          const Vec8 hi = round8<unsigned short>(a);
+          Vec8 lo;
+#pragma unroll
+          for (int q = 0; q < 8; q++) lo.v[q] = a.v[q] - hi.v[q];
+          store8<unsigned short>(o16 + o, hi);
+          store8<unsigned short>(o16 + o + p.coutp, lo);
+          store8<unsigned short>(o16 + o + 2 * p.coutp, hi);
+        }
       }
     } else {
       __syncthreads();
@@ -491,16 +525,23 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
 #endif
 }
 
-template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST, bool FUSE = false>
+template <typename TOUT, int BM, int BN, int WGM, int WGN, int NST, bool FUSE = false, bool X3 = false>
 static void launch_fast(ConvFastArgs& a, hipStream_t st) {
   // parity mode: tiles sized for the largest class (cy = cx = 0); smaller classes exit early
   const long mtile = a.parity ? (long)a.N * ((a.P + 1) / 2) * ((a.Q + 1) / 2) : a.M;
   a.tiles_m = cdiv(mtile, BM);
   dim3 grid(a.tiles_m, cdiv(a.coutp, BN), a.parity ? 4 : (a.ksplits > 1 ? a.ksplits : 1));
   size_t lds = (size_t)NST * (BM + BN) * 128;
-  size_t olds = sizeof(TOUT) == 2 ? (size_t)BM * (BN + 8) * 2 : 0;
+  size_t olds = X3 ? (size_t)BM * (BN + 4) * 4 : (sizeof(TOUT) == 2 ? (size_t)BM * (BN + 8) * 2 : 0);
   if (olds > lds) lds = olds;
-  k_conv_fast<TOUT, BM, BN, WGM, WGN, NST, FUSE><<<grid, dim3(WGM * WGN * 64), lds, st>>>(a);
+  if (lds > 64 * 1024) {                               // above the default dynamic-LDS limit
+    static std::once_flag once;
+    std::call_once(once, [] {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fast<TOUT, BM, BN, WGM, WGN, NST, FUSE, X3>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+  }
+  k_conv_fast<TOUT, BM, BN, WGM, WGN, NST, FUSE, X3><<<grid, dim3(WGM * WGN * 64), lds, st>>>(a);
 }
 
 bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
@@ -524,8 +565,10 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
                              const float* scale, const float* alpha, const void* residual, int res_first,
                              const BnBwdFuse* bnb, int* bnb_rows) {
   if (in_dtype != MSML_BF16) return false;
+  const bool x3 = out_dtype == MSML_BF16X3;            // split-bf16 output planes (x3.hip)
+  if (x3 && (bnb || stats)) return false;
   if (bnb && (out_dtype != MSML_BF16 || stats)) return false;
-  if ((scale || alpha || residual) && out_dtype != MSML_BF16) return false;
+  if ((scale || alpha || residual) && out_dtype != MSML_BF16 && !x3) return false;
   if (c0p % 32 != 0 || (in1 && c1p % 32 != 0)) return false;
   if (!in1 && out_dtype == MSML_BF16 &&
       msml_conv_ws_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h,
@@ -588,6 +631,10 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
     if (bn == 128) launch_fast<unsigned short, 128, 128, 2, 2, 2, true>(a, st);
     else if (bn == 64) launch_fast<unsigned short, 256, 64, 4, 1, 2, true>(a, st);
     else launch_fast<unsigned short, 256, 32, 4, 1, 2, true>(a, st);
+  } else if (x3) {
+    if (bn == 128) launch_fast<unsigned short, 128, 128, 2, 2, 2, false, true>(a, st);
+    else if (bn == 64) launch_fast<unsigned short, 256, 64, 4, 1, 2, false, true>(a, st);
+    else launch_fast<unsigned short, 256, 32, 4, 1, 2, false, true>(a, st);
   } else if (out_dtype == MSML_BF16) { FAST_CASE(unsigned short) }
   else { FAST_CASE(float) }
 #undef FAST_CASE

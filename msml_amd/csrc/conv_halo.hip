@@ -21,6 +21,8 @@
 // LDS-DMA zero-fills out-of-range offsets (conv padding) -- see conv_fast.hip.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 struct ConvHaloArgs {
@@ -402,12 +404,11 @@ static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   size_t olds = (size_t)224 * (BN + 8) * 2;
   if (olds > lds) lds = olds;
   if (XF) lds += 3 * 1024 * sizeof(float);             // coefficient table, C <= 1024
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;                     // (per template instantiation; launches come from
+  std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   dim3 grid(a.N * a.tpy * a.tpx, a.coutp / BN);
   k_conv_halo<BN, NWM, FUSE, XF><<<grid, dim3(512), lds, st>>>(a);
 }

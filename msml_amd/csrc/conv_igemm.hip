@@ -398,6 +398,26 @@ extern "C" int msml_conv2d_fused(const void* in0, int c0p, const void* in1, int 
 }
 
 
+// Split-bf16 inference conv (msml_hip.h "bf16x3"): the fast kernel sees 3 * c0p (+ 3 * c1p) plain bf16
+// input channels; its X3 epilogue writes the three output planes.
+extern "C" int msml_conv2d_x3(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
+                              const float* scale, const float* shift, const float* alpha, const void* residual,
+                              int res_first, void* out, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                              int stride, int pad_h, int pad_w, int transposed, void* stream) {
+  MSML_CHECK(in0 && wp && out, MSML_ERR_SHAPE, "conv2d_x3: null pointer");
+  MSML_CHECK(c0p > 0 && c0p % 32 == 0 && c1p % 32 == 0 && coutp > 0 && coutp % 32 == 0, MSML_ERR_SHAPE,
+             "conv2d_x3: channel padding c0p=%d c1p=%d coutp=%d", c0p, c1p, coutp);
+  const int bn = msml_conv_tile_n(coutp);
+  MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_x3: packed weight rows");
+  MSML_CHECK(msml_conv_fast_dispatch(in0, 3 * c0p, in1, 3 * c1p, wp, kop, shift, out, coutp, nullptr, N, H, W, P, Q,
+                                     R, S, stride, pad_h, pad_w, transposed, MSML_BF16, MSML_BF16X3, bn,
+                                     (hipStream_t)stream, scale, alpha, residual, res_first, nullptr, nullptr),
+             MSML_ERR_UNSUPPORTED, "conv2d_x3: shape not supported by the fast kernel");
+  MSML_LAUNCH_OK("conv2d_x3");
+  return MSML_OK;
+}
+
+
 // Backward-data conv whose output is the gradient of a training-mode BatchNorm(+PReLU) output:
 // the epilogue also produces that BatchNorm's backward partial sums (see msml_hip.h).
 extern "C" int msml_conv2d_bnbwd_rows(int coutp, int N, int P, int Q) {

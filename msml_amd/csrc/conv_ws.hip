@@ -14,6 +14,8 @@
 // row per workgroup.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 struct ConvWsArgs {
@@ -330,12 +332,11 @@ template <bool FUSE, bool XF = false>
 static void launch_ws(ConvWsArgs& a, hipStream_t st) {
   // (+ the 2 pixels the padding rows read past an image, + the input-transform coefficient table)
   const size_t lds = 9 * 64 * 128 + 2 * 256 * 128 + 512 + (XF ? 3 * 64 * sizeof(float) : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;                     // (per template instantiation; launches come from
+  std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_ws<FUSE, XF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   const int wgs = a.ntiles < ws_num_cus() ? a.ntiles : ws_num_cus();
   k_conv_ws<FUSE, XF><<<dim3(wgs), dim3(512), lds, st>>>(a);
 }

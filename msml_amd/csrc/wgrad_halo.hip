@@ -20,6 +20,8 @@
 
 #include <type_traits>
 
+#include <mutex>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -268,12 +270,11 @@ template <int CO, bool XF>
 static void wh_launch(const WgradHaloArgs& a, dim3 grid, hipStream_t st) {
   // two stages of (7 dY row blocks per 32 Cout + 10 X rows x 2 channel groups) KB (+ coefficient table)
   const size_t lds = 2 * (7 * (CO / 32) + 10 * 2) * 1024 + (XF ? 3 * 64 * sizeof(float) : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;                     // (per template instantiation; launches come from
+  std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<CO, XF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   k_wgrad_halo<CO, XF><<<grid, dim3(512), lds, st>>>(a);
 }
 

@@ -210,6 +210,8 @@ class _BnAct(torch.autograd.Function):
 def bn_act(x, stats, bn, prelu=None, residual=None, res_first=False):
     """Apply an nn.BatchNorm module `bn` (+ optional nn.PReLU, + residual) to an NHWC tensor.
     res_first: prelu(bn(x) + residual) instead of prelu(bn(x)) + residual."""
+    if isinstance(x, SplitT):
+        return bn_act_x3(x, bn, prelu, residual, res_first)
     training = bn.training
     if training:
         ops.bn_counter(bn)
@@ -244,6 +246,8 @@ ARITHS = {"add": 0, "sub": 1, "mul": 2, "div": 3}
 
 
 def fm_fuse(x, yf, act, arith):
+    if isinstance(x, SplitT):
+        return fm_fuse_x3(x, yf, act, arith)
     return _FmFuse.apply(x, yf, ACTS[act], ARITHS[arith])
 
 
@@ -260,6 +264,8 @@ class _Add(torch.autograd.Function):
 
 
 def add(a, b):
+    if isinstance(a, SplitT):
+        return add_x3(a, b)
     return _Add.apply(a, b)
 
 
@@ -288,6 +294,8 @@ class _Dap(torch.autograd.Function):
 
 
 def dap(x):
+    if isinstance(x, SplitT):
+        x = x3_to_f32(x)
     return _Dap.apply(x)
 
 
@@ -591,9 +599,10 @@ class RawImage:
     """The NCHW f32 input image as handed to MSML.forward, for the stems' im2col path.  The padded
     NHWC tensor the generic conv path needs is only built if somebody asks for it."""
 
-    def __init__(self, x):
+    def __init__(self, x, x3=False):
         self.raw = x
         self.dtype = torch.bfloat16
+        self.x3 = x3                # inference in split-bf16 (bf16x3) storage
         self._nhwc = None
 
     def nhwc(self):
@@ -654,6 +663,8 @@ class _StemConv(torch.autograd.Function):
 
 def stem_conv_bn(raw, conv_m, bn_m, prelu):
     """Stem conv -> BatchNorm -> PReLU on a RawImage (training and inference)."""
+    if raw.x3:
+        return stem_conv_bn_x3(raw, conv_m, bn_m, prelu)
     if not bn_m.training and not torch.is_grad_enabled():
         cout, cin, r, s = conv_m.weight.shape
         col = ops.stem_im2col(raw.raw, r, s, conv_m.stride[0], conv_m.padding[0])
@@ -671,3 +682,200 @@ def stem_conv_bn(raw, conv_m, bn_m, prelu):
         return out
     y, stats = _StemConv.apply(conv_m.weight, conv_m, raw.raw)
     return bn_act(y, stats if stats.numel() else None, bn_m, prelu)
+
+
+# ---------------------------------------------------------------------------------------------
+# Split-bf16 ("bf16x3") inference: f32-class accuracy on the bf16 MFMA (csrc/x3.hip, msml_conv2d_x3).
+# Every tensor between the ops is a SplitT; the ops below mirror conv / conv_bn_eval / bn_act /
+# fm_fuse / add / dap / flat_fc for that storage.  Inference only (no autograd graph).
+class SplitT:
+    """[N, H, W, 3*Cp] bf16 = planes [hi | lo | hi] of an f32-valued NHWC tensor with Cp channels."""
+    __slots__ = ("t", "c")
+    dtype = "bf16x3"
+
+    def __init__(self, t, c):
+        self.t, self.c = t, c
+
+    @property
+    def shape(self):
+        n, h, w, _ = self.t.shape
+        return (n, h, w, self.c)
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def detach(self):
+        return self
+
+    def record_stream(self, stream):
+        self.t.record_stream(stream)
+
+    def numel(self):
+        n, h, w, _ = self.t.shape
+        return n * h * w * self.c
+
+
+def _x3_empty(n, h, w, cp, dev):
+    return SplitT(torch.empty(n, h, w, 3 * cp, dtype=torch.bfloat16, device=dev), cp)
+
+
+def x3_from_f32(x):
+    """NHWC f32 [N,H,W,Cp] -> SplitT."""
+    n, h, w, cp = x.shape
+    out = _x3_empty(n, h, w, cp, x.device)
+    call("msml_x3_from_f32", x.contiguous(), out.t, n * h * w, cp)
+    return out
+
+
+def x3_to_f32(s):
+    n, h, w, cp = s.shape
+    out = torch.empty(n, h, w, cp, dtype=torch.float32, device=s.device)
+    call("msml_x3_to_f32", s.t, out, n * h * w, cp)
+    return out
+
+
+def to_nchw_any(t, c):
+    """NHWC storage tensor of any precision mode -> NCHW f32 with the first c channels."""
+    if isinstance(t, SplitT):
+        t = x3_to_f32(t)
+    return ops.to_nchw(t, c)
+
+
+def _x3_expand(w, axis, segs):
+    """f32 weight -> the split operand [wh | wh | wl] per input segment along `axis` (the input-channel
+    axis), each segment zero-padded to its storage channel count first."""
+    parts = []
+    off = 0
+    for c, cp_ in segs:
+        ws = w.narrow(axis, off, c)
+        if cp_ != c:
+            pad = list(ws.shape)
+            pad[axis] = cp_ - c
+            ws = torch.cat((ws, ws.new_zeros(pad)), axis)
+        wh = ws.to(torch.bfloat16).float()
+        parts += [wh, wh, ws - wh]
+        off += c
+    return torch.cat(parts, axis).contiguous()
+
+
+def _x3_pack(owner, key, w, transpose, segs):
+    """Packed split operand of parameter `w`, cached on the module until the parameter changes."""
+    stamp = (w._version, ops.WEIGHT_EPOCH, w.data_ptr(), key)
+    cache = owner.__dict__.setdefault("_msml_x3_pack", {})
+    hit = cache.get(key)
+    if hit is None or hit[0] != stamp:
+        wexp = _x3_expand(w.detach().float(), 0 if transpose else 1, segs)
+        c1 = 3 * segs[0][1]
+        c2 = 3 * segs[1][1] if len(segs) > 1 else 0
+        hit = (stamp, ops.pack_weight(wexp, transpose, c1, c2, BF16))
+        cache[key] = hit
+    return hit[1]
+
+
+def conv_x3(x0, x1, conv_m, scale, shift, alpha, residual, res_first, c1=0, weight=None, pack_key="fwd"):
+    """conv / deconv on split tensors with the affine + PReLU + residual epilogue (msml_conv2d_x3)."""
+    import torch.nn as nn
+    deconv = isinstance(conv_m, nn.ConvTranspose2d)
+    w = conv_m.weight if weight is None else weight
+    cin, cout = conv_m.in_channels, conv_m.out_channels
+    c0 = cin - c1
+    r, s = conv_m.kernel_size
+    stride, (ph, pw) = conv_m.stride[0], conv_m.padding
+    n, h, wd, c0p = x0.shape
+    segs = [(c0, c0p)] + ([(c1, x1.shape[3])] if x1 is not None else [])
+    wp = _x3_pack(conv_m, pack_key, w, deconv, segs)
+    coutp = cpad(cout)
+    p = ops.conv_out_size(h, r, stride, ph, deconv)
+    q = ops.conv_out_size(wd, s, stride, pw, deconv)
+    out = _x3_empty(n, p, q, coutp, x0.device)
+    pix = n * h * wd if deconv else n * p * q
+    with ops.PROFILE.rec("conv_x3", 2.0 * pix * cin * cout * r * s):
+        call("msml_conv2d_x3", x0.t, c0p, x1.t if x1 is not None else None, x1.shape[3] if x1 is not None else 0,
+             wp, wp.shape[0], scale, shift, alpha, residual.t if residual is not None else None, int(res_first),
+             out.t, coutp, n, h, wd, p, q, r, s, stride, ph, pw, int(deconv))
+    return out
+
+
+def _pad_vec(v, cp):
+    """Per-channel f32 vector zero-padded to the storage channel count."""
+    if v.numel() == cp:
+        return v.detach()
+    out = torch.zeros(cp, dtype=torch.float32, device=v.device)
+    out[:v.numel()] = v.detach()
+    return out
+
+
+def conv_bn_eval_x3(x0, x1, conv_m, bn_m, prelu, residual, c1, res_first):
+    coutp = cpad(conv_m.out_channels)
+    coef = _eval_bn_coef(bn_m, coutp)
+    return conv_x3(x0, x1, conv_m, coef[0], coef[1], prelu.weight if prelu is not None else None, residual,
+                   res_first, c1)
+
+
+def conv_plain_x3(conv_m, x0, x1, c1):
+    """Conv / deconv (+ bias) without BatchNorm (OSB decoder, FM same_conv)."""
+    shift = _pad_vec(conv_m.bias, cpad(conv_m.out_channels)) if conv_m.bias is not None else None
+    return conv_x3(x0, x1, conv_m, None, shift, None, None, 0, c1)
+
+
+def bn_act_x3(x, bn_m, prelu=None, residual=None, res_first=False):
+    n, h, w, cp = x.shape
+    coef = _eval_bn_coef(bn_m, cp)
+    y = _x3_empty(n, h, w, cp, x.device)
+    call("msml_x3_bn_act_fwd", x.t, coef[0], coef[1], prelu.weight if prelu is not None else None,
+         residual.t if residual is not None else None, int(res_first), y.t, n * h * w, cp)
+    return y
+
+
+def fm_fuse_x3(x, yf, act, arith):
+    n, h, w, cp = x.shape
+    z = _x3_empty(n, h, w, cp, x.device)
+    with ops.PROFILE.rec("fm_fuse_fwd", 0.0, 3 * x.t.numel() * 2):
+        call("msml_x3_fm_fuse_fwd", x.t, yf.t, z.t, n * h * w, cp, ACTS[act], ARITHS[arith])
+    return z
+
+
+def add_x3(a, b):
+    n, h, w, cp = a.shape
+    out = _x3_empty(n, h, w, cp, a.device)
+    call("msml_x3_add", a.t, b.t, out.t, n * h * w, cp)
+    return out
+
+
+def stem_conv_bn_x3(raw, conv_m, bn_m, prelu):
+    """Stem on the raw image: f32 im2col -> split -> 1x1 split conv with the folded BatchNorm + PReLU."""
+    cout, cin, r, s = conv_m.weight.shape
+    col = ops.stem_im2col(raw.raw, r, s, conv_m.stride[0], conv_m.padding[0], dtype=F32)
+    xs = x3_from_f32(col)
+    n, p, q, kp = col.shape
+    k = r * s * cin
+    w2 = conv_m.weight.detach().permute(0, 2, 3, 1).reshape(cout, k, 1, 1)
+    stamp = (conv_m.weight._version, ops.WEIGHT_EPOCH, conv_m.weight.data_ptr())
+    hit = conv_m.__dict__.get("_msml_x3_stem")
+    if hit is None or hit[0] != stamp:
+        hit = (stamp, ops.pack_weight(_x3_expand(w2.float(), 1, [(k, kp)]), False, 3 * kp, 0, BF16))
+        conv_m.__dict__["_msml_x3_stem"] = hit
+    wp = hit[1]
+    coutp = cpad(cout)
+    coef = _eval_bn_coef(bn_m, coutp)
+    out = _x3_empty(n, p, q, coutp, col.device)
+    with ops.PROFILE.rec("conv_x3", 2.0 * n * p * q * k * cout):
+        call("msml_conv2d_x3", xs.t, kp, None, 0, wp, wp.shape[0], coef[0], coef[1],
+             prelu.weight if prelu is not None else None, None, 0, out.t, coutp, n, p, q, p, q, 1, 1, 1, 0, 0, 0)
+    return out
+
+
+def flat_fc_x3(x, fc_m):
+    """flatten(C,H,W) + Linear on a split map: split-K GEMM over K = H*W*3C, f32 result [N, E]."""
+    n, h, w, c = x.shape
+    e = fc_m.out_features
+    stamp = (fc_m.weight._version, ops.WEIGHT_EPOCH, fc_m.weight.data_ptr())
+    hit = fc_m.__dict__.get("_msml_x3_fc")
+    if hit is None or hit[0] != stamp:
+        w4 = fc_m.weight.detach().float().view(e, c, h, w)
+        hit = (stamp, ops.pack_weight(_x3_expand(w4, 1, [(c, c)]), False, 3 * c, 0, BF16))      # [E][H*W*3C]
+        fc_m.__dict__["_msml_x3_fc"] = hit
+    wp = hit[1]
+    y = ops.gemm_splitk(x.t.reshape(n, h * w * 3 * c), wp, cpad(e))
+    return (y[:, :e] + fc_m.bias.detach()).reshape(n, 1, 1, e)

@@ -9,6 +9,7 @@ Goldens:
   g1  eval ires18 bs=4: feature, mask index, seg maps, per-stage checksums
   g2  eval ires50 and the ires100-variant: feature, mask index, checksums
   g4  one full train step ires18 bs=4 (train-mode BN, reference conv init AND key fill)
+  g4b the g4 step at batch 32 (gauge of the bf16 training path)
   g5  AMArcFace / AMCosFace / Softmax heads incl. -1 labels
   g6  PartialFC.forward_backward under gloo, W in {1,2,4,8}, B=8, C=1003 + one SGD step
   g6s the same with negative sampling (sample_rate 0.3 / 0.005): index, step, update()
@@ -183,6 +184,17 @@ def g4():
     m = fill_module(ref_msml("iresnet18", C))
     refinit_frb_convs(m)
     np.savez_compressed(os.path.join(OUT, "g4_train_refinit.npz"), **train_step_record(m, 4, C))
+
+
+def g4b():
+    """The same train step at batch 32 (key fill): the batch-4 step of g4 puts BatchNorm1d over FOUR
+    samples in front of a s=64 ArcFace head, which amplifies any operand rounding (a plain-PyTorch run of
+    the graph with bf16-rounded conv operands already moves the early FRB gradients by 12-19 %); batch 32
+    is the better-conditioned gauge for the bf16 training path."""
+    C = 1000
+    torch.manual_seed(0)
+    m = fill_module(ref_msml("iresnet18", C))
+    np.savez_compressed(os.path.join(OUT, "g4_train_fill_b32.npz"), **train_step_record(m, 32, C))
 
 
 def g5():

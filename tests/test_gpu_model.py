@@ -25,9 +25,11 @@ def hip_msml(frb, C=1000, fp16=False):
     return fill_module(m).cuda()
 
 
-def eval_check(frb, fname, bs, fp16, feat_tol, exact_mask):
+def eval_check(frb, fname, bs, fp16, feat_tol, exact_mask, precision=None):
     g = load(fname)
     m = hip_msml(frb, fp16=fp16).eval()
+    if precision is not None:
+        m.eval_precision = precision
     x, _ = eval_inputs(bs)
     with torch.no_grad():
         feat, final_seg = m(x.cuda())
@@ -56,9 +58,24 @@ def test_eval_ires100_f32():
     eval_check("iresnet100", "g2_ires100_eval.npz", 2, False, 1e-3, True)
 
 
-def test_eval_ires18_bf16():
-    """bf16 operands: looser, documented tolerance (DESIGN.md 'precision modes')."""
-    err, mism = eval_check("iresnet18", "g1_ires18_eval.npz", 4, True, 5e-2, False)
+@pytest.mark.parametrize("frb,fname,bs", [("iresnet18", "g1_ires18_eval.npz", 4),
+                                          ("iresnet50", "g2_ires50_eval.npz", 2),
+                                          ("iresnet100", "g2_ires100_eval.npz", 2)])
+def test_eval_fp16_default_meets_the_parity_bar(frb, fname, bs):
+    """fp16=True inference in its DEFAULT precision (split-bf16, 'bf16x3': three bf16 MFMAs per product)
+    against the reference's f32 goldens: embedding within 1e-3 rel (north_star), occlusion-mask indices
+    bit-exact, final_seg checksums within 1e-4 -- the same bar the exact-f32 mode is held to."""
+    m = hip_msml(frb, fp16=True)
+    assert m.eval_precision == "bf16x3"
+    err, mism = eval_check(frb, fname, bs, True, 1e-3, True)
+    print("bf16x3 eval %s: feature rel err %.3e, mask mismatches %d" % (frb, err, mism))
+    assert err < 2e-4            # measured ~1e-5: keep an order of magnitude of margin visible
+
+
+def test_eval_ires18_bf16_fast_mode():
+    """eval_precision='bf16' (plain bf16 operands, the throughput mode): documented tolerance -- it does
+    NOT meet the 1e-3 bar (DESIGN.md 'precision modes'), which is why it is not the default."""
+    err, mism = eval_check("iresnet18", "g1_ires18_eval.npz", 4, True, 5e-2, False, precision="bf16")
     print("bf16 eval: feature rel err %.3e, mask mismatches %d" % (err, mism))
 
 
@@ -67,6 +84,7 @@ def test_eval_bf16_fused_epilogue_matches_unfused():
     autograd enabled the unfused conv -> bn_act kernels run.  Same arithmetic up to bf16 rounding
     of the intermediate tensors."""
     m = hip_msml("iresnet50", fp16=True).eval()
+    m.eval_precision = "bf16"
     x, _ = eval_inputs(4)
     with torch.no_grad():
         f1, s1 = m(x.cuda())

@@ -79,13 +79,13 @@ def run_train_step(m, bs, C):
     return m, opt, final_cls, final_seg, seg_loss, cls_loss, total, gnorm
 
 
-@pytest.mark.parametrize("variant", ["fill", "refinit"])
-def test_g4_train_step(variant):
+@pytest.mark.parametrize("variant,bs", [("fill", 4), ("refinit", 4), ("fill_b32", 32)])
+def test_g4_train_step(variant, bs):
     g = load("g4_train_%s.npz" % variant)
     m = oracle_msml("iresnet18", 1000)
     if variant == "refinit":
         refinit_frb_convs(m)
-    m, opt, final_cls, final_seg, seg_loss, cls_loss, total, gnorm = run_train_step(m, 4, 1000)
+    m, opt, final_cls, final_seg, seg_loss, cls_loss, total, gnorm = run_train_step(m, bs, 1000)
     tol = 2e-4
     assert abs(seg_loss.item() - g["seg_loss"]) < tol * abs(g["seg_loss"])
     assert abs(cls_loss.item() - g["cls_loss"]) < tol * abs(g["cls_loss"])
