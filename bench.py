@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--classes", type=int, default=85742)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--precision", default=None, choices=["bf16x3", "bf16"],
+                    help="inference precision with --dtype bf16 (default: the model's default, bf16x3)")
+    ap.add_argument("--no-extra-modes", action="store_true",
+                    help="skip the short extra measurements of the other precision modes (rank 0, N == 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
@@ -80,7 +84,7 @@ class Trainer:
             self.opt.enable_overlap(world)
         self.opt_pfc = FlatSGD([{"params": [self.pfc.sub_weight], "lr": 0.1 / 512 * args.batch * world}],
                                0.9, 5e-4, None)
-        self.pfc.weight = self.pfc.sub_weight.data
+        self.pfc.adopt_flat_optimizer(self.opt_pfc)     # weight / momentum / dW live in the head's arenas
         self.seg_crit = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")
         # a short stream of synthetic batches resident in HBM (cycled), so the head cannot
         # simply memorise one batch during the run
@@ -102,17 +106,25 @@ class Trainer:
         Fh = self.Fh
         x, msk, label = batch if batch is not None else self.next_batch()
         self.opt.zero_grad()
+        if self.world > 1:
+            self.pfc.prefetch_labels(label)          # label all-gather on the head's side stream
         feature, final_seg, kd = self.model(x)                   # head-less training return
-        fn = Fh.normalize(feature)
-        x_grad, loss_v = self.pfc.forward_backward(label, fn, None)
         seg_loss = self.seg_crit(final_seg, msk, msk)
-        # (one engine call: the OSB nodes, created first, run last; issuing the OSB backward first
-        # as its own call measured 1 % slower -- the host spends 4 ms on it before the FRB starts)
-        torch.autograd.backward([fn, seg_loss], [x_grad, None])
+        fn = Fh.normalize(feature)
+        if self.world > 1:
+            # the OSB backward depends on final_seg only: issue it first so that it runs (on the OSB
+            # stream) underneath the head's collectives; the FRB backward follows once dX is back
+            seg_loss.backward()
+            x_grad, loss_v = self.pfc.forward_backward(label, fn, self.opt_pfc)
+            fn.backward(x_grad)
+        else:
+            # one engine call: the OSB nodes, created first, run last (as its own call the OSB backward
+            # measured 1 % slower at world size 1 -- 4 ms of host time before the FRB backward starts)
+            x_grad, loss_v = self.pfc.forward_backward(label, fn, self.opt_pfc)
+            torch.autograd.backward([fn, seg_loss], [x_grad, None])
         self.opt.all_reduce_grads(self.world)
         self.opt.step()
-        self.opt_pfc.flat_g.copy_(self.pfc.sub_weight.grad.reshape(-1))
-        self.opt_pfc.step()
+        self.opt_pfc.step()                          # dW was written straight into its gradient arena
         return loss_v, seg_loss
 
 
@@ -127,6 +139,9 @@ class Inferer:
         self.model = MSML(args.frb, "unet", (1, 1, 1, 1), 8, fp16=args.dtype == "bf16",
                           fm_params=(3, 2, "sigmoid", "mul"), header_type="AMArcFace",
                           header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(PEER_OFF)).to(dev).eval()
+        if args.precision:
+            self.model.eval_precision = args.precision
+        self.precision = self.model.eval_precision if args.dtype == "bf16" else "f32"
         a, b, _ = synthetic.occluded_pairs(args.batch // 2, seed=1 + rank)
         self.x = torch.cat((a, b)).to(dev)
 
@@ -180,9 +195,83 @@ def cpu_baseline(args):
         n += 1
     dt = time.time() - t0
     return {"value": round(n * bs / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "cpu_model": cpu_model(), "kind": "port",
             "sample": "%d training steps of the CPU oracle (%s-MSML + %d-id head), batch %d, f32"
                       % (n, args.frb, args.classes, bs)}
+
+
+def pmc_traffic(label):
+    """HBM bytes per launch of `label` from the newest committed PMC summary (profiles/r*_pmc_traffic.json);
+    keys may carry a trailing ' [kernel]' that the event labels of weight gradients do not."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            pm = json.load(open(path))
+        except Exception:
+            continue
+        for k, v in pm.items():
+            if isinstance(v, dict) and (k == label or k.split(" [")[0] == label.split(" [")[0]) and "hbm_bytes" in v:
+                if k == label or best is None:
+                    best = v["hbm_bytes"]
+    return best
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def timed(fn, steps, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_modes(args, rank, local_rank):
+    """Short measurements of the other precision modes on the same workload (rank 0, N == 1), so that
+    every mode that meets the reference's tolerances has a number from the same run as the headline:
+      train_f32     exact-f32 MFMA training step (the parity mode of the training path)
+      infer_bf16x3  embedding extraction, orig + flip, split-bf16 (meets 1e-3 / bit-exact masks; default)
+      infer_bf16    the same in plain bf16 (throughput mode, ~8e-3 embedding error)."""
+    import copy
+    import gc
+    out = {}
+    a = copy.copy(args)
+    a.mode, a.batch = "infer", 1024
+    for prec in ("bf16x3", "bf16"):
+        a.dtype, a.precision = "bf16", prec
+        r = Inferer(a, rank, local_rank, 1)
+        dt = timed(r.step, 4, 2)
+        out["infer_" + prec] = {"value": round(a.batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 2),
+                                "batch": a.batch, "what": "%s-MSML embedding extraction, orig + h-flip" % args.frb}
+        del r
+        gc.collect()
+        torch.cuda.empty_cache()
+    a = copy.copy(args)
+    a.dtype, a.mode, a.precision = "f32", "train", None
+    from msml_amd import ops
+    ops.WGRAD_STREAM = ops.OSB_STREAM = None
+    ops.INPLACE_GRADS = False
+    ops.GRAD_READY = None
+    r = Trainer(a, rank, local_rank, 1)
+    dt = timed(r.step, 2, 1)
+    out["train_f32"] = {"value": round(a.batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 2),
+                        "batch": a.batch, "what": "the headline training step on the exact-f32 MFMA path"}
+    del r
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -256,8 +345,11 @@ def main():
             # RCCL collectives are captured too (verified with a 1-rank communicator); the
             # watchdog thread of ProcessGroupNCCL must not trip the capture -> thread_local mode
             mode = "thread_local" if dist.is_initialized() else "global"
+            if os.environ.get("MSML_GRAPH_STREAMS"):      # experiment: keep the three-stream fork / join
+                eager_mode(True)
             with torch.cuda.graph(graph, capture_error_mode=mode):
                 out = runner.step(static)
+            eager_mode(False)
             graph.replay()
             barrier()
             t0 = time.perf_counter()
@@ -330,9 +422,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    evs = step_events[-(args.steps + 1):]
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else None
     if os.environ.get("MSML_BENCH_STEP_TIMES"):
-        evs = step_events[-(args.steps + 1):]
-        print("step ms:", " ".join("%.0f" % evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)),
+        print("step ms:", " ".join("%.0f" % v for v in step_ms),
               "| reserved GB %.1f" % (torch.cuda.memory_reserved() / 2 ** 30), file=sys.stderr)
     # roofline pass: the same step, eagerly, with a HIP-event pair around every instrumented
     # launch (events cannot be recorded inside a graph replay); kernel durations are unaffected
@@ -359,7 +453,9 @@ def main():
                                                                      "training" if args.mode == "train" else "embedding-extraction"),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "ms_per_step_median": None if median_ms is None else round(median_ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": getattr(runner, "precision", args.dtype),
         "data": "synthetic",
         "config": {"workload": "%s-MSML (OSB r18 + FM x4) + %d-id ArcFace PartialFC, 112x112, batch %d/GPU, %s"
                                % (args.frb, args.classes, args.batch,
@@ -391,28 +487,50 @@ def main():
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": None,
                            "launches": k["n"], "avg_us": round(k["ms"] * 1e3 / k["n"], 2)}
-        # the single most frequent launch (one shape, one kernel): achieved from its own events,
-        # HBM traffic from the committed rocprofv3 PMC run of the same launch
-        convs = {n: v for n, v in prof.items() if n.startswith("conv ")}
-        top = max(convs, key=lambda n: convs[n]["ms"])
-        tv = convs[top]
+        # the dominant launch of the step over conv forward / backward-data AND weight-gradient labels
+        # (one shape, one kernel): achieved from its own events, HBM traffic from the committed rocprofv3
+        # PMC run of the same launch (profiles/*_pmc_traffic.json, keyed by the label)
+        cands = {n: v for n, v in prof.items() if n.startswith("conv ") or n.startswith("wgrad ")}
+        top = max(cands, key=lambda n: cands[n]["ms"])
+        tv = cands[top]
         tach = tv["flops"] / (tv["ms"] * 1e-3) / 1e12
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if top in pm:
-                traffic = pm[top]["hbm_bytes"]
-        except Exception:
-            pass
-        rec["roofline"] = {"bound": "mfma", "kernel": top[top.index("[") + 1:-1] if "[" in top else "conv", "launch": top,
-                           "achieved": round(tach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(tach / peak, 4), "traffic": traffic,
+        rec["roofline"] = {"bound": "mfma", "kernel": top[top.index("[") + 1:-1] if "[" in top else top.split()[0],
+                           "launch": top, "achieved": round(tach, 2), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(tach / peak, 4), "traffic": pmc_traffic(top),
                            "algorithmic_flop": tv["flops"] / tv["n"], "launches": tv["n"],
                            "avg_us": round(tv["ms"] * 1e3 / tv["n"], 2)}
+        # and the heaviest launch of the OTHER family, so that neither hides behind the other
+        for famname, pre in (("roofline_conv", "conv "), ("roofline_wgrad", "wgrad ")):
+            sub = {n: v for n, v in prof.items() if n.startswith(pre)}
+            if not sub:
+                continue
+            t2 = max(sub, key=lambda n: sub[n]["ms"])
+            v2 = sub[t2]
+            a2 = v2["flops"] / (v2["ms"] * 1e-3) / 1e12
+            rec[famname] = {"launch": t2, "achieved": round(a2, 2), "frac": round(a2 / peak, 4), "unit": "TFLOP/s",
+                            "launches": v2["n"], "avg_us": round(v2["ms"] * 1e3 / v2["n"], 2),
+                            "ms_per_step": round(v2["ms"] / prof_steps, 3), "traffic": pmc_traffic(t2)}
+        if "conv_wgrad" in fam:
+            kw = fam["conv_wgrad"]
+            aw = kw["flops"] / (kw["ms"] * 1e-3) / 1e12
+            rec["roofline_family_wgrad"] = {"bound": "mfma", "kernel": "k_wgrad_halo / k_wgrad_fast (+ slab reduce)",
+                                            "achieved": round(aw, 2), "peak": peak, "unit": "TFLOP/s",
+                                            "frac": round(aw / peak, 4), "launches": kw["n"],
+                                            "avg_us": round(kw["ms"] * 1e3 / kw["n"], 2)}
         rec["kernels"] = {name: {"ms_per_step": round(v["ms"] / prof_steps, 3), "launches_per_step": v["n"] // prof_steps,
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                                  "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                           for name, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+    if world == 1 and not args.no_extra_modes and args.mode == "train" and args.dtype == "bf16":
+        runner = None
+        graph = static = out = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            rec["modes"] = extra_modes(args, rank, local_rank)
+        except Exception as e:                                  # pragma: no cover (diagnostic path)
+            rec["modes"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline and args.mode == "train":
         rec["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(rec), flush=True)

@@ -279,6 +279,17 @@ int msml_x3_add(const void* a, const void* b, void* out, long M, int C, void* st
 int msml_x3_from_f32(const float* src, void* dst, long M, int C, void* stream);
 int msml_x3_to_f32(const void* src, float* dst, long M, int C, void* stream);
 
+/* ---------------------------------------------------------------- verification metrics -----------
+ * Device side of eval/verification.py:54-199 (calculate_roc / calculate_val: 10-fold accuracy over a
+ * threshold grid, TAR @ FAR).  msml_pair_sqdist: emb [2*n_pairs][E] f32, rows (2i, 2i+1) = pair i ->
+ * dist[i] = || a/|a| - b/|b| ||^2 in f64 (:298-301,78-79).  msml_pair_hist: hist[nfolds][2][nthr + 1]
+ * int32, hist[f][s][k] = number of pairs of KFold test fold f (shuffle=False) with issame == s whose
+ * first threshold index with dist < thr[k] is k (k == nthr: none); every tp / fp / tn / fn of every
+ * threshold and fold is a prefix sum of it.  thr: ascending f64 grid (np.arange(0, 4, 0.01 | 0.001)). */
+int msml_pair_sqdist(const float* emb, int n_pairs, int E, double* dist, void* stream);
+int msml_pair_hist(const double* dist, const unsigned char* same, int n_pairs, const double* thr, int nthr,
+                   int nfolds, int* hist, void* stream);
+
 /* Backward-data conv fused with the backward REDUCE of the BatchNorm(+PReLU) that produced the
  * conv's input in the forward (IBasicBlock: bn1 -> conv1, bn2 -> prelu -> conv2,
  * backbones/frb/iresnet.py:59-64): the conv output dX is that BatchNorm's dy, so the epilogue

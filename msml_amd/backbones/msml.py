@@ -86,6 +86,7 @@ class MSML(nn.Module):
         # reference, the outputs the north-star tolerances are stated for; "bf16" = plain bf16 operands,
         # ~3x the throughput at ~5e-3 embedding error.  Training with fp16=True is always bf16.
         self.eval_precision = os.environ.get("MSML_EVAL_PRECISION", "bf16x3")
+        self.x3_chunk = 256
 
     def forward(self, x, label=None, ori=None):
         if not x.is_cuda:
@@ -93,6 +94,13 @@ class MSML(nn.Module):
         if not self.use_osb:
             raise NotImplementedError("msml_amd: use_osb=False is not built")
         from .. import ops
+        if (self.fp16 and not self.training and not torch.is_grad_enabled() and self.eval_precision == "bf16x3"
+                and x.shape[0] > self.x3_chunk):
+            # split-bf16 maps hold 6 B per element: a 112 x 112 x 64-channel map of more than ~440 images
+            # passes the 2 GiB range of a buffer descriptor.  Images are independent in eval mode, so
+            # the batch is processed in chunks (bit-identical results, see the batch-composition test).
+            outs = [self.forward(x[i:i + self.x3_chunk], label, ori) for i in range(0, x.shape[0], self.x3_chunk)]
+            return tuple(torch.cat(t) for t in zip(*outs))
         ops.PACKS.refresh_if_stale()      # one batched repack after a FlatSGD step
         ops.DEFER_BN_COUNTERS = True      # num_batches_tracked: one foreach add per forward
         try:
