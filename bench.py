@@ -46,6 +46,9 @@ def parse():
                     help="inference precision with --dtype bf16 (default: the model's default, bf16x3)")
     ap.add_argument("--no-extra-modes", action="store_true",
                     help="skip the short extra measurements of the other precision modes (rank 0, N == 1)")
+    ap.add_argument("--emulate-world", type=int, default=1,
+                    help="config 4 sizing on ONE GPU: run the head as rank 0 of an E-way class-parallel job "
+                         "(classes/E local rows, batch*E gathered feature rows, collectives omitted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
@@ -77,8 +80,14 @@ class Trainer:
         for p in self.model.classification.parameters():   # live full-class head unused here
             p.requires_grad_(False)
         self.model.train()
-        self.pfc = PartialFC(rank, local_rank, world, args.batch, False,
-                             ArcMargin(64.0, 0.48, 0.0, 0.0), args.classes, fp16=fp16)
+        self.emu = max(1, args.emulate_world)
+        if self.emu > 1:
+            assert world == 1
+            self.pfc = PartialFC(0, local_rank, 1, args.batch * self.emu, False, ArcMargin(64.0, 0.48, 0.0, 0.0),
+                                 args.classes // self.emu, fp16=fp16)
+        else:
+            self.pfc = PartialFC(rank, local_rank, world, args.batch, False,
+                                 ArcMargin(64.0, 0.48, 0.0, 0.0), args.classes, fp16=fp16)
         self.opt = FlatSGD(reference_param_groups(self.model, args.batch, world), 0.9, 5e-4, 5.0)
         if world > 1 or os.environ.get("MSML_FORCE_DIST"):
             self.opt.enable_overlap(world)
@@ -117,6 +126,12 @@ class Trainer:
             seg_loss.backward()
             x_grad, loss_v = self.pfc.forward_backward(label, fn, self.opt_pfc)
             fn.backward(x_grad)
+        elif self.emu > 1:
+            # rank 0 of an emu-way job: batch * emu gathered rows against classes / emu local rows (rows
+            # whose class lives elsewhere map to -1 exactly as on a real rank)
+            xg, loss_v = self.pfc.forward_backward(label.repeat(self.emu), fn.detach().repeat(self.emu, 1), self.opt_pfc)
+            x_grad = xg[:fn.shape[0]] * float(self.emu)
+            torch.autograd.backward([fn, seg_loss], [x_grad, None])
         else:
             # one engine call: the OSB nodes, created first, run last (as its own call the OSB backward
             # measured 1 % slower at world size 1 -- 4 ms of host time before the FRB backward starts)
@@ -215,6 +230,33 @@ def pmc_traffic(label):
                 if k == label or best is None:
                     best = v["hbm_bytes"]
     return best
+
+
+def memory_table(runner, args):
+    """HBM sizing of the run (288 GB per GPU): torch's allocator counters plus
+    the resident state by owner; activations = peak minus resident state."""
+    gb = 2.0 ** 30
+    t = {"hbm_capacity_gb": round(torch.cuda.get_device_properties(0).total_memory / gb, 1),
+         "max_allocated_gb": round(torch.cuda.max_memory_allocated() / gb, 2),
+         "reserved_gb": round(torch.cuda.memory_reserved() / gb, 2),
+         "allocated_now_gb": round(torch.cuda.memory_allocated() / gb, 2)}
+    if args.mode != "train":
+        return t
+    bb = runner.opt.flat_w.numel() * 4
+    hw = runner.opt_pfc.flat_w.numel() * 4
+    n_rows = args.batch * max(runner.world, runner.emu)
+    ncls = runner.pfc.num_local
+    el = 2 if args.dtype == "bf16" else 4
+    resident = 3 * bb + 3 * hw
+    t.update({
+        "backbone_params_grads_momentum_gb": round(3 * bb / gb, 3),
+        "head_rows": ncls, "head_weight_grad_momentum_gb": round(3 * hw / gb, 3),
+        "head_normalised_copy_and_transpose_gb": round(2 * ncls * 512 * el / gb, 3),
+        "head_logits_f32_gb": round(n_rows * ncls * 4 / gb, 3),
+        "head_dcos_gb": round(n_rows * ncls * el / gb, 3),
+        "activations_and_workspaces_peak_gb": round((torch.cuda.max_memory_allocated() - resident) / gb, 2),
+    })
+    return t
 
 
 def cpu_model():
@@ -468,6 +510,11 @@ def main():
     }
     if args.mode == "train" and out[0] is not None:
         rec["loss"] = round(float(out[0]), 4)
+    rec["memory"] = memory_table(runner, args)
+    if args.mode == "train" and runner.emu > 1:
+        rec["config"]["head"] = ("rank 0 of a %d-way class-parallel %d-id head emulated on one GPU: %d local rows x %d "
+                                 "gathered feature rows, collectives omitted" % (runner.emu, args.classes,
+                                 args.classes // runner.emu, args.batch * runner.emu))
     if prof:
         # aggregate the per-shape event records into kernel families
         fam = {}

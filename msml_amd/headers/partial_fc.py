@@ -169,6 +169,7 @@ class PartialFC(Module):
             backend = HipBackend(BF16 if fp16 else F32)
         self.backend = backend
         self.eps_ls = 0.1
+        self._stage = None            # collectives staged through the host (gloo group, device tensors)
         self._flat = None             # FlatSGD that re-homed sub_weight (adopt_flat_optimizer)
         self._label_job = None        # (id, total_label, event, label) of a prefetched label gather
         self.perm_fn = None           # tests: replaces torch.rand in sample()
@@ -248,12 +249,42 @@ class PartialFC(Module):
     def _dist(self):
         return self.world_size > 1 or _FORCE
 
+    def _staged(self):
+        """gloo moves host memory only (its CUDA support covers broadcast / all_reduce): under a gloo
+        group with device tensors -- the two-ranks-on-one-GPU test, debugging without RCCL -- the
+        collectives are staged through the host.  RCCL (backend 'nccl') works on device memory."""
+        if self._stage is None:
+            self._stage = self.device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "gloo"
+        return self._stage
+
     def _all_gather(self, x):
         if not self._dist():
             return x.clone()
+        if self._staged():
+            xc = x.contiguous().cpu()
+            out = torch.empty((xc.shape[0] * self.world_size,) + tuple(xc.shape[1:]), dtype=xc.dtype)
+            dist.all_gather_into_tensor(out, xc)
+            return out.to(x.device)
         out = torch.empty((x.shape[0] * self.world_size,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x.contiguous())
         return out
+
+    def _reduce_scatter(self, dx_total, like):
+        if self._staged():
+            out = torch.empty(like.shape, dtype=torch.float32)
+            dist.reduce_scatter_tensor(out, dx_total.contiguous().cpu())
+            return out.to(like.device)
+        out = torch.empty_like(like, dtype=torch.float32)
+        dist.reduce_scatter_tensor(out, dx_total.contiguous())
+        return out
+
+    def _all_reduce_sum(self, t):
+        if self._staged():
+            c = t.cpu()
+            dist.all_reduce(c, dist.ReduceOp.SUM)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, dist.ReduceOp.SUM)
 
     def prefetch_labels(self, label):
         """Start the label all-gather + local mapping on the side stream (partial_fc.py:107-110); call it
@@ -318,11 +349,9 @@ class PartialFC(Module):
             self.sub_weight.grad = dw
         if self._dist():
             # the critical collective first: dX feeds the backbone backward
-            x_grad = torch.empty_like(features, dtype=torch.float32)
-            dist.reduce_scatter_tensor(x_grad, dx_total.contiguous())
-            x_grad = x_grad * self.world_size
+            x_grad = self._reduce_scatter(dx_total, features) * self.world_size
             # loss: the target probability lives on exactly one rank per row -> SUM (8 KB, logged only)
-            dist.all_reduce(ptarget, dist.ReduceOp.SUM)
+            self._all_reduce_sum(ptarget)
         else:
             x_grad = dx_total
         loss_v = ptarget.clamp_min(1e-30).log().mean() * (-1)

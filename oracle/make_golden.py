@@ -50,7 +50,9 @@ def checksum(t):
 def pick(t, n=64):
     """n evenly spaced elements of the flattened tensor (fp32)."""
     f = t.detach().reshape(-1)
-    idx = torch.linspace(0, f.numel() - 1, n).long()
+    # (f32 linspace is exact below 2**24 elements -- every golden; f64 beyond, where f32 would round
+    # the last index past the end)
+    idx = torch.linspace(0, f.numel() - 1, n, dtype=torch.float32 if f.numel() < 2 ** 24 else torch.float64).long()
     return f[idx].float().numpy()
 
 

@@ -1,5 +1,7 @@
 import os
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -12,6 +14,45 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """GPU runs: start the two ranks of test_partial_fc_hip_two_ranks_one_gpu NOW, as fresh child
+    processes, before this process has initialised the GPU (a process that has touched the GPU must not
+    fork + exec on this pool; counting devices does not initialise it).  The test only collects them."""
+    config = session.config
+    config._pfc_ranks = None
+    expr = getattr(config.option, "markexpr", "") or ""
+    if "gpu" not in expr or "not gpu" in expr or os.environ.get("MSML_NO_RANK_CHILDREN"):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    outdir = tempfile.mkdtemp(prefix="pfc_ranks_")
+    port = str(29700 + os.getpid() % 200)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs = []
+    for r in range(2):
+        log = open(os.path.join(outdir, "r%d.log" % r), "w")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pfc_gpu_rank.py"), str(r), "2",
+                                       port, outdir], stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT))
+    config._pfc_ranks = (procs, outdir)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    ranks = getattr(session.config, "_pfc_ranks", None)
+    if ranks:
+        for p in ranks[0]:
+            if p.poll() is None:
+                p.kill()
+
+
+@pytest.fixture(scope="session")
+def pfc_rank_results(request):
+    return request.config._pfc_ranks
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,49 @@
+"""One rank of the two-ranks-on-one-GPU PartialFC test (started by tests/conftest.py as a FRESH process
+before the pytest process touches the GPU; see test_partial_fc_hip_two_ranks_one_gpu).  Each rank
+initialises the GPU itself, joins a gloo group, runs PartialFC.forward_backward on the HIP backend
+(f32 and bf16) against device 0 and writes its results."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from msml_amd.headers.partial_fc import ArcMargin, PartialFC
+    from oracle.inputs import PFC_B, PFC_C, PFC_E, pfc_inputs
+    from tests.helpers import pick
+    feat, label, w = pfc_inputs(world, rank)
+    out = {}
+    for tag, fp16 in (("f32", False), ("bf16", True)):
+        p = PartialFC(rank, 0, world, PFC_B, False, ArcMargin(64.0, 0.48, 0.0, 0.0), PFC_C,
+                      embedding_size=PFC_E, fp16=fp16)
+        assert p.weight.shape == w.shape and p.weight.is_cuda
+        with torch.no_grad():
+            p.weight.copy_(w)
+        opt = torch.optim.SGD([{"params": p.parameters()}], lr=0.1 / 512 * PFC_B * world, momentum=0.9,
+                              weight_decay=5e-4)
+        p.prefetch_labels(label.cuda())              # the side-stream label gather
+        x_grad, loss_v = p.forward_backward(label.cuda(), feat.cuda(), opt)
+        wgrad = p.sub_weight.grad.clone()
+        opt.step()
+        torch.cuda.synchronize()
+        out[tag + "_loss"] = loss_v.item()
+        out[tag + "_x_grad"] = x_grad.cpu().numpy()
+        out[tag + "_wgrad_pick"] = pick(wgrad, 256)
+        out[tag + "_wnew_pick"] = pick(p.sub_weight.data, 256)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), **out)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
