@@ -46,6 +46,10 @@ def parse():
                     help="inference precision with --dtype bf16 (default: the model's default, bf16x3)")
     ap.add_argument("--no-extra-modes", action="store_true",
                     help="skip the short extra measurements of the other precision modes (rank 0, N == 1)")
+    ap.add_argument("--data", default="resident", choices=["resident", "device-synth"],
+                    help="resident: 4 synthetic batches resident in HBM (the contract's timed region); "
+                         "device-synth: uint8 faces from pinned host memory through msml_amd.data.DeviceLoaderX "
+                         "(H2D on a side stream + occlusion / flip / light / normalise kernels) every step")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="config 4 sizing on ONE GPU: run the head as rank 0 of an E-way class-parallel job "
                          "(classes/E local rows, batch*E gathered feature rows, collectives omitted)")
@@ -105,8 +109,16 @@ class Trainer:
             lab = synthetic.labels(args.batch, args.classes, seed=seed)
             self.batches.append((x.to(dev), msk.to(dev), lab.to(dev)))
         self.it = 0
+        self.loader = None
+        if getattr(args, "data", "resident") == "device-synth":
+            from msml_amd import data
+            self.loader = iter(data.DeviceLoaderX(data.SynthFaceSource(args.batch, args.classes, steps=None, seed=1 + rank),
+                                                  local_rank, seed=1 + rank, mode="train", want_ori=False))
 
     def next_batch(self):
+        if self.loader is not None:
+            img, msk, _, lab = next(self.loader)
+            return img, msk, lab
         b = self.batches[self.it % len(self.batches)]
         self.it += 1
         return b
@@ -300,6 +312,20 @@ def extra_modes(args, rank, local_rank):
         del r
         gc.collect()
         torch.cuda.empty_cache()
+    a = copy.copy(args)
+    a.data = "device-synth"
+    from msml_amd import ops
+    r = Trainer(a, rank, local_rank, 1)
+    side, osb = torch.cuda.Stream(), torch.cuda.Stream()
+    ops.WGRAD_STREAM, ops.OSB_STREAM = side, osb
+    dt = timed(r.step, 6, 3)
+    ops.WGRAD_STREAM = ops.OSB_STREAM = None
+    out["train_bf16_device_input"] = {"value": round(a.batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 2),
+                                      "batch": a.batch, "what": "the headline step fed by msml_amd.data.DeviceLoaderX: uint8 faces "
+                                      "from pinned host memory, H2D + occlusion / flip / light / normalise on the GPU every step"}
+    del r
+    gc.collect()
+    torch.cuda.empty_cache()
     a = copy.copy(args)
     a.dtype, a.mode, a.precision = "f32", "train", None
     from msml_amd import ops
@@ -498,7 +524,7 @@ def main():
         "ms_per_step_median": None if median_ms is None else round(median_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": getattr(runner, "precision", args.dtype),
-        "data": "synthetic",
+        "data": "synthetic" if args.data == "resident" else "synthetic uint8 faces, device input pipeline (H2D + occlusion synthesis per step)",
         "config": {"workload": "%s-MSML (OSB r18 + FM x4) + %d-id ArcFace PartialFC, 112x112, batch %d/GPU, %s"
                                % (args.frb, args.classes, args.batch,
                                   "fwd+bwd+clip+SGD" if args.mode == "train" else "orig+flip forward"),

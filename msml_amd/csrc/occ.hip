@@ -1,0 +1,182 @@
+// Device input pipeline: occlusion synthesis + flip + Gaussian light +
+// normalisation on the GPU, producing (img, msk, ori) from decoded uint8 faces.
+//
+// Replaces the per-sample CPU work of FaceByRandOccMask.__getitem__ (datasets/load_dataset.py:101-139):
+//   _get_occluded_face_and_mask  -> RandomRect (datasets/augment/rand_occ.py:103-139), RandomEllipse
+//                                   (:148-203, analytic ellipse instead of cv2's rasteriser), NoneOcc (:80-90),
+//                                   RandomBlock (:43-72, evaluation)
+//   random horizontal flip       -> load_dataset.py:119-123
+//   _add_gauss_to_face           -> load_dataset.py:183-201 with _get_gauss :282-339 (Euclidean, radius 128)
+//   Msk2Tenser / Normalize       -> mask 0 = occluded, 1 = clean (load_dataset.py:37); (x - 0.5) / 0.5
+// Facial-mask records (mask_out.rec), polygon / glasses / scarf / real-object occluders need the dataset's
+// assets and are not synthesised.
+//
+// Random draws come from a counter-based generator (splitmix64 of seed, image index, draw index): the
+// same (seed, offset) gives the same batch on any launch geometry, and the CPU oracle regenerates it.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+// every float expression below is restated operation by operation on the CPU (oracle/occ.py): no FMA
+// contraction, so that truncations to int agree bit for bit
+#pragma clang fp contract(off)
+
+#define OCC_DESC 16      // int32 words per image
+enum { OCC_NONE = 0, OCC_RECT = 1, OCC_ELLIPSE = 2, OCC_BLOCK = 3 };
+// desc: 0 kind | 1 x0 / cx | 2 y0 / cy | 3 w / aw | 4 h / ah | 5,6,7 r g b | 8 flip | 9 light cx (f32 bits)
+//       10 light cy (f32 bits) | 11 light scale (f32 bits) | 12..15 reserved
+
+__host__ __device__ inline unsigned long long occ_mix(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline unsigned int occ_u32(unsigned long long seed, unsigned long long img, int k) {
+  return (unsigned int)(occ_mix(occ_mix(seed) + img * 64ULL + (unsigned long long)k) >> 32);
+}
+// integer in [a, b) (np.random.randint(a, b)): multiply-shift, no rejection
+__host__ __device__ inline int occ_randint(unsigned int u, int a, int b) {
+  return a + (int)(((unsigned long long)u * (unsigned long long)(b - a)) >> 32);
+}
+// uniform f32 in [0, 1) with 24 bits
+__host__ __device__ inline float occ_unif(unsigned int u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+
+// mode 0: training mix -- kind uniform over {rect, ellipse, none}; mode 1: RandomRect only;
+// mode 2: RandomBlock(lo, hi, 'black') (evaluation); mode 3: no occlusion.
+__global__ void k_occ_draw(unsigned long long seed, unsigned long long offset, int N, int H, int W, int mode, int lo,
+                           int hi, int flip_on, int* __restrict__ desc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const unsigned long long img = offset + (unsigned long long)i;
+  int d[OCC_DESC];
+  for (int k = 0; k < OCC_DESC; k++) d[k] = 0;
+  int kind = OCC_NONE;
+  if (mode == 0) {
+    const int pick = occ_randint(occ_u32(seed, img, 0), 0, 3);
+    kind = pick == 0 ? OCC_RECT : (pick == 1 ? OCC_ELLIPSE : OCC_NONE);
+  } else if (mode == 1) kind = OCC_RECT;
+  else if (mode == 2) kind = OCC_BLOCK;
+  if (kind == OCC_RECT) {                       // rand_occ.py:113-121
+    const int pct = occ_randint(occ_u32(seed, img, 1), lo, hi);
+    const float ratio = (float)pct * 0.01f;
+    const int area = (int)((float)(W * H) * ratio);
+    const int ow = occ_randint(occ_u32(seed, img, 2), (int)((float)W * ratio) + 1, W + 1);
+    const int oh = area / ow;
+    d[1] = occ_randint(occ_u32(seed, img, 3), 0, W - ow + 1);
+    d[2] = occ_randint(occ_u32(seed, img, 4), 0, H - oh + 1);
+    d[3] = ow;
+    d[4] = oh;
+    for (int c = 0; c < 3; c++) d[5 + c] = occ_randint(occ_u32(seed, img, 5 + c), 0, 256);
+    if (oh == 0) kind = OCC_NONE;
+  } else if (kind == OCC_ELLIPSE) {             // rand_occ.py:184-199
+    const int ch = occ_randint(occ_u32(seed, img, 1), H / 5, 4 * H / 5);
+    const int cw = occ_randint(occ_u32(seed, img, 2), W / 5, 4 * W / 5);
+    const int mh = ch < H - ch ? ch : H - ch;
+    const int ah = occ_randint(occ_u32(seed, img, 3), 20, mh > 20 ? mh : 21);
+    const float ratio = 0.2f + (0.4f - 0.2f) * occ_unif(occ_u32(seed, img, 4));
+    const int aw = (int)((float)(H * W) * ratio / (3.14f * (float)ah));
+    d[1] = cw; d[2] = ch; d[3] = aw; d[4] = ah;
+    for (int c = 0; c < 3; c++) d[5 + c] = occ_randint(occ_u32(seed, img, 5 + c), 1, 256);
+  } else if (kind == OCC_BLOCK) {               // rand_occ.py:36-70
+    const int pct = occ_randint(occ_u32(seed, img, 1), lo, hi);
+    const float ratio = (float)pct * 0.01f;
+    const int bw = (int)sqrtf(ratio * (float)W * (float)W);
+    if (pct == 0 || bw == 0) kind = OCC_NONE;
+    else {
+      d[1] = occ_randint(occ_u32(seed, img, 2), 0, W - bw + 1);
+      d[2] = occ_randint(occ_u32(seed, img, 3), 0, W - bw + 1);
+      d[3] = bw; d[4] = bw;
+    }
+  }
+  d[0] = kind;
+  d[8] = flip_on ? (occ_randint(occ_u32(seed, img, 8), 1, 11) >= 5 ? 1 : 0) : 0;    // load_dataset.py:120
+  d[9] = __float_as_int((float)W * occ_unif(occ_u32(seed, img, 9)));              // _get_gauss :307-309
+  d[10] = __float_as_int((float)H * occ_unif(occ_u32(seed, img, 10)));
+  d[11] = __float_as_int(0.7f + (1.4f - 0.7f) * occ_unif(occ_u32(seed, img, 11)));  // :194
+  for (int k = 0; k < OCC_DESC; k++) desc[i * OCC_DESC + k] = d[k];
+}
+
+__device__ __forceinline__ bool occ_inside(const int* d, int x, int y) {
+  const int kind = d[0];
+  if (kind == OCC_RECT || kind == OCC_BLOCK) return x >= d[1] && x < d[1] + d[3] && y >= d[2] && y < d[2] + d[4];
+  if (kind == OCC_ELLIPSE) {
+    const float dx = (float)(x - d[1]), dy = (float)(y - d[2]);
+    const float aw = (float)d[3], ah = (float)d[4];
+    return dx * dx * ah * ah + dy * dy * aw * aw <= aw * aw * ah * ah;
+  }
+  return false;
+}
+
+// One workgroup per image.  src: [N][H][W][3] uint8 (decoded RGB, HWC).  img / ori: [N][3][H][W] f32,
+// msk: [N][H][W] int64.  light != 0: Gaussian light on img (not on ori, load_dataset.py:126-127).
+__global__ void __launch_bounds__(256) k_occ_apply(const unsigned char* __restrict__ src, const int* __restrict__ desc,
+                                                   float* __restrict__ img, long* __restrict__ msk,
+                                                   float* __restrict__ ori, int H, int W, int light) {
+  __shared__ int d[OCC_DESC];
+  __shared__ float red[4];
+  const int n = blockIdx.x, t = threadIdx.x;
+  if (t < OCC_DESC) d[t] = desc[n * OCC_DESC + t];
+  __syncthreads();
+  const int HW = H * W;
+  const unsigned char* s = src + (long)n * HW * 3;
+  float* o = img + (long)n * 3 * HW;
+  const bool flip = d[8] != 0;
+  const float lcx = __int_as_float(d[9]), lcy = __int_as_float(d[10]), lscale = __int_as_float(d[11]);
+  auto lightmap = [&](int x, int y) -> float {
+    // _get_gauss: integer-truncated offsets (astype(int16)), Euclidean distance, sigma 128, float16 map
+    const int ix = (int)((float)x - lcx), iy = (int)((float)y - lcy);
+    const float dist = sqrtf((float)(ix * ix + iy * iy));
+    const float g = expf(-0.5f * (dist * dist) / 16384.0f);
+    const __half g16 = __float2half(g);
+    const __half l16 = __float2half(__half2float(g16) * __half2float(__float2half(lscale)));
+    return __half2float(l16);
+  };
+  float vmax = 0.f;
+  for (int p = t; p < HW; p += 256) {
+    const int y = p / W, x = p - y * W;
+    const int sx = flip ? W - 1 - x : x;          // occlude -> flip: tests run in source coordinates
+    const bool in = occ_inside(d, sx, y);
+    const unsigned char* q = s + ((long)y * W + sx) * 3;
+    msk[(long)n * HW + p] = in ? 0 : 1;
+    const float l = light ? lightmap(x, y) : 1.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float clean = (float)q[c] / 255.0f;                       // ToTensor
+      if (ori) ori[((long)n * 3 + c) * HW + p] = (clean - 0.5f) / 0.5f;
+      float v = in ? (d[0] == OCC_BLOCK ? 0.f : (float)d[5 + c] / 255.0f) : clean;
+      v *= l;
+      o[(long)c * HW + p] = v;
+      vmax = fmaxf(vmax, v);
+    }
+  }
+  if (light) {                                    // out_img / out_img.max()  (load_dataset.py:199)
+    vmax = wave_max(vmax);
+    if ((t & 63) == 0) red[t >> 6] = vmax;
+    __syncthreads();
+    vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+  }
+  for (int p = t; p < 3 * HW; p += 256) {
+    float v = o[p];
+    if (light) v = v / vmax;
+    o[p] = (v - 0.5f) / 0.5f;                      // Normalize(0.5, 0.5)
+  }
+}
+
+extern "C" int msml_occ_draw(long seed, long offset, int N, int H, int W, int mode, int lo, int hi,
+                             int flip, int* desc, void* stream) {
+  MSML_CHECK(desc && N > 0 && H >= 32 && W >= 32 && mode >= 0 && mode <= 3 && lo >= 0 && hi > lo && hi <= 101,
+             MSML_ERR_SHAPE, "occ_draw: bad arguments N=%d H=%d W=%d mode=%d lo=%d hi=%d", N, H, W, mode, lo, hi);
+  k_occ_draw<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>((unsigned long long)seed, (unsigned long long)offset, N, H, W, mode, lo, hi, flip, desc);
+  MSML_LAUNCH_OK("occ_draw");
+  return MSML_OK;
+}
+
+extern "C" int msml_occ_apply(const unsigned char* src, const int* desc, float* img, long* msk, float* ori, int N,
+                              int H, int W, int light, void* stream) {
+  MSML_CHECK(src && desc && img && msk && N > 0 && H > 0 && W > 0, MSML_ERR_SHAPE, "occ_apply: bad arguments");
+  k_occ_apply<<<N, 256, 0, (hipStream_t)stream>>>(src, desc, img, msk, ori, H, W, light);
+  MSML_LAUNCH_OK("occ_apply");
+  return MSML_OK;
+}
