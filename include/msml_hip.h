@@ -77,6 +77,28 @@ int msml_fm_fuse_fwd(const void* x, const void* yf, void* z, long n, int act, in
 int msml_fm_fuse_bwd(const void* dz, const void* x, const void* yf, void* dx, void* dyf,
                      long n, int act, int arith, int dtype, void* stream);
 
+/* Peer-guided branch of the FM operators (backbones/fm/fmoperator.py:293-308) and dropout
+ * (backbones/frb/iresnet.py:231).  n elements (a multiple of 8), storage dtype.
+ *   msml_fm_act_fwd / _bwd : M = act(x) as a tensor (the input of conv_m, :294-296) / dx = dM * act'(x)
+ *   msml_mul_fwd / _bwd    : m_bar * identity, m_bar * yt (:297,300); da / db may be NULL
+ *   msml_axpb              : y = a*x + b ('invert' mask transform 1 - M, :163-164)
+ *   msml_mse_fwd / _bwd    : torch.nn.MSELoss()(f_occ, f_out) (:302): loss[0] = sum (a-b)^2 / count (f64
+ *                            partial sums, fixed order; workspace >= 2048 doubles); da = 2 g (a-b) / count,
+ *                            db = -da with g a device scalar
+ *   msml_dropout           : y = x * keep / (1 - p), keep from a counter-based hash of (seed, index); the
+ *                            backward is the same call on dy */
+int msml_fm_act_fwd(const void* x, void* m, long n, int act, int dtype, void* stream);
+int msml_fm_act_bwd(const void* dm, const void* x, void* dx, long n, int act, int dtype, void* stream);
+int msml_mul_fwd(const void* a, const void* b, void* out, long n, int dtype, void* stream);
+int msml_mul_bwd(const void* g, const void* a, const void* b, void* da, void* db, long n, int dtype,
+                 void* stream);
+int msml_axpb(const void* x, void* y, long n, float a, float b, int dtype, void* stream);
+int msml_mse_fwd(const void* a, const void* b, long n, double count, float* loss, double* workspace,
+                 long ws_doubles, int dtype, void* stream);
+int msml_mse_bwd(const void* a, const void* b, const float* g, double count, void* da, void* db, long n,
+                 int dtype, void* stream);
+int msml_dropout(const void* x, void* y, long n, float p, long seed, int dtype, void* stream);
+
 /* ---------------------------------------------------------------- convolution -------------
  * Implicit-GEMM convolution on MFMA.  Replaces nn.Conv2d / nn.ConvTranspose2d / nn.Linear
  * forward and backward-data at: backbones/frb/iresnet.py:56-67,209,232 (IBasicBlock, stem,

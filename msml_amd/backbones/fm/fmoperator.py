@@ -40,13 +40,17 @@ class resblock_bottle(nn.Module):
         return conv_bn(self.conv3, self.bn3, out, prelu=self.prelu3, residual=x, res_first=True)
 
 
+def _cbp(c):
+    """[conv3x3 + bias, BN, PReLU] x 2 (fmoperator.py:136-152)."""
+    return nn.Sequential(nn.Conv2d(c, c, 3, 1, 1), nn.BatchNorm2d(c, eps=1e-05), nn.PReLU(c),
+                         nn.Conv2d(c, c, 3, 1, 1), nn.BatchNorm2d(c, eps=1e-05), nn.PReLU(c))
+
+
 class FMCnn(nn.Module):
     def __init__(self, height, width, channel_f, kernel_size=3, resblocks=2, activation="tanh",
                  arith_strategy="add", peer_params: dict = None):
         super().__init__()
         peer_params = peer_params or {}
-        if peer_params.get("use_ori"):
-            raise NotImplementedError("msml_amd: peer-guided FM branch (use_ori) is not built yet")
         self.height, self.width, self.channel_f = height, width, channel_f
         if kernel_size == 1:
             self.same_conv = nn.Conv2d(18 + channel_f, channel_f, 1, bias=False)
@@ -58,16 +62,54 @@ class FMCnn(nn.Module):
             raise KeyError((activation, arith_strategy))
         self.activation = activation
         self.arith_strategy = arith_strategy
-        self.use_ori = False
+        # Part 5, peer distillation (fmoperator.py:130-166)
+        self.use_ori = bool(peer_params.get("use_ori"))
+        en_conv = peer_params.get("use_conv")
         self.conv1 = nn.Sequential()
         self.conv2 = nn.Sequential()
-        self.conv_m = nn.Sequential()
+        if self.use_ori and en_conv:
+            self.conv1 = _cbp(channel_f)
+            self.conv2 = _cbp(channel_f)
+        mask_trans = peer_params.get("mask_trans")
+        self.invert = False
+        if not self.use_ori:
+            self.conv_m = nn.Sequential()
+        elif mask_trans == "conv":
+            self.conv_m = nn.Sequential(nn.Conv2d(channel_f, channel_f, 3, 1, 1),
+                                        nn.BatchNorm2d(channel_f, eps=1e-05))
+        elif mask_trans == "invert":
+            self.conv_m = nn.Sequential()
+            self.invert = True
+        else:
+            raise ValueError("mask_trans type error")
         self.en_save = False
 
+    @staticmethod
+    def _chain(seq, x):
+        """[conv + bias, BN, PReLU] x 2, or the identity for an empty container (use_conv False)."""
+        if len(seq) == 0:
+            return x
+        x = conv_bn(seq[0], seq[1], x, prelu=seq[2])
+        return conv_bn(seq[3], seq[4], x, prelu=seq[5])
+
     def forward(self, yf, yo, yt=None):
+        if yo is None:
+            raise TypeError("FMCnn needs the OSB mask maps (use_osb=False only works with fm_layers=(0,0,0,0), "
+                            "as in the reference: torch.cat((yf, None)) fails there)")
         x, _ = conv(self.same_conv, yf, yo, c1=18)
         x = self.res_block(x)
-        return Fh.fm_fuse(x, yf, self.activation, self.arith_strategy), None
+        if not self.use_ori:
+            return Fh.fm_fuse(x, yf, self.activation, self.arith_strategy), None
+        # peer-guided branch (fmoperator.py:293-308): the mask is needed as a tensor
+        m = Fh.fm_act(x, self.activation)
+        m_bar = Fh.axpb(m, -1.0, 1.0) if self.invert else conv_bn(self.conv_m[0], self.conv_m[1], m)
+        f_out = self._chain(self.conv1, Fh.mul(m_bar, yf))
+        l2 = None
+        if yt is not None:
+            f_occ = self._chain(self.conv2, Fh.mul(m_bar, yt))
+            l2 = Fh.mse(f_occ, f_out, self.channel_f)
+        z = Fh.fm_fuse(x, yf, self.activation, self.arith_strategy)          # arith(yf, M) + yf
+        return Fh.add(z, f_out), l2
 
 
 class FMNone(nn.Module):

@@ -73,8 +73,6 @@ class IResNet(nn.Module):
                  peer_params: dict = None):
         super().__init__()
         peer_params = peer_params or {}
-        if peer_params.get("use_ori") or peer_params.get("use_decoder"):
-            raise NotImplementedError("msml_amd: peer-guided KD / decoder branches are not built yet")
         self.fp16 = fp16
         self.conv1 = nn.Conv2d(3, 64, kernel_size=3, stride=1, padding=1, bias=False)
         self.bn1 = nn.BatchNorm2d(64, eps=1e-05)
@@ -91,8 +89,27 @@ class IResNet(nn.Module):
         self.features.weight.requires_grad = False
         assert len(fm_ops) == 4
         self.fm_ops = nn.ModuleList(fm_ops)
+        # Peer (frozen teacher; its type follows msml.header_type, iresnet.py:126-144)
+        from ..peer import arcface18, arcface34, arcface50, cosface50_casia
         self.peer = None
         self.header_type = str(peer_params.get("header_type", "")).lower()
+        if peer_params.get("use_ori"):
+            layers = list(layers)
+            if "arc" in self.header_type:
+                ctor = {(2, 2, 2, 2): arcface18, (3, 4, 6, 3): arcface34, (3, 4, 14, 3): arcface50}.get(tuple(layers))
+                if ctor is not None:
+                    self.peer = ctor().requires_grad_(False)
+            elif "cos" in self.header_type:
+                if layers == [3, 4, 14, 3]:
+                    self.peer = cosface50_casia().requires_grad_(False)
+            else:
+                raise ValueError("Error type of iresnet, cannot decide peer network.")
+        # Recover decoder (iresnet.py:146-150): parameters only -- its output and loss are dead in the
+        # reference, so forward() below does not run it
+        self.decoder = None
+        if peer_params.get("use_decoder"):
+            from ..decoder import dm_decoder
+            self.decoder = dm_decoder(n_init=dim_feature)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.normal_(m.weight, 0, 0.1)
@@ -108,17 +125,26 @@ class IResNet(nn.Module):
         """x: NHWC image; segs: [seg3, seg2, seg1, seg0] NHWC 18-channel maps (detached).
         wait_segs: event after which `segs` are valid (OSB running on another stream).
         Returns (feature (B, dim) f32, kd)."""
-        if ori is not None:
-            raise NotImplementedError("msml_amd: `ori` (peer knowledge) is not built yet")
+        ft = (None, None, None, None)
+        if ori is not None:                       # peer knowledge (iresnet.py:203-206)
+            if self.peer is None:
+                raise TypeError("'NoneType' object is not callable: `ori` given but no peer network was built "
+                                "(peer_params.use_ori False)")
+            _, ft = self.peer.forward_nhwc(ori)
         x = conv_bn(self.conv1, self.bn1, x, prelu=self.prelu)
+        kd = None
         for k in range(4):
             x = getattr(self, "layer%d" % (k + 1))(x)
             if k == 0 and wait_segs is not None:
                 torch.cuda.current_stream().wait_event(wait_segs)
-            x, _ = self.fm_ops[k](x, segs[k], None)
+            x, l = self.fm_ops[k](x, segs[k], ft[k])
+            if ori is not None:                   # l + l1 + l2 + l3 (iresnet.py:234)
+                kd = l if kd is None else kd + l
         x = Fh.bn_act(x, None, self.bn2)
+        # (recover decoder: `_rec, l4 = self.decoder(x, ori) if ori is not None else None, 0.` gives l4 = 0
+        # and discards _rec in the reference, iresnet.py:228,235 -- nothing to compute)
         if self.dropout.p > 0 and self.training:
-            raise NotImplementedError("msml_amd: dropout > 0 is not built (reference config uses 0)")
+            x = Fh.dropout(x, self.dropout.p)
         # flatten(C,H,W) + Linear(25088, 512): skinny GEMM on the NHWC-ordered operand
         n, h, w, c = x.shape
         if isinstance(x, Fh.SplitT):
@@ -127,7 +153,7 @@ class IResNet(nn.Module):
             wview = self.fc.weight.view(self.fc.out_features, c, h, w)
             y = Fh.flat_fc(x, wview, self.fc.bias, self.fc.weight)
         y = Fh.bn_act(y, None, self.features)
-        return Fh.to_vec(y, self.fc.out_features), 0.0
+        return Fh.to_vec(y, self.fc.out_features), (kd * 1.0 if kd is not None else 0.0)
 
 
 def _iresnet(layers, fm_ops, pretrained, **kw):

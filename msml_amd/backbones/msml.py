@@ -91,8 +91,6 @@ class MSML(nn.Module):
     def forward(self, x, label=None, ori=None):
         if not x.is_cuda:
             raise RuntimeError("msml_amd.MSML runs on an MI355X only (no CPU path); got a CPU tensor")
-        if not self.use_osb:
-            raise NotImplementedError("msml_amd: use_osb=False is not built")
         from .. import ops
         if (self.fp16 and not self.training and not torch.is_grad_enabled() and self.eval_precision == "bf16x3"
                 and x.shape[0] > self.x3_chunk):
@@ -115,7 +113,16 @@ class MSML(nn.Module):
         x3 = (self.fp16 and not self.training and not torch.is_grad_enabled()
               and self.eval_precision == "bf16x3")
         xh = Fh.RawImage(x.float(), x3=x3) if self.fp16 else Fh.to_nhwc(x, F32)
+        if ori is not None:
+            ori = Fh.RawImage(ori.float()) if self.fp16 else Fh.to_nhwc(ori, F32)
         side = ops.OSB_STREAM
+        if not self.use_osb:                      # msml.py:159-161: no masks (FMNone stages only)
+            feature, kd = self.frb(xh, (None, None, None, None), ori)
+            if self.training:
+                if label is None:
+                    return feature, None, kd
+                return self.classification(feature, label) + kd, None, kd
+            return feature, None
         if side is None:
             seg_list = self.osb(xh)                # [seg0, seg1, seg2, seg3, seg5]
             osb_done = None

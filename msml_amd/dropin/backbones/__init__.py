@@ -28,6 +28,8 @@ _alias.alias(__name__, {
     "osb.unet": "msml_amd.backbones.osb.unet",
     "peer": "msml_amd.backbones.peer",
     "peer.arcface": "msml_amd.backbones.peer.arcface",
+    "decoder": "msml_amd.backbones.decoder",
+    "decoder.deepmind": "msml_amd.backbones.decoder.deepmind",
 }, stubs={
     "frb.iresnet": {n: "backbones/frb/iresnet.py:366-405 (IResNetVanilla)" for n in
                     ("iresnet18_v", "iresnet28_v", "iresnet34_v", "iresnet50_v", "iresnet100_v",

@@ -879,3 +879,136 @@ def flat_fc_x3(x, fc_m):
     wp = hit[1]
     y = ops.gemm_splitk(x.t.reshape(n, h * w * 3 * c), wp, cpad(e))
     return (y[:, :e] + fc_m.bias.detach()).reshape(n, 1, 1, e)
+
+
+# ---------------------------------------------------------------------------------------------
+# Peer-guided FM branch (fmoperator.py:293-308), MSE distillation loss, dropout.
+class _FmAct(torch.autograd.Function):
+    """M = act(x) materialised (the input of conv_m)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        m = torch.empty_like(x)
+        call("msml_fm_act_fwd", x, m, x.numel(), act, DTYPE_OF[x.dtype])
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        call("msml_fm_act_bwd", dm.contiguous(), x, dx, x.numel(), ctx.act, DTYPE_OF[x.dtype])
+        return dx, None
+
+
+def fm_act(x, act):
+    return _FmAct.apply(x, ACTS[act])
+
+
+class _Mul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        call("msml_mul_fwd", a, b, out, a.numel(), DTYPE_OF[a.dtype])
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        call("msml_mul_bwd", g.contiguous(), a, b, da, db, a.numel(), DTYPE_OF[a.dtype])
+        return da, db
+
+
+def mul(a, b):
+    return _Mul.apply(a, b)
+
+
+class _Axpb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, b):
+        y = torch.empty_like(x)
+        call("msml_axpb", x, y, x.numel(), float(a), float(b), DTYPE_OF[x.dtype])
+        ctx.a = a
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        dx = torch.empty_like(g)
+        call("msml_axpb", g.contiguous(), dx, g.numel(), float(ctx.a), 0.0, DTYPE_OF[g.dtype])
+        return dx, None, None
+
+
+def axpb(x, a, b):
+    return _Axpb.apply(x, a, b)
+
+
+class _Mse(torch.autograd.Function):
+    """torch.nn.MSELoss()(a, b) over the REAL channels of two NHWC storage tensors (pad channels are zero
+    in both and do not contribute to the sum; `count` is the real element count)."""
+
+    @staticmethod
+    def forward(ctx, a, b, count):
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        ws = torch.empty(2048, dtype=torch.float64, device=a.device)
+        call("msml_mse_fwd", a, b, a.numel(), float(count), loss, ws, ws.numel(), DTYPE_OF[a.dtype])
+        ctx.save_for_backward(a, b)
+        ctx.count = count
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        gs = g.reshape(1).float().contiguous()
+        call("msml_mse_bwd", a, b, gs, float(ctx.count), da, db, a.numel(), DTYPE_OF[a.dtype])
+        return da, db, None
+
+
+def mse(a, b, real_channels):
+    n, h, w, _ = a.shape
+    return _Mse.apply(a, b, n * h * w * real_channels)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        y = torch.empty_like(x)
+        call("msml_dropout", x, y, x.numel(), float(p), int(seed), DTYPE_OF[x.dtype])
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed = ctx.cfg
+        dx = torch.empty_like(g)
+        call("msml_dropout", g.contiguous(), dx, g.numel(), float(p), int(seed), DTYPE_OF[g.dtype])
+        return dx, None, None
+
+
+_DROP_COUNTER = [0]
+
+
+def dropout(x, p, seed=None):
+    """nn.Dropout(p) in training mode on a storage tensor (iresnet.py:231); the mask comes from a
+    counter-based hash, a fresh seed per call unless one is given."""
+    if seed is None:
+        _DROP_COUNTER[0] += 1
+        seed = (torch.initial_seed() * 1000003 + _DROP_COUNTER[0]) & 0x7FFFFFFFFFFFFFFF
+    return _Dropout.apply(x, p, seed)
+
+
+def relu_res(x, residual=None):
+    """relu(x [+ residual]) without autograd (DeepMind decoder, whose output the reference discards)."""
+    c = x.shape[-1]
+    m = x.numel() // c
+    dev = x.device
+    one = torch.ones(c, dtype=torch.float32, device=dev)
+    zero = torch.zeros(c, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    call("msml_bn_act_fwd", x, one, zero, zero, residual, 1, y, m, c, DTYPE_OF[x.dtype])
+    return y

@@ -15,6 +15,7 @@ Goldens:
   g6s the same with negative sampling (sample_rate 0.3 / 0.005): index, step, update()
   g7  StructureConsensuLossFunction values + input gradient
   g8  lr schedule table and param-group lr map
+  g9  peer-guided KD path: eval + one training step with `ori` (teacher, conv_m/conv1/conv2, MSE)
   fm  FMCnn x 4 stages x {sigmoid,tanh} x {add,sub,mul,div} checksums + slices
 """
 import contextlib
@@ -197,6 +198,75 @@ def g4b():
     torch.manual_seed(0)
     m = fill_module(ref_msml("iresnet18", C))
     np.savez_compressed(os.path.join(OUT, "g4_train_fill_b32.npz"), **train_step_record(m, 32, C))
+
+
+KD_PEER = {"use_ori": True, "use_conv": True, "mask_trans": "conv", "use_decoder": True}
+KD_PICKS = ["frb.conv1.weight", "frb.fm_ops.0.same_conv.weight", "frb.fm_ops.0.conv_m.0.weight",
+            "frb.fm_ops.0.conv_m.0.bias", "frb.fm_ops.0.conv_m.1.weight", "frb.fm_ops.2.conv1.0.weight",
+            "frb.fm_ops.1.conv1.3.bias", "frb.fm_ops.3.conv1.5.weight", "frb.layer3.1.conv2.weight",
+            "osb.deconv5.weight", "classification.weight"]
+KD_STATS = ["frb.peer.bn1.running_mean", "frb.peer.layer4.1.bn3.running_var", "frb.fm_ops.0.conv_m.1.running_var",
+            "frb.fm_ops.2.conv2.1.running_mean", "frb.bn1.running_mean"]
+
+
+def g9():
+    """Peer-guided KD path (config.yaml:22-26: use_ori, use_conv, mask_trans 'conv', use_decoder): frozen
+    teacher returning 4 intermediates (peer/arcface.py:159-194), FM conv_m / conv1 / conv2 + MSE
+    (fmoperator.py:293-308), decoder parameters (its loss is dead, F4).  The teacher checkpoint the
+    factories insist on (cwd-relative, peer/arcface.py:10-16) is a key-filled state dict written to a
+    temporary directory; every weight is then key-filled again through the MSML state dict."""
+    import tempfile
+    import backbones
+    from backbones.peer import arcface18
+    from tricks.consensus_loss import StructureConsensuLossFunction
+    C, bs = 1000, 4
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "backbones", "pretrained"))
+        torch.save(fill_module(arcface18(pretrained=False)).state_dict(),
+                   os.path.join(d, "backbones", "pretrained", "r18-backbone.pth"))
+        os.chdir(d)
+        try:
+            with contextlib.redirect_stdout(open(os.devnull, "w")):
+                m = backbones.MSML(frb_type="iresnet18", osb_type="unet", fm_layers=(1, 1, 1, 1), num_classes=C,
+                                   fp16=False, header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0),
+                                   fm_params=(3, 2, "sigmoid", "mul"), peer_params=dict(KD_PEER))
+        finally:
+            os.chdir(cwd)
+    torch.manual_seed(0)
+    fill_module(m)
+    rec = {"keys": np.array(list(m.state_dict().keys()))}
+    x, msk = eval_inputs(bs)
+    ori = synthetic.images(bs, seed=1)                 # the same faces before the occlusion was pasted
+    label = synthetic.labels(bs, C, seed=1)
+    # eval: the peer-guided branch still adds f_out (no peer knowledge needed at test time)
+    m.eval()
+    with torch.no_grad():
+        feat, final_seg = m(x)
+    rec["eval_feature"] = feat.numpy()
+    rec["eval_mask_bits"] = np.packbits(final_seg.max(1)[1].numpy().astype(np.uint8).reshape(-1))
+    # one training step with peer knowledge
+    m.train()
+    with contextlib.redirect_stderr(open(os.devnull, "w")):
+        seg_crit = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")
+    final_cls, final_seg, kd = m(x, label, ori)
+    seg_loss = seg_crit(final_seg, msk, msk)
+    cls_loss = torch.nn.CrossEntropyLoss()(final_cls, label)
+    (cls_loss + seg_loss).backward()
+    params = dict(m.named_parameters())
+    gnorm = torch.nn.utils.clip_grad_norm_([p for p in m.parameters() if p.grad is not None], 5, 2)
+    rec.update({"kd": np.float64(kd.item()), "seg_loss": np.float64(seg_loss.item()),
+                "cls_loss": np.float64(cls_loss.item()), "grad_norm": np.float64(float(gnorm)),
+                "final_cls_cs": checksum(final_cls)})
+    for n in KD_PICKS:
+        rec["grad_pick/" + n] = pick(params[n].grad, 32)
+    g2 = params["frb.fm_ops.3.conv2.0.weight"].grad          # reaches the loss only through kd: ~0 (F5)
+    rec["conv2_grad_absmax"] = np.float64(0.0 if g2 is None else g2.abs().max().item())
+    rec["no_grad_params"] = np.array([n for n, p in params.items() if p.grad is None])
+    sd = m.state_dict()
+    for n in KD_STATS:
+        rec["stat/" + n] = sd[n].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g9_kd_path.npz"), **rec)
 
 
 def g5():

@@ -95,21 +95,40 @@ _ARITH = {
 }
 
 
-class FMCnn(nn.Module):
-    """backbones/fm/fmoperator.py:84-311, peer/KD branch off (use_ori False).
+def _cbp(c):
+    """[conv3x3 + bias, BN, PReLU] x 2 (fmoperator.py:136-152)."""
+    return nn.Sequential(nn.Conv2d(c, c, 3, 1, 1), nn.BatchNorm2d(c, eps=EPS), nn.PReLU(c),
+                         nn.Conv2d(c, c, 3, 1, 1), nn.BatchNorm2d(c, eps=EPS), nn.PReLU(c))
 
-    M = act(res_block(same_conv(cat(yf, yo)))); z = arith(yf, M) + yf.
+
+class FMCnn(nn.Module):
+    """backbones/fm/fmoperator.py:84-311.
+
+    M = act(res_block(same_conv(cat(yf, yo)))); z = arith(yf, M) [+ f_out] + yf.  Peer-guided branch
+    (use_ori, :130-166,293-308): m_bar = conv_m(M) (conv3x3 + bias, BN) or 1 - M; f_out = conv1(m_bar * yf);
+    with peer knowledge yt: l2 = MSE(conv2(m_bar * yt), f_out).
     """
 
-    def __init__(self, channel_f, kernel_size=3, resblocks=2, activation="tanh", arith="add"):
+    def __init__(self, channel_f, kernel_size=3, resblocks=2, activation="tanh", arith="add", peer_params=None):
         super().__init__()
+        pp = peer_params or {}
         cin = channel_f + SEG_CH
         self.same_conv = _c3(cin, channel_f) if kernel_size != 1 else _c1(cin, channel_f)
         self.res_block = nn.Sequential(*[ResBottle(channel_f) for _ in range(resblocks)])
-        # empty containers keep the attribute layout of fmoperator.py:133-155 (no keys)
+        self.use_ori = bool(pp.get("use_ori"))
         self.conv1 = nn.Sequential()
         self.conv2 = nn.Sequential()
+        if self.use_ori and pp.get("use_conv"):
+            self.conv1, self.conv2 = _cbp(channel_f), _cbp(channel_f)
+        self.invert = False
         self.conv_m = nn.Sequential()
+        if self.use_ori:
+            if pp.get("mask_trans") == "conv":
+                self.conv_m = nn.Sequential(nn.Conv2d(channel_f, channel_f, 3, 1, 1), nn.BatchNorm2d(channel_f, eps=EPS))
+            elif pp.get("mask_trans") == "invert":
+                self.invert = True
+            else:
+                raise ValueError("mask_trans type error")
         self.act = activation
         self.arith = arith
 
@@ -118,7 +137,16 @@ class FMCnn(nn.Module):
 
     def forward(self, yf, yo, yt=None):
         m = self.mask(yf, yo)
-        return _ARITH[self.arith](yf, m) + yf, None
+        f_out, l2 = 0.0, None
+        if self.use_ori:
+            m_bar = (1 - m) if self.invert else self.conv_m(m)
+            f_out = self.conv1(m_bar * yf)
+            if yt is not None:
+                l2 = F.mse_loss(self.conv2(m_bar * yt), f_out)
+        z = _ARITH[self.arith](yf, m)
+        if self.use_ori:
+            z = z + f_out
+        return z + yf, l2
 
 
 class FMNone(nn.Module):
@@ -128,11 +156,70 @@ class FMNone(nn.Module):
         return yf, None
 
 
-class IResNetFRB(nn.Module):
-    """backbones/frb/iresnet.py:70-236 with peer/decoder off."""
+class PeerIResNet(nn.Module):
+    """backbones/peer/arcface.py:72-194: vanilla IResNet returning the embedding and 4 stage outputs."""
 
-    def __init__(self, layers, fm_ops, dim_feature=512, dropout=0.0):
+    def __init__(self, layers):
         super().__init__()
+        self.conv1 = _c3(3, 64)
+        self.bn1 = nn.BatchNorm2d(64, eps=EPS)
+        self.prelu = nn.PReLU(64)
+        cin = 64
+        for i, (c, n) in enumerate(zip(PLANES, layers)):
+            setattr(self, "layer%d" % (i + 1), _stage(cin, c, n))
+            cin = c
+        self.bn2 = nn.BatchNorm2d(512, eps=EPS)
+        self.dropout = nn.Dropout(p=0, inplace=True)
+        self.fc = nn.Linear(512 * 49, 512)
+        self.features = nn.BatchNorm1d(512, eps=EPS)
+        nn.init.constant_(self.features.weight, 1.0)
+        self.features.weight.requires_grad = False
+
+    def forward(self, x):
+        x = self.prelu(self.bn1(self.conv1(x)))
+        inter = []
+        for k in range(4):
+            x = getattr(self, "layer%d" % (k + 1))(x)
+            inter.append(x.detach())
+        x = self.features(self.fc(torch.flatten(self.bn2(x), 1)))
+        return x, inter
+
+
+class _DecResBlock(nn.Module):
+    """backbones/decoder/deepmind.py:20-34."""
+
+    def __init__(self, cin, c):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(cin, c, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(c, cin, 1))
+
+    def forward(self, x):
+        return F.relu(self.conv(x) + x)
+
+
+class Decoder(nn.Module):
+    """backbones/decoder/deepmind.py:60-103 (n_hid 64): 512 x 7 x 7 -> 3 x 112 x 112."""
+
+    def __init__(self, n_init=512, n_hid=64, out=3):
+        super().__init__()
+
+        def stage(cin):
+            return [nn.Conv2d(cin, 2 * n_hid, 3, padding=1), nn.ReLU(), _DecResBlock(2 * n_hid, 2 * n_hid // 4),
+                    _DecResBlock(2 * n_hid, 2 * n_hid // 4), nn.ConvTranspose2d(2 * n_hid, n_hid, 4, stride=2, padding=1),
+                    nn.ReLU(inplace=True)]
+        self.net = nn.Sequential(*(stage(n_init) + stage(n_hid) + stage(n_hid) +
+                                   [nn.ConvTranspose2d(n_hid, out, 4, stride=2, padding=1)]))
+
+    def forward(self, x, ori=None):
+        rec = self.net(x)
+        return rec, (F.mse_loss(rec, ori) if ori is not None else 0.0)
+
+
+class IResNetFRB(nn.Module):
+    """backbones/frb/iresnet.py:70-236."""
+
+    def __init__(self, layers, fm_ops, dim_feature=512, dropout=0.0, peer_params=None):
+        super().__init__()
+        pp = peer_params or {}
         self.conv1 = _c3(3, 64)
         self.bn1 = nn.BatchNorm2d(64, eps=EPS)
         self.prelu = nn.PReLU(64)
@@ -147,6 +234,10 @@ class IResNetFRB(nn.Module):
         nn.init.constant_(self.features.weight, 1.0)
         self.features.weight.requires_grad = False       # iresnet.py:118-120
         self.fm_ops = nn.ModuleList(fm_ops)
+        self.peer = None
+        if pp.get("use_ori"):                            # iresnet.py:126-144 (arc heads)
+            self.peer = PeerIResNet(layers).requires_grad_(False)
+        self.decoder = Decoder(dim_feature) if pp.get("use_decoder") else None      # :146-150
         # iresnet.py:152-157: every Conv2d (FM convs included) ~ N(0, 0.1); BN affine (1, 0)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -155,23 +246,31 @@ class IResNetFRB(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def stages(self, x, segs):
+    def stages(self, x, segs, ft=(None, None, None, None)):
         """Yield the per-stage tensors (layer output, FM output); used by per-stage goldens."""
         x = self.prelu(self.bn1(self.conv1(x)))
-        outs = []
+        outs, kd = [], None
         for k in range(4):
             x = getattr(self, "layer%d" % (k + 1))(x)
-            z, _ = self.fm_ops[k](x, segs[k], None)
+            z, l = self.fm_ops[k](x, segs[k], ft[k])
+            if l is not None:
+                kd = l if kd is None else kd + l
             outs.append((x, z))
             x = z
+        self._kd = kd
         return x, outs
 
     def forward(self, x, segs, ori=None):
-        x, _ = self.stages(x, segs)
+        ft = (None, None, None, None)
+        if ori is not None:
+            _, ft = self.peer(ori)
+        x, _ = self.stages(x, segs, ft)
         x = self.bn2(x)
+        # iresnet.py:228: the decoder runs but its loss is dropped (tuple precedence, SURVEY F4)
         x = self.dropout(torch.flatten(x, 1))
         x = self.features(self.fc(x))
-        return x, 0.0
+        kd = self._kd if (ori is not None and self._kd is not None) else 0.0
+        return x, kd * 1.0
 
 
 class GCM(nn.Module):
@@ -297,12 +396,12 @@ class MSML(nn.Module):
 
     def __init__(self, frb_type, osb_type="unet", fm_layers=(1, 1, 1, 1), num_classes=1000,
                  fm_params=(3, 2, "tanh", "add"), header_type="Softmax",
-                 header_params=(64.0, 0.5, 0.0, 0.0), dropout=0.0):
+                 header_params=(64.0, 0.5, 0.0, 0.0), dropout=0.0, peer_params=None):
         super().__init__()
         ks, nres, act, arith = fm_params
-        fm_ops = [FMCnn(PLANES[i], ks, nres, act, arith) if fm_layers[i] else FMNone()
+        fm_ops = [FMCnn(PLANES[i], ks, nres, act, arith, peer_params) if fm_layers[i] else FMNone()
                   for i in range(4)]
-        self.frb = IResNetFRB(FRB_LAYERS[frb_type], fm_ops, 512, dropout)
+        self.frb = IResNetFRB(FRB_LAYERS[frb_type], fm_ops, 512, dropout, peer_params)
         self.osb = Unet()
         s, m, a, k = header_params
         if header_type == "Softmax":

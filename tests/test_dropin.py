@@ -26,6 +26,8 @@ CALLER_IMPORTS = [
     "from backbones.peer.lightcnn import lightcnn29_v2",                 # :3
     "from backbones.peer import arcface18, arcface34, arcface50",        # frb/iresnet.py:127
     "from backbones.peer import cosface50_casia",                        # frb/iresnet.py:128
+    "from backbones.decoder import dm_decoder",                          # frb/iresnet.py:147
+    "from backbones.decoder.deepmind import dm_decoder",                 # backbones/decoder/__init__.py:1
     "from backbones.fm.fmoperator import FMCnn, FMNone",                 # backbones/fm/__init__.py:1
     "from backbones.osb.unet import unet",                               # backbones/osb/__init__.py:1
     "from backbones import MSML",

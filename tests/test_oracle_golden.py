@@ -247,3 +247,44 @@ def test_dap_identity():
     x = torch.randn(2, 18, 10, 10)
     ref = torch.nn.functional.avg_pool2d(torch.nn.functional.pixel_shuffle(x, 3), 3)
     assert torch.allclose(om.dap(x), ref, atol=1e-6)
+
+
+KD_PEER = {"use_ori": True, "use_conv": True, "mask_trans": "conv", "use_decoder": True}
+
+
+def test_g9_kd_path():
+    """Peer-guided KD path of the oracle (teacher intermediates, conv_m / conv1 / conv2 + MSE, dead decoder)
+    against the reference's golden: state-dict layout, eval output, one training step with `ori`."""
+    g = load("g9_kd_path.npz")
+    torch.manual_seed(0)
+    m = fill_module(om.MSML("iresnet18", "unet", (1, 1, 1, 1), 1000, fm_params=(3, 2, "sigmoid", "mul"),
+                            header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(KD_PEER)))
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    x, msk = eval_inputs(4)
+    ori = synthetic.images(4, seed=1)
+    label = synthetic.labels(4, 1000, seed=1)
+    m.eval()
+    with torch.no_grad():
+        feat, final_seg = m(x)
+    assert rel_err(feat.numpy(), g["eval_feature"]) < TOL
+    assert np.array_equal(np.packbits(om.mask_index(final_seg).numpy().astype(np.uint8).reshape(-1)), g["eval_mask_bits"])
+    m.train()
+    final_cls, final_seg, kd = m(x, label, ori)
+    seg_loss = om.consensus_loss(final_seg, msk)
+    cls_loss = torch.nn.functional.cross_entropy(final_cls, label)
+    (cls_loss + seg_loss).backward()
+    gnorm = torch.nn.utils.clip_grad_norm_([p for p in m.parameters() if p.grad is not None], 5, 2)
+    assert abs(kd.item() - g["kd"]) < 2e-4 * abs(g["kd"])
+    assert abs(seg_loss.item() - g["seg_loss"]) < 2e-4 * abs(g["seg_loss"])
+    assert abs(cls_loss.item() - g["cls_loss"]) < 2e-4 * abs(g["cls_loss"])
+    assert abs(float(gnorm) - g["grad_norm"]) < 1e-3 * abs(g["grad_norm"])
+    params = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith("grad_pick/"):
+            n = key.split("/", 1)[1]
+            assert rel_err(pick(params[n].grad, 32), g[key]) < 2e-3, n
+    assert set(n for n, p in params.items() if p.grad is None) == set(str(n) for n in g["no_grad_params"])
+    for key in g.files:
+        if key.startswith("stat/"):
+            n = key.split("/", 1)[1]
+            assert rel_err(m.state_dict()[n].numpy(), g[key]) < 1e-4, n
