@@ -330,8 +330,6 @@ def extra_modes(args, rank, local_rank):
     a.dtype, a.mode, a.precision = "f32", "train", None
     from msml_amd import ops
     ops.WGRAD_STREAM = ops.OSB_STREAM = None
-    ops.INPLACE_GRADS = False
-    ops.GRAD_READY = None
     r = Trainer(a, rank, local_rank, 1)
     dt = timed(r.step, 2, 1)
     out["train_f32"] = {"value": round(a.batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 2),

@@ -103,7 +103,7 @@ def _wgrad(dy, x, cp, xin=None):
     xin = (coef, alpha): x is the INPUT of the BatchNorm(+PReLU) in front of the conv (the
     activation was not materialised, see _bn_conv_fwd)."""
     wparam, (cout, cin, r, s), stride, ph, pw = cp
-    inplace = ops.INPLACE_GRADS and wparam.grad is not None
+    inplace = ops.inplace(wparam)
     dw = wparam.grad.view(wparam.shape) if inplace else torch.empty_like(wparam)
     side = ops.WGRAD_STREAM if inplace else None
     if side is not None:
@@ -153,7 +153,7 @@ class _ParamGrads:
     def __init__(self, params, c, dev):
         self.params = params
         self.want = [p is not None and p.requires_grad for p in params]
-        self.inplace = ops.INPLACE_GRADS and all((not w) or p.grad is not None for w, p in zip(self.want, params))
+        self.inplace = all((not w) or ops.inplace(p) for w, p in zip(self.want, params))
         if self.inplace:
             self.tg = [p.grad if w else None for w, p in zip(self.want, params)]
         else:

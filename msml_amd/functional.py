@@ -58,6 +58,7 @@ class _Conv(torch.autograd.Function):
         ctx.set_materialize_grads(False)       # no zeros tensor for the statistics output's "gradient"
         ctx.has_bias = bias is not None
         ctx.wparam = cfg.get("grad_param", weight)      # the leaf whose .grad receives dW
+        ctx.wobj = weight                               # the parameter object (pack-cache key)
         ctx.bparam = bias
         ctx.save_for_backward(x0, x1, weight)
         if stats is None:
@@ -85,16 +86,16 @@ class _Conv(torch.autograd.Function):
             if x is None or not ctx.needs_input_grad[i]:
                 continue
             if deconv:      # backward-data of a transposed conv = strided conv of dy
-                wp = ops.PACKS.get(w, False, off, ci, 0, cout, cout, 0, dtype)
+                wp = ops.PACKS.get(w, False, off, ci, 0, cout, cout, 0, dtype, owner=ctx.wobj)
                 grads[i], _ = ops.conv2d(dy, None, wp, None, cpad(ci), r, s, stride, ph, pw, False,
                                          p=h, q=wd, real=(cout, ci))
             else:           # backward-data of a conv = transposed gather of dy
-                wp = ops.PACKS.get(w, True, 0, cout, off, ci, cout, 0, dtype)
+                wp = ops.PACKS.get(w, True, 0, cout, off, ci, cout, 0, dtype, owner=ctx.wobj)
                 grads[i], _ = ops.conv2d(dy, None, wp, None, cpad(ci), r, s, stride, ph, pw, True,
                                          p=h, q=wd, real=(cout, ci))
         dw = None
         if ctx.needs_input_grad[2]:
-            inplace = ops.INPLACE_GRADS and ctx.wparam.grad is not None
+            inplace = ops.inplace(ctx.wparam)
             dw = ctx.wparam.grad.view(w.shape) if inplace else torch.empty_like(w)
             side = ops.WGRAD_STREAM if inplace else None
             if side is not None:                       # dW has no consumer before the optimizer
@@ -121,7 +122,7 @@ class _Conv(torch.autograd.Function):
             cp = dy.shape[-1]
             rows = ops.bn_stats_rows(m, cp)
             wsb = ops.workspace(rows * 2 * cp * 4, dy.device)
-            binplace = ops.INPLACE_GRADS and ctx.bparam.grad is not None
+            binplace = ops.inplace(ctx.bparam)
             db = ctx.bparam.grad if binplace else torch.empty(cout, dtype=torch.float32, device=dy.device)
             call("msml_bias_grad", dy, m, cp, cout, db, int(binplace), wsb, wsb.numel() // 4, dtype)
             if binplace:
@@ -187,8 +188,7 @@ class _BnAct(torch.autograd.Function):
         want = (has_g and ctx.needs_input_grad[2], has_b and ctx.needs_input_grad[3],
                 has_a and ctx.needs_input_grad[4])
         # parameter gradients go straight into the flat arena when FlatSGD owns the .grad views
-        inplace = ops.INPLACE_GRADS and all(
-            (not w) or prm.grad is not None for w, prm in zip(want, (gamma, beta, alpha_p)))
+        inplace = all((not w) or ops.inplace(prm) for w, prm in zip(want, (gamma, beta, alpha_p)))
         if inplace:
             tg = [prm.grad if w else None for w, prm in zip(want, (gamma, beta, alpha_p))]
         else:
@@ -498,7 +498,7 @@ class _FlatFc(torch.autograd.Function):
         n, h, w, c = x.shape
         e = weight.shape[0]
         dtype = DTYPE_OF[x.dtype]
-        wp = ops.PACKS.get(weight, False, 0, e, 0, c, c, 0, dtype)           # [E][H*W*C]
+        wp = ops.PACKS.get(weight, False, 0, e, 0, c, c, 0, dtype, owner=grad_param)      # [E][H*W*C]
         xf = x.reshape(n, h * w * c)
         if dtype == BF16:
             y = ops.gemm_splitk(xf, wp, cpad(e))
@@ -527,13 +527,13 @@ class _FlatFc(torch.autograd.Function):
                 dxf, _ = ops.conv2d(dy, None, wpt, None, k, 1, 1, 1, 0, 0, False, real=(e, k))
                 dx = dxf.reshape(n, h, w, c)
             else:
-                wt = ops.PACKS.get(weight, True, 0, e, 0, c, e, 0, dtype)
+                wt = ops.PACKS.get(weight, True, 0, e, 0, c, e, 0, dtype, owner=ctx.grad_param)
                 dx, _ = ops.conv2d(dy, None, wt, None, c, h, w, 1, 0, 0, True, p=h, q=w, real=(e, c))
         gp = ctx.grad_param
-        inplace = ops.INPLACE_GRADS and gp.grad is not None
+        inplace = ops.inplace(gp)
         dw = gp.grad.view(weight.shape) if inplace else torch.empty_like(weight)
         ops.conv_wgrad(dy, x, dw, e, c, c, 0, h, w, 1, 0, 0, accumulate=inplace)
-        binplace = ops.INPLACE_GRADS and bias.grad is not None
+        binplace = ops.inplace(bias)
         rows = ops.bn_stats_rows(n, e)
         wsb = ops.workspace(rows * 2 * e * 4, dy.device)
         db = bias.grad if binplace else torch.empty(e, dtype=torch.float32, device=dy.device)
@@ -654,7 +654,7 @@ class _StemConv(torch.autograd.Function):
         dw2 = torch.empty(cout, k, 1, 1, dtype=torch.float32, device=dy.device)
         ops.conv_wgrad(dy.contiguous(), col, dw2, cout, k, k, 0, 1, 1, 1, 0, 0)
         dw = dw2.view(cout, r, s, cin).permute(0, 3, 1, 2)          # back to the parameter's OIHW
-        if ops.INPLACE_GRADS and w.grad is not None:
+        if ops.inplace(w):
             w.grad.view(w.shape).add_(dw)
             ops.grad_ready(w)
             return None, None, None

@@ -2,6 +2,7 @@
 pass raw pointers.  Everything here requires the HIP library and a GPU tensor."""
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -71,11 +72,13 @@ class _Rec:
 
 PROFILE = _Profile()
 
-# When True (set by msml_amd.optim.FlatSGD) the backward kernels add parameter gradients
-# straight into the pre-zeroed param.grad views of the flat arena and autograd gets None for
-# them: no temporary gradient tensors and no AccumulateGrad add kernels (~470 tiny launches per
-# ires50 step).  Requires grads to be zeroed by FlatSGD.zero_grad() before every backward.
-INPLACE_GRADS = False
+# In-place parameter gradients.  A parameter whose .grad is a view into a flat gradient arena is marked
+# by the arena's owner (msml_amd.optim.FlatSGD sets `p._msml_arena = self`): the backward kernels then
+# add its gradient straight into that view and hand autograd None -- no temporary gradient tensors and no
+# AccumulateGrad add kernels (~470 tiny launches per ires50 step).  The mark is per PARAMETER, so two
+# models / optimizers in one process do not interfere; the owner zeroes the arena before every backward.
+def inplace(p):
+    return p is not None and p.grad is not None and getattr(p, "_msml_arena", None) is not None
 
 
 def cpad(c):
@@ -337,17 +340,15 @@ def flush_bn_counters():
         _PENDING_COUNTERS.clear()
 
 
-# Optional callback `fn(param)` invoked by the backward functions right after they have enqueued
-# the kernel that completes param.grad (in-place mode): FlatSGD uses it to launch the bucketed
-# gradient all-reduce while the rest of the backward is still running.
-GRAD_READY = None
-
-
+# A parameter may carry a callback `p._msml_ready(p)` (set by FlatSGD.enable_overlap): the backward functions
+# call it right after they have enqueued the kernel that completes p.grad in place, which lets the owner
+# launch the bucketed gradient all-reduce while the rest of the backward is still running.
 def grad_ready(*params):
-    if GRAD_READY is not None:
-        for p in params:
-            if p is not None:
-                GRAD_READY(p)
+    for p in params:
+        if p is not None:
+            cb = getattr(p, "_msml_ready", None)
+            if cb is not None:
+                cb(p)
 
 
 def wgrad_stream_join():
@@ -403,11 +404,15 @@ class PackCache:
     """Packed GEMM operands of every conv-like parameter, refreshed by ONE batched launch per
     optimizer step instead of ~260 small pack kernels (and the sliced parameter copies the
     backward-data packs needed).  Entries register themselves on first use; `refresh()` repacks
-    all of them; a use whose key (parameter version, WEIGHT_EPOCH, storage) is stale falls back
-    to an immediate single pack, so results never depend on refresh() having been called."""
+    all of them; a use whose stamp (parameter version, WEIGHT_EPOCH, storage address) is stale falls
+    back to an immediate single pack, so results never depend on refresh() having been called.
+
+    Entries are keyed on the PARAMETER OBJECT (id + a weak reference that is checked on every hit): a
+    parameter that dies takes its entries with it (no dead model is repacked forever), and a new
+    parameter that lands on a recycled address or id can never be served another parameter's operand."""
 
     def __init__(self):
-        self.entries = {}          # key -> dict(desc, dst, stamp)
+        self.entries = {}          # key -> dict(desc, dst, stamp, ref)
         self.stale_log = None      # debugging: list that collects every lazy (non-batched) repack
         self.table = None
         self.order = []
@@ -420,11 +425,21 @@ class PackCache:
     def _stamp(w):
         return (w._version, WEIGHT_EPOCH, w.data_ptr())
 
-    def get(self, w, transpose, a_off, a_n, b_off, b_n, c1, c2, dtype):
-        """Packed operand of the sub-block rows [a_off, a_off+a_n) x cols [b_off, b_off+b_n)."""
+    def _evict(self, key):
+        def cb(_ref):
+            self.entries.pop(key, None)
+            self.table = None
+        return cb
+
+    def get(self, w, transpose, a_off, a_n, b_off, b_n, c1, c2, dtype, owner=None):
+        """Packed operand of the sub-block rows [a_off, a_off+a_n) x cols [b_off, b_off+b_n) of w.
+        owner: the parameter `w` is a (whole-tensor) view of, when w itself is a temporary."""
+        own = w if owner is None else owner
         afull, bfull, r, s = w.shape
-        key = (w.data_ptr(), tuple(w.shape), transpose, a_off, a_n, b_off, b_n, c1, c2, dtype)
+        key = (id(own), (afull, bfull, r, s), transpose, a_off, a_n, b_off, b_n, c1, c2, dtype)
         e = self.entries.get(key)
+        if e is not None and e["ref"]() is not own:          # id reused by another object
+            e = None
         if e is None:
             ko = b_n if transpose else a_n
             kop = (cpad(ko) + tile_n(cpad(ko)) - 1) // tile_n(cpad(ko)) * tile_n(cpad(ko))
@@ -433,14 +448,14 @@ class PackCache:
             dst = torch.zeros(kop, ktot, dtype=TORCH_DTYPE[dtype], device=w.device)   # padding stays zero
             desc = [0, dst.data_ptr(), afull, bfull, a_off, a_n, b_off, b_n, r, s, int(transpose), c1,
                     c1p, c2, c2p, kop]
-            e = {"desc": desc, "dst": dst, "stamp": None, "w": w}
+            e = {"desc": desc, "dst": dst, "stamp": None, "ref": weakref.ref(own, self._evict(key))}
             self.entries[key] = e
             self.table = None
-        st = self._stamp(w)
+        st = self._stamp(own)
         if e["stamp"] != st:
             if self.stale_log is not None:
                 self.stale_log.append((tuple(w.shape), transpose, e["stamp"], st))
-            e["desc"][0] = w.data_ptr()
+            e["desc"][0] = own.data_ptr()
             t = torch.tensor([e["desc"]], dtype=torch.int64, device=w.device)
             call("msml_pack_weights_batched", t, 1, dtype)
             e["stamp"] = st
@@ -453,14 +468,16 @@ class PackCache:
     def refresh(self):
         """Repack every registered operand in one launch (call after the optimizer step)."""
         self.last_epoch = WEIGHT_EPOCH
-        if not self.entries:
+        live = [(e, e["ref"]()) for e in list(self.entries.values())]
+        live = [(e, w) for e, w in live if w is not None]
+        if not live:
             return
-        ents = list(self.entries.values())
-        ptrs = tuple(e["w"].data_ptr() for e in ents)
+        ents = [e for e, _ in live]
+        ptrs = tuple(w.data_ptr() for _, w in live)
         dtype = DTYPE_OF[ents[0]["dst"].dtype]
         if self.table is None or self.order != ptrs:
-            for e in ents:
-                e["desc"][0] = e["w"].data_ptr()
+            for e, w in live:
+                e["desc"][0] = w.data_ptr()
             dev = ents[0]["dst"].device
             self.table = torch.tensor([e["desc"] for e in ents], dtype=torch.int64, device=dev)
             tiles = [_lib.value("msml_pack_tiles", e["desc"][5], e["desc"][7], e["desc"][8], e["desc"][9]) for e in ents]
@@ -479,8 +496,8 @@ class PackCache:
             call("msml_pack_weights_tiled", self.table, self.prefix, len(ents), self.total_tiles, dtype)
         else:
             call("msml_pack_weights_batched", self.table, len(ents), dtype)
-        for e in ents:
-            e["stamp"] = self._stamp(e["w"])
+        for e, w in live:
+            e["stamp"] = self._stamp(w)
 
 
 WEIGHT_EPOCH = 0          # bumped by optimizers that update parameters behind torch's back

@@ -75,8 +75,8 @@ class FlatSGD:
             self.groups.append({"start": start, "end": off, "lr": g["lr"], "base_lr": g["lr"]})
         self.params = params
         self.steps = 0
-        from . import ops
-        ops.INPLACE_GRADS = True      # backward kernels accumulate into the arena views directly
+        for p in params:              # backward kernels accumulate into the arena views directly
+            p._msml_arena = self
         self.norm_coef = torch.ones(2, dtype=torch.float32, device=dev)
         self.ws = torch.empty(1024, dtype=torch.float32, device=dev)
 
@@ -88,6 +88,13 @@ class FlatSGD:
     def set_lr_factor(self, factor):
         for g in self.groups:
             g["lr"] = g["base_lr"] * factor
+
+    def release(self):
+        """Detach the parameters from the arena protocol (in-place gradients, overlap callbacks): they
+        behave like plain parameters again (their data / grad stay views of the arenas)."""
+        for p in self.params:
+            p.__dict__.pop("_msml_arena", None)
+            p.__dict__.pop("_msml_ready", None)
 
     def zero_grad(self):
         from . import ops
@@ -105,7 +112,7 @@ class FlatSGD:
     def enable_overlap(self, world_size, bucket_bytes=32 << 20):
         """Bucket the arena (contiguous ranges of ~bucket_bytes) and all-reduce every bucket on
         a communication stream as soon as the backward kernels of all its parameters have been
-        enqueued (ops.GRAD_READY callbacks from the in-place gradient path).  xGMI is a
+        enqueued (per-parameter `_msml_ready` callbacks from the in-place gradient path).  xGMI is a
         point-to-point mesh: a few tens of MB per message keep every link busy without
         serialising the tail of the backward behind one huge ring pass."""
         from . import ops
@@ -129,7 +136,8 @@ class FlatSGD:
         self.fired = [False] * len(self.buckets)
         self.works = []
         self.train_stream = torch.cuda.current_stream()     # refreshed by zero_grad()
-        ops.GRAD_READY = self._grad_ready
+        for p in self.params:
+            p._msml_ready = self._grad_ready
 
     def _fire(self, bi):
         from . import ops

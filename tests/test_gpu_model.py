@@ -261,7 +261,7 @@ def test_inplace_grads_match_autograd():
             opt = FlatSGD(reference_param_groups(m, 2, 1), 0.9, 5e-4, 5.0)
             opt.zero_grad()
         else:
-            ops.INPLACE_GRADS = False
+            pass
         cls, seg, _ = m(x.cuda(), label.cuda())
         loss = torch.nn.functional.cross_entropy(cls, label.cuda()) + \
             StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
@@ -381,7 +381,6 @@ def test_overlapped_allreduce_one_rank():
     def grads(overlap):
         m = hip_msml("iresnet18", 50, fp16=True).train()
         opt = FlatSGD(reference_param_groups(m, 2, 1), 0.9, 5e-4, 5.0)
-        ops.GRAD_READY = None
         if overlap:
             opt.enable_overlap(1, bucket_bytes=8 << 20)
         ops.WGRAD_STREAM = torch.cuda.Stream()
@@ -403,7 +402,6 @@ def test_overlapped_allreduce_one_rank():
         finally:
             ops.WGRAD_STREAM = None
             ops.OSB_STREAM = None
-            ops.GRAD_READY = None
     a, _ = grads(False)
     b, nb = grads(True)
     assert nb >= 4

@@ -79,7 +79,6 @@ def test_train_step_g4_bf16_fused_path(variant, bs):
         torch.cuda.synchronize()
     finally:
         ops.WGRAD_STREAM = ops.OSB_STREAM = None
-        ops.INPLACE_GRADS = False
     # the chained blocks really handed their bn3 sums over (ires18: one hand-off per stage, FRB + OSB)
     assert ops.COUNTERS["bn3_partial_hits"] - hits0 >= 6
     assert abs(seg_loss.item() - g["seg_loss"]) < tl * abs(g["seg_loss"])
@@ -318,3 +317,51 @@ def test_reference_param_groups_on_device_model():
         if p.requires_grad:
             assert abs(lr_of[id(p)] - want[n]) < 1e-12, n
     assert len(names) == len(lr_of)
+
+
+def test_pack_cache_is_keyed_on_live_parameters():
+    """ops.PACKS: steady state = no lazy repack and a constant entry count (entries are keyed on the
+    parameter objects, refreshed by ONE batched launch per optimizer step); a model that dies takes its
+    entries with it; a second model in the same process gets its own operands."""
+    import gc
+    from msml_amd import ops
+    from msml_amd.optim import FlatSGD, reference_param_groups
+    x, msk = eval_inputs(2)
+    label = synthetic.labels(2, 50, seed=1)
+
+    def steps(m, opt, n):
+        for _ in range(n):
+            opt.zero_grad()
+            cls, seg, _ = m(x.cuda(), label.cuda())
+            loss = torch.nn.functional.cross_entropy(cls, label.cuda()) + \
+                StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
+            loss.backward()
+            opt.step()
+    gc.collect()
+    base = len(ops.PACKS.entries)
+    m = hip_msml("iresnet18", 50, fp16=True).train()
+    opt = FlatSGD(reference_param_groups(m, 2, 1), 0.9, 5e-4, 5.0)
+    steps(m, opt, 2)
+    n_entries = len(ops.PACKS.entries)
+    assert n_entries - base > 100
+    ops.PACKS.stale_log = []
+    try:
+        steps(m, opt, 2)
+        assert len(ops.PACKS.entries) == n_entries
+        assert ops.PACKS.stale_log == [], ops.PACKS.stale_log[:3]        # every operand came from the batched refresh
+    finally:
+        ops.PACKS.stale_log = None
+    # a second model: same shapes, other parameters -> its own entries, results independent of the first
+    m2 = hip_msml("iresnet18", 50, fp16=True).train()
+    opt2 = FlatSGD(reference_param_groups(m2, 2, 1), 0.9, 5e-4, 5.0)
+    steps(m2, opt2, 1)
+    assert len(ops.PACKS.entries) == 2 * n_entries - base
+    w_before = opt.flat_w.clone()
+    steps(m2, opt2, 1)
+    assert torch.equal(opt.flat_w, w_before)                              # stepping m2 never touched m
+    del m2, opt2
+    gc.collect()
+    assert len(ops.PACKS.entries) == n_entries                            # dead parameters evict their operands
+    del m, opt
+    gc.collect()
+    assert len(ops.PACKS.entries) == base
