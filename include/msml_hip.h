@@ -139,6 +139,11 @@ int msml_conv_wgrad(const void* u, int up, const void* v, int vp, float* dw, int
                     int stride, int pad_h, int pad_w, int accumulate, void* workspace,
                     long ws_bytes, int dtype, void* stream);
 
+/* 1 when msml_conv_wgrad (bf16) runs this shape on the narrow-operand kernel (wgrad_n32.hip: both operands
+ * 32 stored channels, 4x4 / stride-2 transposed convs of the OSB decoder or 3x3 / stride-1). */
+int msml_conv_wgrad_kernel_is_n32(int up, int vp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                                  int pad_h, int pad_w);
+
 /* ---------------------------------------------------------------- BatchNorm / PReLU --------
  * nn.BatchNorm2d(eps=1e-5, momentum=0.1) + nn.PReLU + residual of IBasicBlock
  * (backbones/frb/iresnet.py:56-67, backbones/osb/unet.py:80-91), resblock_bottle

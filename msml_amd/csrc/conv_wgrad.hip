@@ -322,6 +322,11 @@ int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W
 bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
                             int splits, hipStream_t st, const BnIn* xin = nullptr);
 
+int msml_wgrad_n32_splits(int up, int vp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                          int pad_w);
+bool msml_wgrad_n32_launch(const void* u, const void* v, float* ws, int N, int H, int W, int P, int Q, int R,
+                           int stride, int splits, hipStream_t st);
+
 // taps handled by one workgroup of the bf16 fast kernel (narrow V operands share the U tile)
 static int wgrad_ntw(int vp, int taps) {
   static const bool off = getenv("MSML_WGRAD_NO_MULTITAP") != nullptr;
@@ -369,7 +374,15 @@ extern "C" long msml_conv_wgrad_workspace(int up, int vp, int N, int P, int Q, i
     int hs = msml_wgrad_halo_splits(up, vp, up, vp, N, P, Q, P, Q, 3, 3, 1, 1, 1);
     if (hs > splits) splits = hs;
   }
+  // narrow-operand kernel (wgrad_n32.hip): H / W are not known here, assume its largest split count
+  if (up == 32 && vp == 32 && (R * S == 16 || R * S == 9) && splits < 512) splits = 512;
   return (long)splits * up * R * S * vp * (long)sizeof(float);
+}
+
+// 1 when the bf16 weight gradient of this shape runs on the narrow-operand kernel (tests, profiling labels)
+extern "C" int msml_conv_wgrad_kernel_is_n32(int up, int vp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                                             int pad_h, int pad_w) {
+  return msml_wgrad_n32_splits(up, vp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0 ? 1 : 0;
 }
 
 extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, float* dw, int A,
@@ -404,6 +417,13 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   dim3 grid(atiles, btiles * taps, splits);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSML_BF16) {
+    const int ns = msml_wgrad_n32_splits(up, vp, N, H, W, P, Q, R, S, stride, pad_h, pad_w);
+    if (ns > 0 && msml_wgrad_n32_launch(u, v, a.ws, N, H, W, P, Q, R, stride, ns, st)) {
+      MSML_LAUNCH_OK("conv_wgrad(n32)");
+      wgrad_reduce_launch(a.ws, dw, ns, up, taps, vp, A, Breal, Btot, boff, accumulate, st);
+      MSML_LAUNCH_OK("conv_wgrad_reduce");
+      return MSML_OK;
+    }
     const int hs = msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w);
     if (hs > 0 && msml_wgrad_halo_launch(u, up, v, vp, a.ws, N, H, W, hs, st)) {
       MSML_LAUNCH_OK("conv_wgrad(halo)");

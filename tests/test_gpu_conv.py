@@ -450,3 +450,44 @@ def test_conv_bn_in_lds_refuses_other_shapes():
     rc = _lib.try_call("msml_conv2d_bnin", x, 512, coef[0], coef[1], None, wp, 512, out, 512, None, 4, 7, 7, 7, 7,
                        3, 3, 1, 1, 1)
     assert rc == _lib.UNSUPPORTED
+
+
+# Narrow-operand weight-gradient kernel (wgrad_n32.hip): (N, P, Q, kind) with kind 'd4' = 4x4 / stride-2
+# transposed conv on 18-channel maps (OSB deconv2..5: u = x on P x Q, v = dy on 2P x 2Q) and 'c3' = 3x3 /
+# stride-1 conv with 32 -> 32 channels (FM bottleneck).  Odd sizes exercise the strip / plane edges.
+WGRAD_N32 = [(3, 14, 14, "d4"), (2, 28, 28, "d4"), (2, 15, 17, "d4"), (5, 56, 56, "d4"),
+             (3, 14, 14, "c3"), (2, 56, 56, "c3"), (2, 19, 33, "c3")]
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("shape", WGRAD_N32)
+def test_conv_wgrad_n32(shape, accumulate):
+    n, p, q, kind = shape
+    g = torch.Generator().manual_seed(31 + p + q)
+    if kind == "d4":
+        cin, cout, k = 18, 18, 4
+        x = torch.randn(n, cin, p, q, generator=g).bfloat16().float()
+        wt = torch.zeros(cin, cout, k, k, dtype=torch.double, requires_grad=True)
+        y = F.conv_transpose2d(x.double(), wt, None, 2, 1)
+        dy = torch.randn(y.shape, generator=g).bfloat16().float()
+        y.backward(dy.double())
+        assert _lib.value("msml_conv_wgrad_kernel_is_n32", 32, 32, n, 2 * p, 2 * q, p, q, 4, 4, 2, 1, 1) == 1
+        dw = torch.full((cin, cout, k, k), 2.0, device="cuda")
+        ops.conv_wgrad(ops.to_nhwc(x.cuda(), _lib.BF16), ops.to_nhwc(dy.cuda(), _lib.BF16), dw, cin, cout, cout, 0,
+                       k, k, 2, 1, 1, accumulate=accumulate)
+        ref = wt.grad.float()
+    else:
+        cin, cout = 32, 32
+        x = torch.randn(n, cin, p, q, generator=g).bfloat16().float()
+        w = torch.zeros(cout, cin, 3, 3, dtype=torch.double, requires_grad=True)
+        y = F.conv2d(x.double(), w, None, 1, 1)
+        dy = torch.randn(y.shape, generator=g).bfloat16().float()
+        y.backward(dy.double())
+        assert _lib.value("msml_conv_wgrad_kernel_is_n32", 32, 32, n, p, q, p, q, 3, 3, 1, 1, 1) == 1
+        dw = torch.full((cout, cin, 3, 3), 2.0, device="cuda")
+        ops.conv_wgrad(ops.to_nhwc(dy.cuda(), _lib.BF16), ops.to_nhwc(x.cuda(), _lib.BF16), dw, cout, cin, cin, 0,
+                       3, 3, 1, 1, 1, accumulate=accumulate)
+        ref = w.grad.float()
+    if accumulate:
+        ref = ref + 2.0
+    assert (dw.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()     # bf16 operands, f32 sums

@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""Microbenchmark of the narrow / HBM-bound layers of the step (OSB decoder, FM bottleneck, stems, fc) at the
+BASELINE batch: time and achieved GB/s of algorithmic bytes per launch."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from msml_amd import _lib, ops  # noqa: E402
+from tools.bench_conv import timeit  # noqa: E402
+
+BF = _lib.BF16
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    rows = []
+    for p in (56, 28):
+        x = torch.randn(n, p, p, 32, device="cuda").bfloat16()
+        dy = torch.randn(n, 2 * p, 2 * p, 32, device="cuda").bfloat16()
+        dw = torch.empty(18, 18, 4, 4, device="cuda")
+        t = timeit(lambda: ops.conv_wgrad(x, dy, dw, 18, 18, 18, 0, 4, 4, 2, 1, 1))
+        rows.append(("deconv 4x4 s2 wgrad 18->18 @%d" % p, t, (x.numel() + dy.numel()) * 2))
+    x = torch.randn(n, 56, 56, 32, device="cuda").bfloat16()
+    dy = torch.randn(n, 56, 56, 32, device="cuda").bfloat16()
+    dw = torch.empty(32, 32, 3, 3, device="cuda")
+    t = timeit(lambda: ops.conv_wgrad(dy, x, dw, 32, 32, 32, 0, 3, 3, 1, 1, 1))
+    rows.append(("conv 3x3 s1 wgrad 32->32 @56", t, (x.numel() + dy.numel()) * 2))
+    for name, t, b in rows:
+        print("%-40s %8.1f us  %7.0f GB/s of algorithmic bytes" % (name, t * 1e6, b / t / 1e9))
+
+
+if __name__ == "__main__":
+    main()
