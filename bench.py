@@ -548,7 +548,7 @@ def main():
             for q in d:
                 d[q] += v[q]
         if os.environ.get("MSML_PROFILE_DETAIL"):
-            for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:45]:
+            for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("MSML_PROFILE_DETAIL") or 45) if os.environ.get("MSML_PROFILE_DETAIL", "1") != "1" else 45]:
                 print("%-52s n=%3d ms/step=%7.3f TF/s=%6.1f" % (name, v["n"] // prof_steps, v["ms"] / prof_steps,
                       v["flops"] / max(v["ms"], 1e-9) / 1e9), file=sys.stderr)
         peak = PEAK_TFLOPS[args.dtype]

@@ -532,6 +532,11 @@ static void launch_fast(ConvFastArgs& a, hipStream_t st) {
   a.tiles_m = cdiv(mtile, BM);
   dim3 grid(a.tiles_m, cdiv(a.coutp, BN), a.parity ? 4 : (a.ksplits > 1 ? a.ksplits : 1));
   size_t lds = (size_t)NST * (BM + BN) * 128;
+  // K of one stage (1x1 convs over <= 64 channels, the im2col'd stems): the ring never advances, so only
+  // one buffer is needed -- 2 - 3 workgroups fit a CU instead of 1 - 2 and their load / epilogue phases
+  // overlap (these launches are pure streaming: X in, Y out)
+  static const bool one_stage_ok = getenv("MSML_CONV_NO_ONE_STAGE") == nullptr;
+  if (one_stage_ok && NST == 2 && a.ksplits <= 1 && (a.nsub[0] + a.nsub[1] + 1) / 2 <= 1) lds = (size_t)(BM + BN) * 128;
   size_t olds = X3 ? (size_t)BM * (BN + 4) * 4 : (sizeof(TOUT) == 2 ? (size_t)BM * (BN + 8) * 2 : 0);
   if (olds > lds) lds = olds;
   if (lds > 64 * 1024) {                               // above the default dynamic-LDS limit

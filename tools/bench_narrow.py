@@ -33,3 +33,19 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def conv1x1():
+    """1x1 convs of the FM bottlenecks / stems: streaming launches (X in, Y out)."""
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    for cin, cout, h in ((32, 64, 112), (32, 64, 56), (64, 32, 56), (64, 128, 28), (128, 64, 28), (128, 256, 14)):
+        x = torch.randn(n, h, h, cin, device="cuda").bfloat16()
+        w = torch.randn(cout, cin, 1, 1, device="cuda") * 0.05
+        wp = ops.pack_weight(w, False, cin, 0, BF)
+        t = timeit(lambda: ops.conv2d(x, None, wp, None, cout, 1, 1, 1, 0, 0, False, want_stats=True))
+        b = (x.numel() + n * h * h * cout) * 2
+        print("%-40s %8.1f us  %7.0f GB/s of algorithmic bytes" % ("conv 1x1 %d->%d @%d (+stats)" % (cin, cout, h), t * 1e6, b / t / 1e9))
+
+
+if __name__ == "__main__":
+    conv1x1()
