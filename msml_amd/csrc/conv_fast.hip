@@ -50,6 +50,7 @@ struct ConvFastArgs {
                       // parity class, visiting only the taps that hit real input pixels
   int ksplits;        // > 1: split-K over stages, slice z writes f32 partials to out + z*split_stride
   long split_stride;
+  int lds_stages;     // A-tile stages actually allocated in LDS (set by launch_fast): B tiles start behind them
 };
 
 // exact m / d, m % d for 0 <= m < 2^24 via a float reciprocal (integer division costs ~40
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ABYTES = BM * 128, BBYTES = BN * 128;  // one stage of A / of B
   char* As = smem;                                     // [NST][BM][128 B]
-  char* Bs = smem + NST * ABYTES;                      // [NST][BN][128 B]
+  char* Bs = smem + p.lds_stages * ABYTES;             // [stages][BN][128 B]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int row0 = t >> 3;                             // RPP rows per pass, lane l -> LDS slot l
@@ -536,7 +537,11 @@ static void launch_fast(ConvFastArgs& a, hipStream_t st) {
   // one buffer is needed -- 2 - 3 workgroups fit a CU instead of 1 - 2 and their load / epilogue phases
   // overlap (these launches are pure streaming: X in, Y out)
   static const bool one_stage_ok = getenv("MSML_CONV_NO_ONE_STAGE") == nullptr;
-  if (one_stage_ok && NST == 2 && a.ksplits <= 1 && (a.nsub[0] + a.nsub[1] + 1) / 2 <= 1) lds = (size_t)(BM + BN) * 128;
+  a.lds_stages = NST;
+  if (one_stage_ok && NST == 2 && a.ksplits <= 1 && (a.nsub[0] + a.nsub[1] + 1) / 2 <= 1) {
+    a.lds_stages = 1;
+    lds = (size_t)(BM + BN) * 128;
+  }
   size_t olds = X3 ? (size_t)BM * (BN + 4) * 4 : (sizeof(TOUT) == 2 ? (size_t)BM * (BN + 8) * 2 : 0);
   if (olds > lds) lds = olds;
   if (lds > 64 * 1024) {                               // above the default dynamic-LDS limit

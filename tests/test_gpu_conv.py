@@ -491,3 +491,27 @@ def test_conv_wgrad_n32(shape, accumulate):
     if accumulate:
         ref = ref + 2.0
     assert (dw.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()     # bf16 operands, f32 sums
+
+
+# single-stage launches (K <= 64: one LDS stage is allocated, conv_fast.hip launch_fast) in every tile shape
+@pytest.mark.parametrize("shape", [(32, 64, 20, 1), (64, 32, 20, 1), (64, 64, 30, 2), (64, 128, 14, 1), (32, 18, 12, 1),
+                                   (64, 256, 9, 1)])
+def test_conv1x1_single_stage(shape):
+    cin, cout, h, stride = shape
+    g = torch.Generator().manual_seed(cin + cout + h)
+    n = 5
+    x = torch.randn(n, cin, h, h, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, stride, 0).float()
+    out, stats = run_conv(x, None, w, None, stride, 0, 0, _lib.BF16)
+    got = ops.to_nchw(out, cout).cpu()
+    assert (got - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[0][:cout], ref.sum((0, 2, 3)), rtol=2e-2, atol=0.05 * ref.abs().max().item() * n)
+    # backward-data of the same layer (transposed gather, K = cout)
+    if stride == 1 and cout <= 64:
+        dy = torch.randn(n, cout, h, h, generator=g).bfloat16().float()
+        wpt = ops.pack_weight(w.cuda(), True, cout, 0, _lib.BF16)
+        dx, _ = ops.conv2d(ops.to_nhwc(dy.cuda(), _lib.BF16), None, wpt, None, ops.cpad(cin), 1, 1, 1, 0, 0, True, p=h, q=h)
+        rdx = F.conv_transpose2d(dy.double(), w.double(), None, 1, 0).float()
+        assert (ops.to_nchw(dx, cin).cpu() - rdx).abs().max().item() <= 1.5e-2 * rdx.abs().max().item()
