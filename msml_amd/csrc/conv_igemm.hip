@@ -313,6 +313,11 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
                              const float* scale, const float* alpha, const void* residual, int res_first,
                              const BnBwdFuse* bnb, int* bnb_rows);
 
+bool msml_conv_line_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                            int pad_w);
+bool msml_conv_line_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
+                             int N, int H, int W, int R, int S, int transposed, hipStream_t st);
+
 extern "C" int msml_conv_tile_m(int coutp) { return coutp <= 64 ? 256 : 128; }
 extern "C" int msml_conv_tile_n(int coutp) { return coutp <= 32 ? 32 : (coutp <= 64 ? 64 : 128); }
 
@@ -354,6 +359,13 @@ extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, c
   MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE,
              "conv2d: packed weight has %d rows, need %d", kop, cdiv(coutp, bn) * bn);
   hipStream_t st = (hipStream_t)stream;
+  // 7x1 / 1x7 line convs of the OSB's Global-Convolution modules (and their backward-data convs): conv_line.hip
+  if (in_dtype == MSML_BF16 && out_dtype == MSML_BF16 && !in1 && !stats && !getenv("MSML_NO_FAST_CONV") &&
+      msml_conv_line_applies(c0p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) &&
+      msml_conv_line_dispatch(in0, c0p, wp, kop, bias, out, coutp, N, H, W, R, S, transposed, st)) {
+    MSML_LAUNCH_OK("conv2d(line)");
+    return MSML_OK;
+  }
   if ((out_dtype == MSML_BF16 || out_dtype == MSML_F32) && !getenv("MSML_NO_FAST_CONV") &&
       msml_conv_fast_dispatch(in0, c0p, in1, c1p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R,
                               S, stride, pad_h, pad_w, transposed, in_dtype, out_dtype, bn, st, nullptr, nullptr,
@@ -510,6 +522,9 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
   const int bn = msml_conv_tile_n(coutp);
   const bool fast = in_dtype == MSML_BF16 && !getenv("MSML_NO_FAST_CONV") && c0p % 32 == 0 && c1p % 32 == 0 &&
                     (c1p == 0 || ((R * S * (c0p / 32)) & 1) == 0) && (long)N * P * Q < (1L << 24);
+  if (fast && c1p == 0 && out_dtype == MSML_BF16 && !want_stats &&
+      msml_conv_line_applies(c0p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w))
+    return "k_conv_line<full lines in LDS, weights resident, persistent>";
   if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
       msml_conv_ws_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
     return "k_conv_ws<64 -> 64 channels, weights resident, persistent>";

@@ -8,6 +8,7 @@ which is data (inputs are re-derived from seeds; outputs are small arrays + chec
 Goldens:
   g1  eval ires18 bs=4: feature, mask index, seg maps, per-stage checksums
   g2  eval ires50 and the ires100-variant: feature, mask index, checksums
+  g2c eval ires18 at the sqrt(2/fan_in) fill with calibrated running statistics + f32-vs-f64 gain check
   g4  one full train step ires18 bs=4 (train-mode BN, reference conv init AND key fill)
   g4b the g4 step at batch 32 (gauge of the bf16 training path)
   g5  AMArcFace / AMCosFace / Softmax heads incl. -1 labels
@@ -267,6 +268,44 @@ def g9():
     for n in KD_STATS:
         rec["stat/" + n] = sd[n].numpy().copy()
     np.savez_compressed(os.path.join(OUT, "g9_kd_path.npz"), **rec)
+
+
+def g2c():
+    """Eval golden at the survey's sqrt(2 / fan_in) fill (gain 2) with CALIBRATED running statistics: one
+    train-mode forward at momentum 1 on a calibration batch sets every BatchNorm's running mean / var to
+    that batch's statistics (oracle.fill.calibrate_running_stats), then the eval forward is recorded.
+    Also records the f32-vs-f64 error of the reference itself for the two gains WITHOUT calibration --
+    the evidence behind oracle/fill.py's choice of gain 0.5 for the uncalibrated goldens."""
+    from oracle.fill import calibrate_running_stats
+    rec = {}
+    for frb, gain in (("iresnet18", 0.5), ("iresnet18", 2.0), ("iresnet50", 0.5), ("iresnet50", 2.0)):
+        torch.manual_seed(0)
+        m = fill_module(ref_msml(frb), gain).eval()
+        x, _ = eval_inputs(2)
+        with torch.no_grad():
+            f32 = m(x)[0]
+            f64 = m.double()(x.double())[0]
+        err = ((f32.double() - f64).norm() / f64.norm()).item()
+        rec["f32_vs_f64/%s_gain%g" % (frb, gain)] = np.float64(err)
+        rec["absmax/%s_gain%g" % (frb, gain)] = np.float64(f64.abs().max().item())
+        print("reference f32 vs f64, %s gain %g (uncalibrated running stats): %.3e, |feature|max %.3e"
+              % (frb, gain, err, f64.abs().max().item()))
+    torch.manual_seed(0)
+    m = fill_module(ref_msml("iresnet18"), 2.0)
+    xc, _ = eval_inputs(8)
+    calibrate_running_stats(m, lambda mod: mod(xc, synthetic.labels(8, 1000, seed=2), None))
+    m.eval()
+    x, _ = eval_inputs(4)
+    with torch.no_grad():
+        feat, final_seg = m(x)
+        f64 = m.double()(x.double())[0]
+    rec["f32_vs_f64/iresnet18_gain2_calibrated"] = np.float64(((feat.double() - f64).norm() / f64.norm()).item())
+    rec["feature"] = feat.numpy()
+    rec["mask_bits"] = np.packbits(final_seg.max(1)[1].numpy().astype(np.uint8).reshape(-1))
+    rec["final_seg_cs"] = checksum(final_seg)
+    rec["stat/frb.layer4.1.bn3.running_var"] = m.float().state_dict()["frb.layer4.1.bn3.running_var"].numpy().copy()
+    rec["stat/osb.bn1.running_mean"] = m.state_dict()["osb.bn1.running_mean"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g2c_ires18_gain2_calibrated.npz"), **rec)
 
 
 def g5():

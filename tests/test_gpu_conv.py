@@ -515,3 +515,31 @@ def test_conv1x1_single_stage(shape):
         dx, _ = ops.conv2d(ops.to_nhwc(dy.cuda(), _lib.BF16), None, wpt, None, ops.cpad(cin), 1, 1, 1, 0, 0, True, p=h, q=h)
         rdx = F.conv_transpose2d(dy.double(), w.double(), None, 1, 0).float()
         assert (ops.to_nchw(dx, cin).cpu() - rdx).abs().max().item() <= 1.5e-2 * rdx.abs().max().item()
+
+
+# Line-conv kernel (conv_line.hip): GCM 7x1 / 1x7 convs with bias at the 56 / 28 levels, forward and backward-data
+@pytest.mark.parametrize("shape", [(64, 18, 56, 7, 1), (64, 18, 56, 1, 7), (18, 18, 56, 7, 1), (18, 18, 56, 1, 7),
+                                   (64, 18, 28, 7, 1), (18, 18, 28, 1, 7)])
+def test_conv_line(shape):
+    cin, cout, h, r, s = shape
+    ph, pw = (r - 1) // 2, (s - 1) // 2
+    g = torch.Generator().manual_seed(cin + h + r)
+    n = 5
+    x = torch.randn(n, cin, h, h, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, r, s, generator=g) * (2.0 / (cin * 7)) ** 0.5).bfloat16().float()
+    bias = torch.randn(cout, generator=g)
+    assert _lib.value("msml_conv2d_kernel", ops.cpad(cin), 0, ops.cpad(cout), n, h, h, h, h, r, s, 1, ph, pw, 0, 1, 1, 0) \
+        .decode().startswith("k_conv_line")
+    ref = F.conv2d(x.double(), w.double(), bias.double(), 1, (ph, pw)).float()
+    wp = ops.pack_weight(w.cuda(), False, cin, 0, _lib.BF16)
+    bp = torch.zeros(ops.cpad(cout), device="cuda")
+    bp[:cout] = bias.cuda()
+    out, _ = ops.conv2d(ops.to_nhwc(x.cuda(), _lib.BF16), None, wp, bp, ops.cpad(cout), r, s, 1, ph, pw, False)
+    assert (ops.to_nchw(out, cout).cpu() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+    assert out[..., cout:].abs().max().item() == 0                       # pad channels stay exact zeros
+    # backward-data: transposed gather with the (ko = cin, ci = cout) packing
+    dy = torch.randn(n, cout, h, h, generator=g).bfloat16().float()
+    rdx = F.conv_transpose2d(dy.double(), w.double(), None, 1, (ph, pw)).float()
+    wpt = ops.pack_weight(w.cuda(), True, cout, 0, _lib.BF16)
+    dx, _ = ops.conv2d(ops.to_nhwc(dy.cuda(), _lib.BF16), None, wpt, None, ops.cpad(cin), r, s, 1, ph, pw, True, p=h, q=h)
+    assert (ops.to_nchw(dx, cin).cpu() - rdx).abs().max().item() <= 1.5e-2 * rdx.abs().max().item()

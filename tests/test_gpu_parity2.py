@@ -365,3 +365,35 @@ def test_pack_cache_is_keyed_on_live_parameters():
     del m, opt
     gc.collect()
     assert len(ops.PACKS.entries) == base
+
+
+def test_eval_gain2_calibrated_golden():
+    """Eval parity at the survey's sqrt(2/fan_in) fill (gain 2, activations ~30x larger than the default
+    goldens) with running statistics calibrated on the device (train-mode forward at momentum 1, exact-f32
+    path): embedding <= 1e-3 and bit-exact masks in f32 AND in the fp16=True default (split-bf16)."""
+    from oracle.fill import calibrate_running_stats
+    g = load("g2c_ires18_gain2_calibrated.npz")
+    torch.manual_seed(0)
+    m = MSML("iresnet18", "unet", (1, 1, 1, 1), 1000, fp16=False, fm_params=(3, 2, "sigmoid", "mul"),
+             header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(PEER_OFF))
+    m = fill_module(m, 2.0).cuda()
+    xc, _ = eval_inputs(8)
+    lab = synthetic.labels(8, 1000, seed=2)
+    calibrate_running_stats(m, lambda mod: mod(xc.cuda(), lab.cuda(), None))
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("stat/"):
+            assert rel_err(sd[key.split("/", 1)[1]].cpu().numpy(), g[key]) < 1e-3, key
+    x, _ = eval_inputs(4)
+    mx = MSML("iresnet18", "unet", (1, 1, 1, 1), 1000, fp16=True, fm_params=(3, 2, "sigmoid", "mul"),
+              header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(PEER_OFF)).cuda()
+    mx.load_state_dict(sd, strict=True)
+    for name, mod in (("f32", m), ("bf16x3", mx)):
+        mod.eval()
+        with torch.no_grad():
+            feat, seg = mod(x.cuda())
+        err = rel_err(feat.cpu().numpy(), g["feature"])
+        bits = np.packbits(Fh.mask_index(seg).cpu().numpy().reshape(-1))
+        mism = int(np.unpackbits(bits ^ g["mask_bits"]).sum())
+        print("gain-2 calibrated eval %-6s: feature rel err %.3e, mask px differing %d" % (name, err, mism))
+        assert err < 1e-3 and mism == 0, (name, err, mism)

@@ -288,3 +288,27 @@ def test_g9_kd_path():
         if key.startswith("stat/"):
             n = key.split("/", 1)[1]
             assert rel_err(m.state_dict()[n].numpy(), g[key]) < 1e-4, n
+
+
+def test_g2c_gain2_calibrated_eval():
+    """The survey's sqrt(2/fan_in) fill (gain 2) with calibrated running statistics (one train-mode forward
+    at momentum 1): the oracle follows the reference; and the recorded f32-vs-f64 errors of the reference
+    itself are the evidence for oracle/fill.py's gain 0.5 on the uncalibrated goldens."""
+    from oracle.fill import calibrate_running_stats
+    g = load("g2c_ires18_gain2_calibrated.npz")
+    assert g["f32_vs_f64/iresnet50_gain2"] > 1e-3 > 1e-5 > g["f32_vs_f64/iresnet50_gain0.5"]
+    assert g["f32_vs_f64/iresnet18_gain2_calibrated"] < 1e-5
+    torch.manual_seed(0)
+    m = fill_module(om.MSML("iresnet18", "unet", (1, 1, 1, 1), 1000, fm_params=(3, 2, "sigmoid", "mul"),
+                            header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0)), 2.0)
+    xc, _ = eval_inputs(8)
+    calibrate_running_stats(m, lambda mod: mod(xc, synthetic.labels(8, 1000, seed=2), None))
+    m.eval()
+    x, _ = eval_inputs(4)
+    with torch.no_grad():
+        feat, final_seg = m(x)
+    assert rel_err(feat.numpy(), g["feature"]) < TOL
+    assert np.array_equal(np.packbits(om.mask_index(final_seg).numpy().astype(np.uint8).reshape(-1)), g["mask_bits"])
+    for key in g.files:
+        if key.startswith("stat/"):
+            assert rel_err(m.state_dict()[key.split("/", 1)[1]].numpy(), g[key]) < 1e-4, key

@@ -49,3 +49,21 @@ def conv1x1():
 
 if __name__ == "__main__":
     conv1x1()
+
+
+def gcm():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    for cin, cout, h, r, s in ((64, 18, 56, 7, 1), (64, 18, 56, 1, 7), (18, 18, 56, 7, 1), (18, 18, 56, 1, 7), (64, 18, 28, 7, 1), (18, 18, 28, 1, 7)):
+        cinp, coutp = ops.cpad(cin), ops.cpad(cout)
+        x = torch.randn(n, h, h, cinp, device="cuda").bfloat16()
+        w = torch.randn(cout, cin, r, s, device="cuda") * 0.05
+        wp = ops.pack_weight(w, False, cin, 0, BF)
+        bp = torch.zeros(coutp, device="cuda")
+        ph, pw = (r - 1) // 2, (s - 1) // 2
+        t = timeit(lambda: ops.conv2d(x, None, wp, bp, coutp, r, s, 1, ph, pw, False))
+        b = (x.numel() + n * h * h * coutp) * 2
+        print("%-40s %8.1f us  %7.0f GB/s of algorithmic bytes" % ("gcm conv %dx%d %d->%d @%d" % (r, s, cin, cout, h), t * 1e6, b / t / 1e9))
+
+
+if __name__ == "__main__":
+    gcm()
