@@ -326,6 +326,10 @@ int msml_wgrad_n32_splits(int up, int vp, int N, int H, int W, int P, int Q, int
                           int pad_w);
 bool msml_wgrad_n32_launch(const void* u, const void* v, float* ws, int N, int H, int W, int P, int Q, int R,
                            int stride, int splits, hipStream_t st);
+int msml_wgrad_line_splits(int up, int vp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                           int pad_w);
+bool msml_wgrad_line_launch(const void* u, const void* v, int vp, float* ws, int N, int H, int R, int splits,
+                            hipStream_t st);
 
 // taps handled by one workgroup of the bf16 fast kernel (narrow V operands share the U tile)
 static int wgrad_ntw(int vp, int taps) {
@@ -376,13 +380,15 @@ extern "C" long msml_conv_wgrad_workspace(int up, int vp, int N, int P, int Q, i
   }
   // narrow-operand kernel (wgrad_n32.hip): H / W are not known here, assume its largest split count
   if (up == 32 && vp == 32 && (R * S == 16 || R * S == 9) && splits < 512) splits = 512;
+  if (up == 32 && (vp == 32 || vp == 64) && R * S == 7 && splits < 512) splits = 512;          // line kernel
   return (long)splits * up * R * S * vp * (long)sizeof(float);
 }
 
 // 1 when the bf16 weight gradient of this shape runs on the narrow-operand kernel (tests, profiling labels)
 extern "C" int msml_conv_wgrad_kernel_is_n32(int up, int vp, int N, int H, int W, int P, int Q, int R, int S, int stride,
                                              int pad_h, int pad_w) {
-  return msml_wgrad_n32_splits(up, vp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0 ? 1 : 0;
+  return (msml_wgrad_n32_splits(up, vp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0 ||
+          msml_wgrad_line_splits(up, vp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0) ? 1 : 0;
 }
 
 extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, float* dw, int A,
@@ -421,6 +427,13 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
     if (ns > 0 && msml_wgrad_n32_launch(u, v, a.ws, N, H, W, P, Q, R, stride, ns, st)) {
       MSML_LAUNCH_OK("conv_wgrad(n32)");
       wgrad_reduce_launch(a.ws, dw, ns, up, taps, vp, A, Breal, Btot, boff, accumulate, st);
+      MSML_LAUNCH_OK("conv_wgrad_reduce");
+      return MSML_OK;
+    }
+    const int ls = msml_wgrad_line_splits(up, vp, N, H, W, P, Q, R, S, stride, pad_h, pad_w);
+    if (ls > 0 && msml_wgrad_line_launch(u, v, vp, a.ws, N, H, R, ls, st)) {
+      MSML_LAUNCH_OK("conv_wgrad(line)");
+      wgrad_reduce_launch(a.ws, dw, ls, up, taps, vp, A, Breal, Btot, boff, accumulate, st);
       MSML_LAUNCH_OK("conv_wgrad_reduce");
       return MSML_OK;
     }

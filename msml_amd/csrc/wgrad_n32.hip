@@ -222,3 +222,153 @@ bool msml_wgrad_n32_launch(const void* u, const void* v, float* ws, int N, int H
   else return false;
   return true;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient of the GCM line convs (backbones/osb/unet.py:16-38: 7x1 / 1x7, stride 1): u = dY (18 -> 32 stored
+// channels), v = X (32 or 64 stored channels).  Same line-major tiles as conv_line.hip: a tile is a full line along the
+// conv axis times B positions across it (224 pixels = 14 k-steps of 16), the v region is the tile plus three zero
+// pixels at either end of every line, and tap t reads the region t * B pixels further on -- operands go to LDS once
+// for all 7 taps (the im2col kernel gathered v once per tap: 104-113 us per launch at 56 x 56).  Wave w < 7 owns tap w.
+struct WgradLineArgs {
+  const unsigned short* u; unsigned int u_bytes;     // dY [N][L][L][32]
+  const unsigned short* v; unsigned int v_bytes;     // X  [N][L][L][VP]
+  int N, L, B, tiles_per_img, ntiles, chunk, vertical;
+  float* ws;                                         // [split][32][7][VP]
+};
+
+template <int VP>
+__global__ void __launch_bounds__(512) k_wgrad_line(const WgradLineArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NH = VP / 32, UBLK = 14, VBLK = 18;  // 224 u pixels, <= 288 region pixels per 32-channel half
+  constexpr int UB = UBLK * 1024, VB = NH * VBLK * 1024, STAGE = UB + VB;
+  constexpr int NBLK = UBLK + NH * VBLK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int split = blockIdx.x, L = p.L, B = p.B, nreg = (L + 6) * B;
+  const int t_begin = split * p.chunk;
+  int t_end = t_begin + p.chunk;
+  if (t_end > p.ntiles) t_end = p.ntiles;
+
+  __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, (int)p.u_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)p.v, 0, (int)p.v_bytes, 0x00020000);
+  const int lp = lane >> 2, lc = lane & 3;
+  auto issue = [&](int tile, int buf) {
+    const int n = tile / p.tiles_per_img, b0 = (tile - n * p.tiles_per_img) * B;
+    char* ub = smem + buf * STAGE;
+    char* vb = ub + UB;
+    for (int blk = wave; blk < NBLK; blk += 8) {
+      if (blk < UBLK) {
+        const int q = blk * 16 + lp, a = q / B, b = b0 + (q - a * B);
+        const bool ok = b < L;
+        const int y = p.vertical ? a : b, x = p.vertical ? b : a;
+        const unsigned int off = ok ? (unsigned int)((n * L + y) * L + x) * 64u + (unsigned int)lc * 16u : WN_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lptr_t)(ub + blk * 1024), 16, off, 0, 0, 0);
+      } else {
+        const int bb = blk - UBLK, hf = bb / VBLK, j = bb - hf * VBLK;
+        const int q = j * 16 + lp, a = q / B - 3, b = b0 + (q - (q / B) * B);
+        const bool ok = (q < nreg) & ((unsigned)a < (unsigned)L) & (b < L);
+        const int y = p.vertical ? a : b, x = p.vertical ? b : a;
+        const unsigned int off = ok ? (unsigned int)((n * L + y) * L + x) * (unsigned int)(VP * 2) + (unsigned int)(hf * 64 + lc * 16)
+                                    : WN_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lptr_t)(vb + bb * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[NH];
+#pragma unroll
+  for (int k = 0; k < NH; k++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[k][e] = 0.f;
+  const int g4 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+  const int px = 8 * (g4 >> 1) + q4;
+  const int chan = (2 * (g4 & 1) + (pp >> 1)) * 16 + (pp & 1) * 8;
+  const int aofs = px * 64 + chan;
+  const int vofs = (wave < 7 ? wave : 0) * B * 64 + px * 64 + chan;      // tap = wave: region pixel p + tap * B
+  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+  auto tr2 = [&](const char* lo) -> s16x8 {
+    s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(lo));
+    s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(lo + 256));
+    s16x8 o;
+    o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = l[3];
+    o[4] = h[0]; o[5] = h[1]; o[6] = h[2]; o[7] = h[3];
+    return o;
+  };
+
+  if (t_begin < t_end) issue(t_begin, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int tile = t_begin; tile < t_end; tile++) {
+    if (tile + 1 < t_end) issue(tile + 1, cur ^ 1);
+    if (wave < 7) {
+      const char* ub = smem + cur * STAGE + aofs;
+      const char* vb = smem + cur * STAGE + UB + vofs;
+#pragma unroll
+      for (int j = 0; j < UBLK; j++) {               // k-step = 16 consecutive line-major pixels
+        const s16x8 fa = tr2(ub + j * 1024);
+#pragma unroll
+        for (int k = 0; k < NH; k++) {
+          const s16x8 fb = tr2(vb + k * (VBLK * 1024) + j * 1024);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
+                                                           acc[k], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (wave < 7) {
+    const int h = lane >> 5, b = lane & 31;
+#pragma unroll
+    for (int k = 0; k < NH; k++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int a = (e & 3) + 8 * (e >> 2) + 4 * h;
+        p.ws[(((long)split * 32 + a) * 7 + wave) * VP + k * 32 + b] = acc[k][e];
+      }
+  }
+#endif
+}
+
+int msml_wgrad_line_splits(int up, int vp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                           int pad_w) {
+  static const bool off = getenv("MSML_NO_N32_WGRAD") != nullptr;
+  if (off || up != 32 || (vp != 32 && vp != 64) || stride != 1) return 0;
+  if (!((R == 7 && S == 1 && pad_h == 3 && pad_w == 0) || (R == 1 && S == 7 && pad_h == 0 && pad_w == 3))) return 0;
+  if (H != W || P != H || Q != W || !(H == 56 || H == 28)) return 0;
+  if ((long)N * H * W * vp * 2 >= 0x70000000L) return 0;
+  const long tiles = (long)N * cdiv(H, 224 / H);
+  long splits = (vp == 32 ? 2L : 1L) * wn_cus();
+  if (splits > tiles) splits = tiles;
+  if (splits > 512) splits = 512;
+  return (int)splits;
+}
+
+template <int VP>
+static void wl_launch(const WgradLineArgs& a, int splits, hipStream_t st) {
+  const size_t lds = 2 * (size_t)(14 + (VP / 32) * 18) * 1024;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_line<VP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  });
+  k_wgrad_line<VP><<<dim3(splits), dim3(512), lds, st>>>(a);
+}
+
+bool msml_wgrad_line_launch(const void* u, const void* v, int vp, float* ws, int N, int H, int R, int splits,
+                            hipStream_t st) {
+  WgradLineArgs a;
+  a.u = (const unsigned short*)u; a.u_bytes = (unsigned int)((long)N * H * H * 64);
+  a.v = (const unsigned short*)v; a.v_bytes = (unsigned int)((long)N * H * H * vp * 2);
+  a.N = N; a.L = H; a.B = 224 / H;
+  a.tiles_per_img = cdiv(H, a.B);
+  a.ntiles = N * a.tiles_per_img;
+  a.chunk = cdiv(a.ntiles, splits);
+  a.vertical = R == 7 ? 1 : 0;
+  a.ws = ws;
+  if (vp == 64) wl_launch<64>(a, splits, st);
+  else wl_launch<32>(a, splits, st);
+  return true;
+}

@@ -543,3 +543,24 @@ def test_conv_line(shape):
     wpt = ops.pack_weight(w.cuda(), True, cout, 0, _lib.BF16)
     dx, _ = ops.conv2d(ops.to_nhwc(dy.cuda(), _lib.BF16), None, wpt, None, ops.cpad(cin), r, s, 1, ph, pw, True, p=h, q=h)
     assert (ops.to_nchw(dx, cin).cpu() - rdx).abs().max().item() <= 1.5e-2 * rdx.abs().max().item()
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("shape", [(64, 18, 56, 7, 1), (64, 18, 56, 1, 7), (18, 18, 56, 7, 1), (18, 18, 28, 1, 7), (64, 18, 28, 7, 1)])
+def test_conv_wgrad_line(shape, accumulate):
+    """Weight gradient of the GCM line convs on the line-major kernel (wgrad_n32.hip k_wgrad_line)."""
+    cin, cout, h, r, s = shape
+    ph, pw = (r - 1) // 2, (s - 1) // 2
+    g = torch.Generator().manual_seed(cin + h + r + 5)
+    n = 4
+    x = torch.randn(n, cin, h, h, generator=g).bfloat16().float()
+    w = torch.zeros(cout, cin, r, s, dtype=torch.double, requires_grad=True)
+    y = F.conv2d(x.double(), w, None, 1, (ph, pw))
+    dy = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dy.double())
+    ref = w.grad.float() + (2.0 if accumulate else 0.0)
+    assert _lib.value("msml_conv_wgrad_kernel_is_n32", 32, ops.cpad(cin), n, h, h, h, h, r, s, 1, ph, pw) == 1
+    dw = torch.full((cout, cin, r, s), 2.0, device="cuda")
+    ops.conv_wgrad(ops.to_nhwc(dy.cuda(), _lib.BF16), ops.to_nhwc(x.cuda(), _lib.BF16), dw, cout, cin, cin, 0, r, s, 1,
+                   ph, pw, accumulate=accumulate)
+    assert (dw.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()

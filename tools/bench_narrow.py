@@ -67,3 +67,20 @@ def gcm():
 
 if __name__ == "__main__":
     gcm()
+
+
+def gcm_wgrad():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    for cin, h, r, s in ((64, 56, 7, 1), (64, 56, 1, 7), (18, 56, 7, 1), (18, 28, 1, 7), (64, 28, 7, 1)):
+        cinp = ops.cpad(cin)
+        x = torch.randn(n, h, h, cinp, device="cuda").bfloat16()
+        dy = torch.randn(n, h, h, 32, device="cuda").bfloat16()
+        dw = torch.empty(18, cin, r, s, device="cuda")
+        ph, pw = (r - 1) // 2, (s - 1) // 2
+        t = timeit(lambda: ops.conv_wgrad(dy, x, dw, 18, cin, cin, 0, r, s, 1, ph, pw))
+        b = (x.numel() + dy.numel()) * 2
+        print("%-40s %8.1f us  %7.0f GB/s of algorithmic bytes" % ("gcm wgrad %dx%d %d->18 @%d" % (r, s, cin, h), t * 1e6, b / t / 1e9))
+
+
+if __name__ == "__main__":
+    gcm_wgrad()
