@@ -335,6 +335,15 @@ int msml_occ_draw(long seed, long offset, int N, int H, int W, int mode, int lo,
 int msml_occ_apply(const unsigned char* src, const int* desc, float* img, long* msk, float* ori, int N, int H,
                    int W, int light, void* stream);
 
+/* Backward-data of the OSB decoder's ConvTranspose2d(36 -> 18, k 4, s 2, p 1) on cat(seg, gcm) (backbones/osb/unet.py:
+ * 140-156, autograd of deconv2..5) for BOTH input segments from one pass over dY (bf16):
+ *   dxS[n, i, j, ci] = sum_{r, s, co} dy[n, 2i - 1 + r, 2j - 1 + s, co] * w[S * 18 + ci][co][r][s]
+ * dy [N][2H][2H][32], dx0 / dx1 [N][H][H][32]; wp0 / wp1 = msml_pack_weight of the segment's rows of the
+ * ConvTranspose2d weight (transpose 0, C1 = 18: [32 ci rows][16 taps x 32 co]).  H in {14, 28, 56};
+ * MSML_ERR_UNSUPPORTED otherwise (callers then run msml_conv2d per segment). */
+int msml_deconv4_bwd_data(const void* dy, const void* wp0, const void* wp1, void* dx0, void* dx1, int N, int H,
+                          void* stream);
+
 /* Backward-data conv fused with the backward REDUCE of the BatchNorm(+PReLU) that produced the
  * conv's input in the forward (IBasicBlock: bn1 -> conv1, bn2 -> prelu -> conv2,
  * backbones/frb/iresnet.py:59-64): the conv output dX is that BatchNorm's dy, so the epilogue

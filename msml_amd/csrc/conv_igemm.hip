@@ -318,6 +318,11 @@ bool msml_conv_line_applies(int c0p, int coutp, int N, int H, int W, int P, int 
 bool msml_conv_line_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
                              int N, int H, int W, int R, int S, int transposed, hipStream_t st);
 
+bool msml_deconv4_applies(int c0p, int c1p, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                          int pad_h, int pad_w, int transposed);
+bool msml_deconv4_dispatch(const void* in0, const void* in1, const void* wp, int kop, const float* bias, void* out, int N,
+                           int H, hipStream_t st);
+
 extern "C" int msml_conv_tile_m(int coutp) { return coutp <= 64 ? 256 : 128; }
 extern "C" int msml_conv_tile_n(int coutp) { return coutp <= 32 ? 32 : (coutp <= 64 ? 64 : 128); }
 
@@ -364,6 +369,13 @@ extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, c
       msml_conv_line_applies(c0p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) &&
       msml_conv_line_dispatch(in0, c0p, wp, kop, bias, out, coutp, N, H, W, R, S, transposed, st)) {
     MSML_LAUNCH_OK("conv2d(line)");
+    return MSML_OK;
+  }
+  // 4x4 / stride-2 transposed convs of the OSB decoder on cat(seg, gcm): conv_d4.hip
+  if (in_dtype == MSML_BF16 && out_dtype == MSML_BF16 && in1 && !stats && !getenv("MSML_NO_FAST_CONV") &&
+      msml_deconv4_applies(c0p, c1p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed) &&
+      msml_deconv4_dispatch(in0, in1, wp, kop, bias, out, N, H, st)) {
+    MSML_LAUNCH_OK("conv2d(deconv4)");
     return MSML_OK;
   }
   if ((out_dtype == MSML_BF16 || out_dtype == MSML_F32) && !getenv("MSML_NO_FAST_CONV") &&
@@ -522,6 +534,9 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
   const int bn = msml_conv_tile_n(coutp);
   const bool fast = in_dtype == MSML_BF16 && !getenv("MSML_NO_FAST_CONV") && c0p % 32 == 0 && c1p % 32 == 0 &&
                     (c1p == 0 || ((R * S * (c0p / 32)) & 1) == 0) && (long)N * P * Q < (1L << 24);
+  if (fast && out_dtype == MSML_BF16 && !want_stats &&
+      msml_deconv4_applies(c0p, c1p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed))
+    return "k_deconv4_fwd<14x16 input tile, 4 parity classes, weights resident>";
   if (fast && c1p == 0 && out_dtype == MSML_BF16 && !want_stats &&
       msml_conv_line_applies(c0p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w))
     return "k_conv_line<full lines in LDS, weights resident, persistent>";

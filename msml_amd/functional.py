@@ -82,7 +82,23 @@ class _Conv(torch.autograd.Function):
         w = weight.detach()
         n, h, wd, _ = x0.shape
         grads = [None, None]
+        if (deconv and x1 is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dtype == BF16
+                and r == 4 and s == 4 and stride == 2 and ph == 1 and pw == 1 and x0.shape[3] == 32 and x1.shape[3] == 32
+                and dy.shape[3] == 32 and h == wd and h in (14, 28, 56)):
+            # OSB decoder: both segments' input gradients from ONE pass over dY (msml_deconv4_bwd_data)
+            wp0 = ops.PACKS.get(w, False, 0, c0, 0, cout, cout, 0, dtype, owner=ctx.wobj)
+            wp1 = ops.PACKS.get(w, False, c0, c1, 0, cout, cout, 0, dtype, owner=ctx.wobj)
+            g0, g1 = torch.empty_like(x0), torch.empty_like(x1)
+            name = "conv_igemm"
+            if ops.PROFILE.on:
+                name = "conv N c32+0->32+32 %dx%d k4x4 s2 n%d [k_deconv4_bwd<both segments>]" % (2 * h, 2 * h, n)
+            with ops.PROFILE.rec(name, 2.0 * n * h * wd * (c0 + c1) * cout * 16):
+                rc = _lib.try_call("msml_deconv4_bwd_data", dy, wp0, wp1, g0, g1, n, h)
+            if rc == 0:
+                grads = [g0, g1]
         for i, (x, off, ci) in enumerate(((x0, 0, c0), (x1, c0, c1))):
+            if grads[i] is not None:
+                continue
             if x is None or not ctx.needs_input_grad[i]:
                 continue
             if deconv:      # backward-data of a transposed conv = strided conv of dy

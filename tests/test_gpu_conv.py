@@ -79,7 +79,9 @@ def test_conv_fwd(shape, dtype, tol):
 DECONVS = [
     (8, 0, 18, 4, 3, 2, 1),        # deconv1: 8 -> 18, k3 s2 p1, 4x4 -> 7x7
     (18, 18, 18, 7, 4, 2, 1),      # deconv2..5 on cat(seg, gcm): 36 -> 18, k4 s2 p1
-    (18, 18, 18, 14, 4, 2, 1),
+    (18, 18, 18, 14, 4, 2, 1),     # from here: the dedicated kernel (conv_d4.hip) in bf16
+    (18, 18, 18, 28, 4, 2, 1),
+    (18, 18, 18, 56, 4, 2, 1),
 ]
 
 
@@ -564,3 +566,28 @@ def test_conv_wgrad_line(shape, accumulate):
     ops.conv_wgrad(ops.to_nhwc(dy.cuda(), _lib.BF16), ops.to_nhwc(x.cuda(), _lib.BF16), dw, cout, cin, cin, 0, r, s, 1,
                    ph, pw, accumulate=accumulate)
     assert (dw.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("h", [14, 28, 56])
+def test_deconv4_bwd_data_both_segments(h):
+    """Input gradients of ConvTranspose2d(36 -> 18, 4, 2, 1) on cat(seg, gcm): one kernel for both segments
+    (msml_deconv4_bwd_data) against autograd in f64."""
+    g = torch.Generator().manual_seed(40 + h)
+    n = 3
+    x = torch.randn(n, 36, h, h, generator=g, dtype=torch.double, requires_grad=True)
+    wt = (torch.randn(36, 18, 4, 4, generator=g) * 0.2).bfloat16().double()
+    y = F.conv_transpose2d(x, wt, None, 2, 1)
+    dy = torch.randn(y.shape, generator=g).bfloat16().double()
+    y.backward(dy)
+    wc = wt.float().cuda()
+    wp0 = ops.pack_weight(wc[:18].contiguous(), False, 18, 0, _lib.BF16)
+    wp1 = ops.pack_weight(wc[18:].contiguous(), False, 18, 0, _lib.BF16)
+    dyd = ops.to_nhwc(dy.float().cuda(), _lib.BF16)
+    g0 = torch.empty(n, h, h, 32, dtype=torch.bfloat16, device="cuda")
+    g1 = torch.empty_like(g0)
+    _lib.call("msml_deconv4_bwd_data", dyd, wp0, wp1, g0, g1, n, h)
+    ref = x.grad.float()
+    scale = ref.abs().max().item()
+    assert (ops.to_nchw(g0, 18).cpu() - ref[:, :18]).abs().max().item() <= 1.5e-2 * scale
+    assert (ops.to_nchw(g1, 18).cpu() - ref[:, 18:]).abs().max().item() <= 1.5e-2 * scale
+    assert g0[..., 18:].abs().max().item() == 0 and g1[..., 18:].abs().max().item() == 0

@@ -84,3 +84,19 @@ def gcm_wgrad():
 
 if __name__ == "__main__":
     gcm_wgrad()
+
+
+def deconv():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    for h in (56, 28, 14):
+        x0 = torch.randn(n, h, h, 32, device="cuda").bfloat16()
+        x1 = torch.randn(n, h, h, 32, device="cuda").bfloat16()
+        wt = torch.randn(36, 18, 4, 4, device="cuda") * 0.1
+        wp = ops.pack_weight(wt, True, 18, 18, BF)
+        t = timeit(lambda: ops.conv2d(x0, x1, wp, None, 32, 4, 4, 2, 1, 1, True))
+        b = (2 * x0.numel() + n * 4 * h * h * 32) * 2
+        print("%-40s %8.1f us  %7.0f GB/s of algorithmic bytes" % ("deconv 4x4 s2 fwd 36->18 @%d" % h, t * 1e6, b / t / 1e9))
+
+
+if __name__ == "__main__":
+    deconv()
