@@ -552,6 +552,9 @@ def main():
                 print("%-52s n=%3d ms/step=%7.3f TF/s=%6.1f" % (name, v["n"] // prof_steps, v["ms"] / prof_steps,
                       v["flops"] / max(v["ms"], 1e-9) / 1e9), file=sys.stderr)
         peak = PEAK_TFLOPS[args.dtype]
+        if "conv_igemm" not in fam:            # inference runs: fused / split-precision conv labels
+            fam["conv_igemm"] = dict(fam.get("conv_x3") or fam.get("conv_fused") or
+                                     {"ms": 1e-9, "n": 1, "flops": 0.0, "bytes": 0.0})
         k = fam["conv_igemm"]
         ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
         rec["roofline_family"] = {"bound": "mfma", "kernel": "k_conv_halo / k_conv_fast / k_conv_igemm (conv fwd + dgrad, every shape of the step)",
@@ -561,7 +564,7 @@ def main():
         # the dominant launch of the step over conv forward / backward-data AND weight-gradient labels
         # (one shape, one kernel): achieved from its own events, HBM traffic from the committed rocprofv3
         # PMC run of the same launch (profiles/*_pmc_traffic.json, keyed by the label)
-        cands = {n: v for n, v in prof.items() if n.startswith("conv ") or n.startswith("wgrad ")}
+        cands = {n: v for n, v in prof.items() if n.startswith("conv") or n.startswith("wgrad ")}
         top = max(cands, key=lambda n: cands[n]["ms"])
         tv = cands[top]
         tach = tv["flops"] / (tv["ms"] * 1e-3) / 1e12
@@ -572,7 +575,7 @@ def main():
                            "avg_us": round(tv["ms"] * 1e3 / tv["n"], 2)}
         # and the heaviest launch of the OTHER family, so that neither hides behind the other
         for famname, pre in (("roofline_conv", "conv "), ("roofline_wgrad", "wgrad ")):
-            sub = {n: v for n, v in prof.items() if n.startswith(pre)}
+            sub = {n: v for n, v in prof.items() if n.startswith(pre.strip() if pre == "conv " else pre)}
             if not sub:
                 continue
             t2 = max(sub, key=lambda n: sub[n]["ms"])

@@ -57,7 +57,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // 7 accumulator tiles, (128, 2) = 4 channel groups x {4, 3} tiles -- waves w and w + 4 share a SIMD,
 // so every SIMD still carries 7 tiles.
 // XF: forward launch whose input is PReLU(in * xin.scale + xin.shift), applied per slab in LDS.
-template <int BN, int NWM, bool FUSE, bool XF = false>
+// X3: split-bf16 inference (x3.hip): `in` / `residual` / `out` hold 3 x their logical channels as planes
+// [hi | lo | hi]; C = 3 x the logical input channels (the K loop is unaware), coutp = logical output channels.
+template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo(const ConvHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -278,12 +280,67 @@ k_conv_halo(const ConvHaloArgs p) {
   // Forward launches without a residual store straight from registers: v_permlane32_swap gives
   // the lane pair of a pixel 16 contiguous channels each (32 B), so a wave writes 64 B runs per
   // pixel with two 16-B stores per lane and tile -- no LDS transpose, no barrier.
-  const bool direct = !FUSE && p.residual == nullptr;
+  const bool direct = X3 || (!FUSE && p.residual == nullptr);
 #pragma unroll
   for (int i = 0; i < MTW; i++) {
     if (i >= nmt) break;
     const int m = (i0 + i) * 32 + r32;
     const bool valid = pix_ok(m);
+    if constexpr (X3) {
+      // split-bf16 output: residual (hi + lo planes) joins in f32, the result leaves as three planes
+      const long po = pix_off(m) * 3;
+      u32x2 pkh[4], pkl[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.residual && valid) {
+          const unsigned short* rp = p.residual + po + n0 + kb + 8 * g;
+          const u32x2 rh = *reinterpret_cast<const u32x2*>(rp), rl = *reinterpret_cast<const u32x2*>(rp + p.coutp);
+          r4[0] = __uint_as_float(rh[0] << 16) + __uint_as_float(rl[0] << 16);
+          r4[1] = __uint_as_float(rh[0] & 0xffff0000u) + __uint_as_float(rl[0] & 0xffff0000u);
+          r4[2] = __uint_as_float(rh[1] << 16) + __uint_as_float(rl[1] << 16);
+          r4[3] = __uint_as_float(rh[1] & 0xffff0000u) + __uint_as_float(rl[1] & 0xffff0000u);
+        }
+        unsigned short hh[4], ll[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float z = acc[i][g * 4 + j] * sv[g][j] + bv[g][j];
+          if (act_here) z = z > 0.f ? z : z * av[g][j];
+          if (p.residual) {
+            z += r4[j];
+            if (p.res_first && p.alpha) z = z > 0.f ? z : z * p.alpha[n0 + kb + 8 * g + j];
+          }
+          hh[j] = f2bf(z);
+          ll[j] = f2bf(z - bf2f(hh[j]));
+        }
+        pkh[g][0] = (unsigned int)hh[0] | ((unsigned int)hh[1] << 16);
+        pkh[g][1] = (unsigned int)hh[2] | ((unsigned int)hh[3] << 16);
+        pkl[g][0] = (unsigned int)ll[0] | ((unsigned int)ll[1] << 16);
+        pkl[g][1] = (unsigned int)ll[2] | ((unsigned int)ll[3] << 16);
+      }
+      u32x4 loh, hih, lol, hil;
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        auto a01 = __builtin_amdgcn_permlane32_swap(pkh[0][e], pkh[1][e], false, false);
+        auto a23 = __builtin_amdgcn_permlane32_swap(pkh[2][e], pkh[3][e], false, false);
+        loh[e] = a01[0]; loh[2 + e] = a01[1];
+        hih[e] = a23[0]; hih[2 + e] = a23[1];
+        auto b01 = __builtin_amdgcn_permlane32_swap(pkl[0][e], pkl[1][e], false, false);
+        auto b23 = __builtin_amdgcn_permlane32_swap(pkl[2][e], pkl[3][e], false, false);
+        lol[e] = b01[0]; lol[2 + e] = b01[1];
+        hil[e] = b23[0]; hil[2 + e] = b23[1];
+      }
+      if (valid) {
+        unsigned short* o = p.out + po + n0 + kg * 32 + 8 * h;
+        *reinterpret_cast<u32x4*>(o) = loh;
+        *reinterpret_cast<u32x4*>(o + 16) = hih;
+        *reinterpret_cast<u32x4*>(o + p.coutp) = lol;
+        *reinterpret_cast<u32x4*>(o + p.coutp + 16) = hil;
+        *reinterpret_cast<u32x4*>(o + 2 * p.coutp) = loh;
+        *reinterpret_cast<u32x4*>(o + 2 * p.coutp + 16) = hih;
+      }
+      continue;
+    }
     u32x2 pk[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -398,7 +455,7 @@ k_conv_halo(const ConvHaloArgs p) {
 #endif
 }
 
-template <int BN, int NWM, bool FUSE, bool XF = false>
+template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false>
 static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;      // two halo images + eight private weight rings
   size_t olds = (size_t)224 * (BN + 8) * 2;
@@ -406,11 +463,11 @@ static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   if (XF) lds += 3 * 1024 * sizeof(float);             // coefficient table, C <= 1024
   static std::once_flag attr_once;                     // (per template instantiation; launches come from
   std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF, X3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   dim3 grid(a.N * a.tpy * a.tpx, a.coutp / BN);
-  k_conv_halo<BN, NWM, FUSE, XF><<<grid, dim3(512), lds, st>>>(a);
+  k_conv_halo<BN, NWM, FUSE, XF, X3><<<grid, dim3(512), lds, st>>>(a);
 }
 
 // Shape test shared by the dispatch and by msml_conv2d_kernel (the name query).
@@ -437,9 +494,10 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
                              int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
                              const float* scale, const float* alpha, const void* residual, int res_first,
-                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin) {
+                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin, int x3) {
   if (!msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
     return false;
+  if (x3 && (bnb || xin || stats || transposed)) return false;
   if (bnb && (bias || scale || alpha || residual || stats)) return false;
   if (xin && (bnb || transposed || c0p > 1024)) return false;
   ConvHaloArgs a;
@@ -459,7 +517,10 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   if (xin) a.xin = *xin;
   if (bnb_rows) *bnb_rows = (int)tiles;
   const bool wide = coutp % 256 == 0;
-  if (xin) {
+  if (x3) {
+    if (wide) launch_halo<256, 1, false, false, true>(a, st);
+    else launch_halo<128, 2, false, false, true>(a, st);
+  } else if (xin) {
     if (wide) launch_halo<256, 1, false, true>(a, st);
     else launch_halo<128, 2, false, true>(a, st);
   } else if (bnb) {

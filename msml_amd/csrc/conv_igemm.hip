@@ -487,7 +487,7 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
                              int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
                              const float* scale, const float* alpha, const void* residual, int res_first,
-                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin);
+                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin, int x3 = 0);
 bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
                            int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                            int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
