@@ -41,6 +41,46 @@ def main():
         out[tag + "_x_grad"] = x_grad.cpu().numpy()
         out[tag + "_wgrad_pick"] = pick(wgrad, 256)
         out[tag + "_wnew_pick"] = pick(p.sub_weight.data, 256)
+    # ---- bucketed gradient all-reduce overlapped with the backward (FlatSGD.enable_overlap) at world size 2,
+    # both side streams on, against the plain all_reduce_grads path on the same gradients (a bucket
+    # fired from a side-stream autograd node must also wait for the training stream)
+    from msml_amd import ops, synthetic
+    from msml_amd.backbones import MSML
+    from msml_amd.optim import FlatSGD, reference_param_groups
+    from msml_amd.tricks.consensus_loss import StructureConsensuLossFunction
+    from oracle.fill import fill_module
+    peer = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
+
+    def grads(overlap):
+        torch.manual_seed(0)
+        m = fill_module(MSML("iresnet18", "unet", (1, 1, 1, 1), 50, fp16=True, fm_params=(3, 2, "sigmoid", "mul"),
+                             header_type="AMArcFace", peer_params=dict(peer))).cuda().train()
+        opt = FlatSGD(reference_param_groups(m, 2, world), 0.9, 5e-4, 5.0)
+        if overlap:
+            opt.enable_overlap(world, bucket_bytes=8 << 20)
+        ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
+        x = synthetic.images(2, seed=10 + rank)               # different data per rank
+        x, msk = synthetic.rect_occlusion(x, seed=10 + rank)
+        lab = synthetic.labels(2, 50, seed=10 + rank)
+        try:
+            opt.zero_grad()
+            cls, seg, _ = m(x.cuda(), lab.cuda())
+            loss = torch.nn.functional.cross_entropy(cls, lab.cuda()) + \
+                StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
+            loss.backward()
+            fired = sum(opt.fired) if overlap else 0
+            opt.all_reduce_grads(world)
+            torch.cuda.synchronize()
+            return opt.flat_g.clone(), fired, (len(opt.buckets) if overlap else 0)
+        finally:
+            ops.WGRAD_STREAM = ops.OSB_STREAM = None
+            opt.release()
+    ga, _, _ = grads(False)
+    gb, fired, nb = grads(True)
+    out["ddp_equal"] = int(torch.equal(ga, gb))
+    out["ddp_fired_during_backward"] = fired
+    out["ddp_buckets"] = nb
+    out["ddp_gsum"] = float(ga.double().abs().sum().item())
     np.savez(os.path.join(outdir, "r%d.npz" % rank), **out)
     dist.destroy_process_group()
 

@@ -172,3 +172,11 @@ def test_partial_fc_hip_two_ranks_one_gpu(pfc_rank_results):
         assert abs(z["bf16_loss"] - g[pre + "loss"]) < 5e-3 * abs(g[pre + "loss"])
         assert rel_err(z["bf16_x_grad"], g[pre + "x_grad"]) < 2e-2
         assert rel_err(z["bf16_wgrad_pick"], g[pre + "wgrad_pick"]) < 2e-2
+    # the same two processes also ran the overlapped bucketed gradient all-reduce (world size 2, side streams on):
+    # identical to the non-overlapped reduce on both ranks, most buckets fired while the backward was still running,
+    # and both ranks hold the same averaged gradient
+    z0, z1 = (np.load(os.path.join(outdir, "r%d.npz" % r)) for r in range(2))
+    for z in (z0, z1):
+        assert int(z["ddp_equal"]) == 1
+        assert int(z["ddp_buckets"]) >= 4 and int(z["ddp_fired_during_backward"]) >= int(z["ddp_buckets"]) - 1
+    assert abs(float(z0["ddp_gsum"]) - float(z1["ddp_gsum"])) <= 1e-6 * float(z0["ddp_gsum"])
