@@ -32,9 +32,12 @@ PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_deco
 # head 2.3 %, OSB 0.4-1.1 %; batch 32 -- gnorm 0.1 %, early FRB 10-14 %, late FRB 3 %, head 1.3 %, OSB
 # 0.5-0.8 %.  (BatchNorm1d over 4 samples in front of a s=64 ArcFace head amplifies operand rounding: the
 # batch-4 goldens are a conditioning stress test, the batch-32 golden is the gauge.)  The HIP path also
-# rounds the backward operands, hence the factor ~2.5 on the FRB numbers.
+# rounds the backward operands, hence the factor ~2.5 on the FRB numbers.  At batch 4 the head pick is a draw
+# from that noise, not a constant: two equally valid bf16 roundings of the OSB decoder (im2col kernels vs the
+# tile+halo kernels that replaced them) moved classification.weight between 8e-2 and 1.6e-1 while the
+# batch-32 value stayed at 3.5e-2 -- the batch-4 head bound is set at the FRB noise level for that reason.
 TOL = {          # batch: (loss, gnorm, OSB picks, head picks, FRB picks, running stats)
-    4: (2e-2, 1.5e-1, 3e-2, 1e-1, 6e-1, 2e-2),
+    4: (2e-2, 1.5e-1, 3e-2, 2.5e-1, 6e-1, 2e-2),
     32: (5e-3, 2e-2, 3e-2, 1e-1, 3.5e-1, 1e-2),
 }
 
