@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--shapes", default="", help="comma-separated indices into SHAPES")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--zeros", action="store_true",
+                    help="all-zero operands: the clock the chip holds rises (MI355X_MICROARCH.md DVFS give-back), "
+                         "so random-vs-zero tells whether a kernel is clock-limited")
     args = ap.parse_args()
     dt = _lib.BF16 if args.dtype == "bf16" else _lib.F32
     tdt = _lib.TORCH_DTYPE[dt]
@@ -54,6 +57,8 @@ def main():
         x = torch.randn(n, h, h, cin, device="cuda").to(tdt)
         w = torch.randn(cout, cin, r, r, device="cuda") * 0.05
         dy = torch.randn(n, p, p, cout, device="cuda").to(tdt)
+        if args.zeros:
+            x.zero_(); w.zero_(); dy.zero_()
         wp = ops.pack_weight(w, False, cin, 0, dt)
         wpt = ops.pack_weight(w, True, cout, 0, dt)
         dw = torch.empty_like(w)
