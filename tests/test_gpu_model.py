@@ -72,6 +72,25 @@ def test_eval_fp16_default_meets_the_parity_bar(frb, fname, bs):
     assert err < 2e-4            # measured ~1e-5: keep an order of magnitude of margin visible
 
 
+@pytest.mark.parametrize("fp16", [False, True])
+def test_eval_ires34_vs_oracle(fp16):
+    """iresnet34 ([3, 4, 6, 3], the third FRB the reference's MSML constructs: backbones/msml.py:106-108) has no
+    recorded golden: compare with the CPU oracle (itself pinned to the reference on ires18 / 50 / 100) run here on
+    the same fill and inputs -- f32 and the fp16=True default (bf16x3) to the same bar as the goldens."""
+    torch.manual_seed(0)
+    ref = fill_module(om.MSML("iresnet34", "unet", (1, 1, 1, 1), 1000, fm_params=(3, 2, "sigmoid", "mul"),
+                              header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0))).eval()
+    m = hip_msml("iresnet34", fp16=fp16).eval()
+    x, _ = eval_inputs(2)
+    with torch.no_grad():
+        rf, rseg = ref(x)
+        feat, seg = m(x.cuda())
+    err = rel_err(feat.cpu().numpy(), rf.numpy())
+    assert err < 1e-3, err
+    assert torch.equal(Fh.mask_index(seg).cpu().long(), rseg.float().max(dim=1)[1])       # train.py:357
+    assert rel_err(seg.float().cpu().numpy(), rseg.numpy()) < 1e-4
+
+
 def test_eval_ires18_bf16_fast_mode():
     """eval_precision='bf16' (plain bf16 operands, the throughput mode): documented tolerance -- it does
     NOT meet the 1e-3 bar (DESIGN.md 'precision modes'), which is why it is not the default."""
