@@ -322,6 +322,9 @@ int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W
 bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
                             int splits, hipStream_t st, const BnIn* xin = nullptr);
 
+int msml_fc_wgrad_launch(const void* u, int up, const void* v, int vp, float* dw, int A, int Breal, int Btot, int boff,
+                         int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
+                         int accumulate, hipStream_t st);      // fc_wgrad.hip
 int msml_wgrad_n32_splits(int up, int vp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
                           int pad_w);
 bool msml_wgrad_n32_launch(const void* u, const void* v, float* ws, int N, int H, int W, int P, int Q, int R,
@@ -423,6 +426,11 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   dim3 grid(atiles, btiles * taps, splits);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSML_BF16) {
+    if (msml_fc_wgrad_launch(u, up, v, vp, dw, A, Breal, Btot, boff, N, H, W, P, Q, R, S, stride, pad_h, pad_w,
+                             accumulate, st)) {
+      MSML_LAUNCH_OK("conv_wgrad(fc)");
+      return MSML_OK;
+    }
     const int ns = msml_wgrad_n32_splits(up, vp, N, H, W, P, Q, R, S, stride, pad_h, pad_w);
     if (ns > 0 && msml_wgrad_n32_launch(u, v, a.ws, N, H, W, P, Q, R, stride, ns, st)) {
       MSML_LAUNCH_OK("conv_wgrad(n32)");

@@ -591,3 +591,23 @@ def test_deconv4_bwd_data_both_segments(h):
     assert (ops.to_nchw(g0, 18).cpu() - ref[:, :18]).abs().max().item() <= 1.5e-2 * scale
     assert (ops.to_nchw(g1, 18).cpu() - ref[:, 18:]).abs().max().item() <= 1.5e-2 * scale
     assert g0[..., 18:].abs().max().item() == 0 and g1[..., 18:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("n,c,e,k,boff,btot,acc", [(256, 512, 512, 7, 0, 512, 0), (40, 64, 96, 7, 0, 64, 1),
+                                                   (16, 32, 32, 4, 32, 96, 0), (33, 64, 64, 3, 0, 64, 1)])
+def test_fc_wgrad_window(n, c, e, k, boff, btot, acc):
+    """Weight gradient of flatten + Linear on a k x k map (the 'window' conv: R = H, S = W, one output pixel) on the
+    all-taps-per-workgroup kernel (fc_wgrad.hip): against f64 torch, with a batch that is not a multiple of the
+    16-image k-step, a channel offset into a wider dW (two-segment inputs) and accumulation into a live gradient."""
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, k, k, generator=g).bfloat16().float()
+    dy = torch.randn(n, e, 1, 1, generator=g).bfloat16().float()
+    ref = torch.einsum("ne,nchw->echw", dy[:, :, 0, 0].double(), x.double()).float()
+    dw = torch.full((e, btot, k, k), 0.25, device="cuda")
+    ops.conv_wgrad(ops.to_nhwc(dy.cuda(), _lib.BF16), ops.to_nhwc(x.cuda(), _lib.BF16), dw, e, c, btot, boff, k, k, 1, 0, 0,
+                   accumulate=bool(acc))
+    got = dw[:, boff:boff + c].cpu()
+    want = ref + (0.25 if acc else 0.0)
+    assert (got - want).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    rest = torch.cat([dw[:, :boff], dw[:, boff + c:]], 1)
+    assert (rest == 0.25).all()                     # columns of other segments are left alone

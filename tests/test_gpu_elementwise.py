@@ -127,3 +127,55 @@ def test_pack_refresh_tiled_matches_elementwise():
         want = ref.get(w, *sp[1:], _lib.BF16)
         got = cache.get(w, *sp[1:], _lib.BF16)
         assert torch.equal(got, want), sp
+
+
+@pytest.mark.parametrize("E", [512, 1024, 320])          # 512 / 1024: the 8-per-lane kernels; 320: the scalar ones
+@pytest.mark.parametrize("dtype,tol", DT)
+def test_rownorm_fwd_bwd(E, dtype, tol):
+    """F.normalize of the head weight rows (headers/partial_fc.py:126, margin_losses.py:274) and its backward,
+    against f64 torch; padded rows [R, Rp) come back zero."""
+    torch.manual_seed(E)
+    R, Rp = 301, 320
+    w = (torch.randn(R, E, dtype=torch.float64) * 0.3).requires_grad_(True)
+    wn = torch.nn.functional.normalize(w)
+    dy = torch.randn(R, E, dtype=torch.float64)
+    wn.backward(dy)
+    wd = w.detach().float().cuda()
+    dst = torch.full((Rp, E), 7.0, device="cuda").to(_lib.TORCH_DTYPE[dtype])
+    inv = torch.empty(R, device="cuda")
+    _lib.call("msml_rownorm_fwd", wd, R, Rp, E, dst, E, inv, dtype)
+    assert (dst[:R].double().cpu() - wn.detach()).abs().max() < tol
+    assert (dst[R:] == 0).all()
+    assert ((inv.double().cpu() - 1.0 / w.detach().norm(dim=1)).abs() * w.detach().norm(dim=1)).max() < 1e-5
+    for acc in (0, 1):
+        dw = torch.full((R, E), 0.5, device="cuda")
+        _lib.call("msml_rownorm_bwd", wd, inv, dy.float().cuda(), E, R, E, dw, acc)
+        ref = w.grad + (0.5 if acc else 0.0)
+        assert (dw.double().cpu() - ref).abs().max() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("C,ld", [(1000, 1024), (85742, 85760), (37, 37), (5, 8)])
+@pytest.mark.parametrize("kind", ["arc", "cos"])
+def test_pfc_rowstats(C, ld, kind):
+    """Online (row max, sum exp) of the margin logits of one class shard (headers/partial_fc.py:132-141) against
+    f64 torch, rows with and without a local target; ld % 4 == 0 takes the 16-B-load kernel, 37 the scalar one."""
+    from msml_amd import functional as Fh
+    torch.manual_seed(C)
+    n, s, m = 9, 64.0, 0.4
+    cos = (torch.rand(n, ld, dtype=torch.float64) * 1.6 - 0.8)
+    label = torch.randint(0, C, (n,))
+    label[::3] = -1
+    logits = s * cos[:, :C].clone()
+    for i in range(n):
+        y = int(label[i])
+        if y >= 0:
+            th = torch.acos(cos[i, y])
+            logits[i, y] = s * torch.cos(th + m) if kind == "arc" else s * (cos[i, y] - m)
+    rm, rs = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    _lib.call("msml_pfc_rowstats", cos.float().cuda(), ld, n, C, label.cuda(), Fh.HEAD_KIND[kind], s, m, 0.0, 0.0, rm, rs)
+    mx = logits.max(dim=1)[0]
+    # the kernel's max may be any valid max of the row (it is the row max): compare log-sum-exp, then the max itself
+    lse_ref = mx + torch.log(torch.exp(logits - mx[:, None]).sum(1))
+    lse = rm.double().cpu() + torch.log(rs.double().cpu())
+    assert (lse - lse_ref).abs().max() < 2e-4
+    assert (rm.double().cpu() - mx).abs().max() < 1e-4

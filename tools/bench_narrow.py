@@ -100,3 +100,33 @@ def deconv():
 
 if __name__ == "__main__":
     deconv()
+
+
+def fc():
+    """fc (flatten + Linear 25 088 -> 512) weight gradient, and the head's element-wise kernels."""
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    x = torch.randn(n, 7, 7, 512, device="cuda").bfloat16()
+    dy = torch.randn(n, 1, 1, 512, device="cuda").bfloat16()
+    dw = torch.zeros(512, 512, 7, 7, device="cuda")
+    for acc in (False, True):
+        t = timeit(lambda: ops.conv_wgrad(dy, x, dw, 512, 512, 512, 0, 7, 7, 1, 0, 0, accumulate=acc))
+        print("%-40s %8.1f us  %7.1f TFLOP/s" % ("fc wgrad 25088->512 acc=%d" % acc, t * 1e6, 2.0 * n * 25088 * 512 / t / 1e12))
+    c, e = 85742, 512
+    w = torch.randn(c, e, device="cuda")
+    wn = torch.empty(85760, e, device="cuda", dtype=torch.bfloat16)
+    inv = torch.empty(c, device="cuda")
+    t = timeit(lambda: _lib.call("msml_rownorm_fwd", w, c, 85760, e, wn, e, inv, BF))
+    print("%-40s %8.1f us  %7.0f GB/s" % ("rownorm_fwd 85742x512", t * 1e6, (c * e * 6) / t / 1e9))
+    g = torch.randn(c, e, device="cuda")
+    dwo = torch.empty(c, e, device="cuda")
+    t = timeit(lambda: _lib.call("msml_rownorm_bwd", w, inv, g, e, c, e, dwo, 0))
+    print("%-40s %8.1f us  %7.0f GB/s" % ("rownorm_bwd 85742x512", t * 1e6, (c * e * 12) / t / 1e9))
+    cos = torch.rand(n, 85760, device="cuda") - 0.5
+    lab = torch.randint(0, c, (n,), device="cuda")
+    rm, rs = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    t = timeit(lambda: _lib.call("msml_pfc_rowstats", cos, 85760, n, c, lab, 0, 64.0, 0.5, 0.0, 0.0, rm, rs))
+    print("%-40s %8.1f us  %7.0f GB/s" % ("pfc_rowstats 256x85742", t * 1e6, (n * c * 4) / t / 1e9))
+
+
+if __name__ == "__main__":
+    fc()
