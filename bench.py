@@ -549,8 +549,8 @@ def main():
                 d[q] += v[q]
         if os.environ.get("MSML_PROFILE_DETAIL"):
             for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("MSML_PROFILE_DETAIL") or 45) if os.environ.get("MSML_PROFILE_DETAIL", "1") != "1" else 45]:
-                print("%-52s n=%3d ms/step=%7.3f TF/s=%6.1f" % (name, v["n"] // prof_steps, v["ms"] / prof_steps,
-                      v["flops"] / max(v["ms"], 1e-9) / 1e9), file=sys.stderr)
+                print("%-52s n=%3d ms/step=%7.3f TF/s=%6.1f GB/s=%6.0f" % (name, v["n"] // prof_steps, v["ms"] / prof_steps,
+                      v["flops"] / max(v["ms"], 1e-9) / 1e9, v["bytes"] / max(v["ms"], 1e-9) / 1e6), file=sys.stderr)
         peak = PEAK_TFLOPS[args.dtype]
         if "conv_igemm" not in fam:            # inference runs: fused / split-precision conv labels
             fam["conv_igemm"] = dict(fam.get("conv_x3") or fam.get("conv_fused") or

@@ -49,8 +49,7 @@ class _Conv(torch.autograd.Function):
             wp = ops.PACKS.get(weight, deconv, 0, weight.shape[0], 0, weight.shape[1], c0, c1, dtype)
         bp = None
         if bias is not None:
-            bp = torch.zeros(cpad(cout), dtype=torch.float32, device=x0.device)
-            bp[:cout] = bias.detach()
+            bp = ops.padded_bias(bias, cpad(cout))
         y, stats = ops.conv2d(x0, x1, wp, bp, cpad(cout), r, s, cfg["stride"], cfg["pad_h"],
                               cfg["pad_w"], deconv, out_dtype=cfg.get("out_dtype"),
                               want_stats=cfg.get("want_stats", False), real=(c0 + c1, cout))

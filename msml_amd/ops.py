@@ -17,6 +17,7 @@ class _Profile:
     def __init__(self):
         self.on = False
         self.recs = []
+        self.by_size = bool(os.environ.get("MSML_PROFILE_BY_SIZE"))    # diagnostic: split byte-bound labels by traffic
 
     def start(self):
         self.recs = []
@@ -25,6 +26,8 @@ class _Profile:
     def rec(self, name, flops=0.0, nbytes=0.0):
         if not self.on:
             return _NO_REC             # shared no-op context: ~1500 launches per step pass through here
+        if nbytes and not flops and self.by_size:
+            name = "%s %dMB" % (name, int(nbytes) >> 20)
         return _Rec(self, name, flops, nbytes)
 
     def stop(self):
@@ -501,4 +504,21 @@ class PackCache:
 
 
 WEIGHT_EPOCH = 0          # bumped by optimizers that update parameters behind torch's back
+
+
+def padded_bias(bias, cp):
+    """f32 [cp] copy of a conv bias for the kernels' padded channel count.  The buffer lives on the parameter
+    (its padding stays zero), and is refreshed with ONE copy when the parameter changed -- the zeros + slice
+    copy it replaces were two launches per biased conv and step."""
+    b = bias.detach()
+    if b.numel() == cp and b.dtype == torch.float32 and b.is_contiguous():
+        return b
+    stamp = (bias._version, WEIGHT_EPOCH, bias.data_ptr(), cp)
+    hit = getattr(bias, "_msml_bias_pad", None)
+    if hit is None or hit[0] != stamp:
+        buf = hit[1] if hit is not None and hit[1].numel() == cp and hit[1].device == b.device else \
+            torch.zeros(cp, dtype=torch.float32, device=b.device)
+        buf[:b.numel()].copy_(b)
+        bias._msml_bias_pad = hit = (stamp, buf)
+    return hit[1]
 PACKS = PackCache()

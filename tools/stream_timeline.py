@@ -37,3 +37,22 @@ for s, e in allbusy[1:]:
         cur_e = max(cur_e, e)
 union += cur_e - cur_s
 print("GPU busy (union of all kernels) %.2f ms = %.1f %% of the step" % (union / 1e6, 100.0 * union / (t1 - t0)))
+
+# idle time (no kernel of any stream running), attributed to the kernel that ENDS the gap
+gaps = collections.defaultdict(lambda: [0, 0.0])
+evs = sorted([(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-44:]) for r in sel])
+cur_e = evs[0][1]
+half = t0 + (t1 - t0) // 2
+idle_half = [0.0, 0.0]
+for s, e, name in evs[1:]:
+    if s > cur_e:
+        g = gaps[name]
+        g[0] += 1
+        g[1] += (s - cur_e) / 1e3
+        idle_half[0 if s < half else 1] += (s - cur_e) / 1e3
+    cur_e = max(cur_e, e)
+tot = sum(v[1] for v in gaps.values())
+print("idle %.2f ms in %d gaps (first half of the step %.2f ms, second half %.2f ms); by the kernel that ends the gap:" % (
+    tot / 1e3, sum(v[0] for v in gaps.values()), idle_half[0] / 1e3, idle_half[1] / 1e3))
+for name, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
+    print("   %-46s %4d gaps %8.1f us  (%.1f us each)" % (name, v[0], v[1], v[1] / v[0]))
