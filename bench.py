@@ -348,19 +348,26 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # rehearsal of the multi-rank control flow on a ONE-GPU box (MSML_BENCH_ONE_GPU=1): every rank on device 0, gloo
+    # instead of RCCL (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+    one_gpu = bool(os.environ.get("MSML_BENCH_ONE_GPU"))
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     force_dist = bool(os.environ.get("MSML_FORCE_DIST"))   # exercise the RCCL path at world == 1
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
     from msml_amd import ops
     if args.no_graph or (world > 1 and args.launch == "auto"):
         # multi-rank: eager only -- capturing RCCL collectives into a hipGraph was verified with a
         # one-rank communicator only, and a capture that fails mid-collective cannot be retried
         args.launch = "eager"
     side_stream = torch.cuda.Stream()
-    runner = (Trainer if args.mode == "train" else Inferer)(args, rank, local_rank, world)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the heads announce themselves like the reference's do: stdout
+        runner = (Trainer if args.mode == "train" else Inferer)(args, rank, local_rank, world)   # carries the JSON line only
 
     def barrier():
         torch.cuda.synchronize()
@@ -602,11 +609,15 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         try:
-            rec["modes"] = extra_modes(args, rank, local_rank)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):
+                rec["modes"] = extra_modes(args, rank, local_rank)
         except Exception as e:                                  # pragma: no cover (diagnostic path)
             rec["modes"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline and args.mode == "train":
-        rec["cpu_baseline"] = cpu_baseline(args)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):
+            rec["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(rec), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
