@@ -124,6 +124,16 @@ int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, const void* 
                 int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int transposed,
                 int in_dtype, int out_dtype, void* stream);
 
+/* msml_conv2d whose BatchNorm statistics go to an ACCUMULATOR instead of partial rows: `acc` is a zero-initialised
+ * double[8][2][coutp]; every workgroup adds its per-channel (sum, sumsq) of the stored output with f64 atomics into
+ * row (workgroup index % 8).  f64 sums of f32 partials are exact unless two partials differ by more than 2^29, so the
+ * totals do not depend on the order of the adds.  Consumed by msml_bn_fin_act_fwd (no finalize launch in between:
+ * the nn.BatchNorm2d that follows a conv in IBasicBlock, backbones/frb/iresnet.py:56-67). */
+int msml_conv2d_acc(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
+                    const float* bias, void* out, int coutp, double* acc, int N, int H, int W,
+                    int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int transposed,
+                    int in_dtype, int out_dtype, void* stream);
+
 /* Weight gradient of the same family of layers (autograd of the call sites above, and
  * headers/partial_fc.py:169 sub_weight.grad):
  *   dw[a][boff+b][r][s] (+)= sum_{n,py,px} u[n,py,px,a] * v[n, py*stride-pad_h+r, px*stride-pad_w+s, b]
@@ -179,6 +189,15 @@ int msml_bn_act_fwd_stats_rows(long M, int C);
 int msml_bn_act_fwd_stats(const void* x, const float* scale, const float* shift, const float* alpha,
                           const void* residual, int res_first, void* y, long M, int C,
                           float* stats, int dtype, void* stream);
+/* msml_bn_finalize (training mode) + msml_bn_act_fwd[_stats] in ONE launch from an accumulator (msml_conv2d_acc):
+ * every workgroup folds acc[8][2][C] and derives the coefficients itself, workgroup 0 writes scale / shift /
+ * save_mean / save_invstd and updates the running statistics; acc_out (optional, zero-initialised
+ * double[8][2][C]) receives the (sum, sumsq) of the stored output.  C / 8 must divide 256. */
+int msml_bn_fin_act_fwd(const double* acc, double count, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                        float* shift, float* save_mean, float* save_invstd, const void* x,
+                        const float* alpha, const void* residual, int res_first, void* y, long M, int C,
+                        double* acc_out, int dtype, void* stream);
 int msml_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
                     const float* alpha, const float* save_mean, const float* save_invstd,
                     const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,

@@ -28,6 +28,7 @@ def _bn_pack(bn):
 def _bn_coef(x, stats, bnp):
     """Batch statistics -> coef[4][C] = scale, shift, mean, invstd of a training-mode BatchNorm
     (running statistics updated); stats: partial rows from the producer of x, or None."""
+    assert not _is_acc(stats), "accumulator-mode statistics go through _bn_fin_apply"
     c = x.shape[-1]
     m = x.numel() // c
     coef = torch.empty(4, c, dtype=torch.float32, device=x.device)
@@ -58,9 +59,32 @@ def _bn_apply(x, coef, alpha, residual, emit_stats=False, res_first=0):
     return y
 
 
+def _bn_fin_apply(x, acc, bnp, alpha, residual, emit_stats=False, res_first=0):
+    """Accumulator-mode statistics (ops.ACC_STATS): finalize + apply (+ statistics of y into a fresh accumulator) in
+    ONE launch.  Returns (y, coef[, accumulator of y])."""
+    c = x.shape[-1]
+    m = x.numel() // c
+    coef = torch.empty(4, c, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    yacc = ops.stats_acc(c, x.device) if emit_stats else None
+    with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
+        call("msml_bn_fin_act_fwd", acc, float(m), bnp[0], bnp[1], bnp[2], bnp[3], bnp[4], bnp[5], coef[0], coef[1],
+             coef[2], coef[3], x, alpha, residual, res_first, y, m, c, yacc, BF16)
+    ops.bn_counter(bnp[6])
+    if emit_stats:
+        return y, coef, yacc
+    return y, coef
+
+
+def _is_acc(stats):
+    return stats is not None and stats.dtype == torch.float64
+
+
 def _bn_fwd(x, stats, bnp, alpha, residual, emit_stats=False):
     """Training-mode BatchNorm (+PReLU) (+residual after it) on raw NHWC tensors.
     Returns (y, coef[4][C] = scale, shift, mean, invstd[, partial statistics of y])."""
+    if _is_acc(stats):
+        return _bn_fin_apply(x, stats, bnp, alpha, residual, emit_stats)
     coef = _bn_coef(x, stats, bnp)
     if emit_stats:
         y, ystats = _bn_apply(x, coef, alpha, residual, True)
@@ -84,6 +108,10 @@ def _bn_conv_fwd(x, stats, bnp, alpha, cp):
     """BatchNorm(+PReLU) -> conv.  When the conv's kernels can take the BatchNorm as an input
     transform (ops.bnin_applies) the normalised activation is never written: returns
     (None, coef, conv out, conv out statistics), else (activation, coef, conv out, statistics)."""
+    if _is_acc(stats):
+        o, coef = _bn_fin_apply(x, stats, bnp, alpha, None)
+        y, st = _conv_fwd(o, cp)
+        return o, coef, y, st
     coef = _bn_coef(x, stats, bnp)
     w, (cout, cin, r, s), stride, ph, pw = cp
     n, h, wd, cp_in = x.shape
@@ -349,8 +377,11 @@ class _Bottle(torch.autograd.Function):
         c2, st2 = _conv_fwd(o1, bp["c2"])
         o2, k2 = _bn_fwd(c2, st2, bp["bn2"], bp["a2"], None)
         c3, st3 = _conv_fwd(o2, bp["c3"])
-        k3 = _bn_coef(c3, st3, bp["bn3"])
-        out = _bn_apply(c3, k3, bp["a3"], x, res_first=1)          # prelu3(bn3(c3) + x)
+        if _is_acc(st3):
+            out, k3 = _bn_fin_apply(c3, st3, bp["bn3"], bp["a3"], x, res_first=1)
+        else:
+            k3 = _bn_coef(c3, st3, bp["bn3"])
+            out = _bn_apply(c3, k3, bp["a3"], x, res_first=1)      # prelu3(bn3(c3) + x)
         ctx.bp = bp
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, c1, o1, c2, o2, c3, k1, k2, k3)

@@ -350,6 +350,130 @@ extern "C" int msml_bn_act_fwd_stats(const void* x, const float* scale, const fl
   return MSML_OK;
 }
 
+// ------------------------------------------------------------------ finalize + apply, one launch ----
+// Accumulator mode (common.h): the producer of x added its per-workgroup (sum, sumsq) into acc[MSML_ACC_ROWS][2][C]
+// (f64 atomics); every workgroup folds the rows and derives (scale, shift) of all C channels into LDS -- 32 KB of L2
+// reads and C rsqrt per workgroup -- and workgroup 0 also writes them (with mean / invstd for the backward) and
+// updates the running statistics exactly like k_bn_finalize.  The 5-7 us finalize launch between the producer and
+// this kernel disappears (266 of them per training step of ires50-MSML).  STATS: the (sum, sumsq) of the OUTPUT go to
+// acc_out the same way (next block's leading BatchNorm).
+template <typename T, bool STATS>
+__global__ void __launch_bounds__(256) k_bn_fin_act_fwd(const double* __restrict__ acc, double count,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                                        float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                        float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                        const T* __restrict__ x, const float* __restrict__ alpha,
+                                                        const T* __restrict__ residual, int res_first,
+                                                        T* __restrict__ y, long n8, int C8, double* __restrict__ acc_out) {
+  extern __shared__ float cs[];                        // [2][C]: scale, shift
+  const int C = C8 * 8, t = threadIdx.x;
+  for (int c = t; c < C; c += 256) {
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < MSML_ACC_ROWS; r++) {
+      s += acc[(r * 2 + 0) * C + c];
+      ss += acc[(r * 2 + 1) * C + c];
+    }
+    const double m = s / count;
+    double var = ss / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd, sh = b - mean * g * invstd;
+    cs[c] = sc;
+    cs[C + c] = sh;
+    if (blockIdx.x == 0) {
+      scale[c] = sc;
+      shift[c] = sh;
+      save_mean[c] = mean;
+      save_invstd[c] = invstd;
+      if (rmean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const long tid = blockIdx.x * (long)blockDim.x + t;
+  const int c0 = (int)(tid % C8) * 8;
+  Coef8 sc, sh;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    sc.v[j] = cs[c0 + j];
+    sh.v[j] = cs[C + c0 + j];
+  }
+  const Coef8 al = ldc8(alpha, c0, 1.f);
+  float q1[8], q2[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) q1[j] = q2[j] = 0.f;
+  for (long i = tid; i < n8; i += (long)gridDim.x * blockDim.x) {
+    Vec8 v = load8<T>(x + i * 8);
+    Vec8 r;
+    if (residual) r = load8<T>(residual + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float z = v.v[j] * sc.v[j] + sh.v[j];
+      if (residual && res_first) z += r.v[j];
+      if (alpha) z = z > 0.f ? z : z * al.v[j];
+      if (residual && !res_first) z += r.v[j];
+      v.v[j] = z;
+    }
+    store8<T>(y + i * 8, v);
+    if (STATS) {
+      const Vec8 vr = round8<T>(v);                    // what the consumer will read back
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        q1[j] += vr.v[j];
+        q2[j] += vr.v[j] * vr.v[j];
+      }
+    }
+  }
+  if (STATS) {
+    __shared__ float red[2][256][9];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      red[0][t][j] = q1[j];
+      red[1][t][j] = q2[j];
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * C; i += 256) {
+      const int which = i / C, c = i % C, cx = c >> 3, j = c & 7;
+      float sum = 0.f;
+      for (int k = cx; k < 256; k += C8) sum += red[which][k][j];
+      stats_emit(reinterpret_cast<float*>(acc_out), 1, blockIdx.x, which, C, c, sum);
+    }
+  }
+}
+
+extern "C" int msml_bn_fin_act_fwd(const double* acc, double count, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                                   float* shift, float* save_mean, float* save_invstd, const void* x,
+                                   const float* alpha, const void* residual, int res_first, void* y, long M, int C,
+                                   double* acc_out, int dtype, void* stream) {
+  MSML_CHECK(acc && x && y && scale && shift && save_mean && save_invstd && M > 0 && C > 0 && C % 8 == 0 && count > 0,
+             MSML_ERR_SHAPE, "bn_fin_act_fwd: bad arguments M=%ld C=%d", M, C);
+  MSML_CHECK(256 % (C / 8) == 0, MSML_ERR_UNSUPPORTED, "bn_fin_act_fwd: C/8 = %d must divide 256", C / 8);
+  const long n8 = M * (C / 8);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (acc_out) {
+    MSML_DISPATCH_DTYPE(dtype, "bn_fin_act_fwd",
+                        (k_bn_fin_act_fwd<DT, true>)<<<ew_grid_c(n8, C / 8), 256, lds, st>>>(
+                            acc, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
+                            save_invstd, (const DT*)x, alpha, (const DT*)residual, res_first, (DT*)y, n8, C / 8, acc_out);)
+  } else {
+    MSML_DISPATCH_DTYPE(dtype, "bn_fin_act_fwd",
+                        (k_bn_fin_act_fwd<DT, false>)<<<ew_grid_c(n8, C / 8), 256, lds, st>>>(
+                            acc, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
+                            save_invstd, (const DT*)x, alpha, (const DT*)residual, res_first, (DT*)y, n8, C / 8, nullptr);)
+  }
+  MSML_LAUNCH_OK("bn_fin_act_fwd");
+  return MSML_OK;
+}
+
 // ------------------------------------------------------------------ backward ------------------
 // With z = x*scale + shift, g = dy * prelu'(z), xhat = (x - mean) * invstd:
 //   reduce: s1 = sum g, s2 = sum g * xhat, s3 = sum dy * min(z, 0)   (d alpha)

@@ -6,6 +6,14 @@
 
 #include "../../include/msml_hip.h"
 
+// BatchNorm statistics in ACCUMULATOR mode (msml_conv2d_acc / msml_bn_fin_act_fwd, bn.hip): the `stats` pointer of a
+// producer is a zero-initialised double[MSML_ACC_ROWS][2][C] and every workgroup adds its per-channel (sum, sumsq)
+// with f64 atomics into row (workgroup index % MSML_ACC_ROWS) instead of storing a partial row of its own.  The
+// f64 sum of f32 partials is exact unless two partials differ by more than 2^29, so the result does not depend on
+// the order of the adds (and equals the fixed-order f64 sum of the row format).  The mode travels from the C entry
+// point to the launch sites in a thread-local (set and reset inside one call: the library stays reentrant).
+#define MSML_ACC_ROWS 8
+extern thread_local int msml_tl_stats_acc;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -118,6 +126,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// one per-channel partial of a producer workgroup: a row store, or an f64 atomic add in accumulator mode
+__device__ __forceinline__ void stats_emit(float* stats, int acc_mode, long wg, int which, int C, int col, float v) {
+  if (acc_mode)
+    unsafeAtomicAdd(reinterpret_cast<double*>(stats) + ((wg & (MSML_ACC_ROWS - 1)) * 2 + which) * C + col, (double)v);
+  else
+    stats[(wg * 2 + which) * C + col] = v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -43,6 +43,7 @@ struct ConvFastArgs {
   const unsigned short* residual;
   int res_first;
   float* stats;
+  int stats_acc;      // accumulator mode (common.h): stats is double[MSML_ACC_ROWS][2][coutp]
   BnBwdFuse bnb;      // bnb.partial != nullptr: fused BatchNorm backward-reduce (common.h)
   long M;
   int tiles_m;
@@ -520,7 +521,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
       for (int w = 0; w < WPH; w++) v += red[((hf * WPH + w) * 2 + which) * BN + c];
       int col = n0 + c;
       long srow = (long)bid * NH + hf;
-      if (col < p.coutp && srow * SROWS < Mc) p.stats[(srow * 2 + which) * p.coutp + col] = v;
+      if (col < p.coutp && srow * SROWS < Mc) stats_emit(p.stats, p.stats_acc, srow, which, p.coutp, col, v);
     }
   }
 #endif
@@ -614,6 +615,7 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   a.stride_shift = stride == 1 ? 0 : (stride == 2 ? 1 : 2);
   a.pad_h = pad_h; a.pad_w = pad_w; a.transposed = transposed;
   a.wp = (const unsigned short*)wp; a.out = out; a.coutp = coutp; a.bias = bias; a.stats = stats;
+  a.stats_acc = stats ? msml_tl_stats_acc : 0;
   a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual; a.res_first = res_first;
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
@@ -676,7 +678,7 @@ bool msml_conv_fast_splitk(const void* in0, int c0p, const void* wp, int kop, fl
   a.w_bytes = (unsigned int)w_bytes;
   a.N = N; a.H = 1; a.W = 1; a.P = 1; a.Q = 1; a.R = 1; a.S = 1;
   a.stride = 1; a.stride_shift = 0; a.pad_h = 0; a.pad_w = 0; a.transposed = 0;
-  a.wp = (const unsigned short*)wp; a.out = ws; a.coutp = coutp; a.bias = nullptr; a.stats = nullptr;
+  a.wp = (const unsigned short*)wp; a.out = ws; a.coutp = coutp; a.bias = nullptr; a.stats = nullptr; a.stats_acc = 0;
   a.scale = nullptr; a.alpha = nullptr; a.residual = nullptr; a.res_first = 0;
   a.bnb = BnBwdFuse{};
   a.M = N;

@@ -43,6 +43,7 @@ struct ConvHaloArgs {
   int res_first;
   float* stats;
   int stats_rows;
+  int stats_acc;      // accumulator mode (common.h): stats is double[MSML_ACC_ROWS][2][coutp]
   BnBwdFuse bnb;      // bnb.partial != nullptr: fused BatchNorm backward-reduce (common.h)
   BnIn xin;           // xin.scale != nullptr: BatchNorm(+PReLU) applied to the input image in LDS (common.h)
 };
@@ -446,9 +447,9 @@ k_conv_halo(const ConvHaloArgs p) {
       for (int gm = 0; gm < NWM; gm++)
 #pragma unroll 8
         for (int rr = 0; rr < 32; rr++) sum += red[gm * KG * 64 * 33 + (hh * 32 + rr) * 33 + k];
-      p.stats[((long)blockIdx.x * 2 + which) * p.coutp + n0 + kg * 32 + kl] = sum;
+      stats_emit(p.stats, p.stats_acc, blockIdx.x, which, p.coutp, n0 + kg * 32 + kl, sum);
     }
-    for (int row = gridDim.x + blockIdx.x; row < p.stats_rows; row += gridDim.x)
+    for (int row = gridDim.x + blockIdx.x; !p.stats_acc && row < p.stats_rows; row += gridDim.x)
       for (int c = t; c < 2 * BN; c += NT)
         p.stats[((long)row * 2 + c / BN) * p.coutp + n0 + c % BN] = 0.f;
   }
@@ -511,6 +512,7 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   a.bias = bias; a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual;
   a.res_first = res_first; a.stats = stats;
   a.stats_rows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
+  a.stats_acc = stats ? msml_tl_stats_acc : 0;
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
   a.xin = BnIn{nullptr, nullptr, nullptr};

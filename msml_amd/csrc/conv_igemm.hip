@@ -35,6 +35,7 @@ struct ConvArgs {
   int coutp;        // output channel stride (and valid column bound)
   const float* bias;
   float* stats;     // [tiles_m][2][coutp] partial (sum, sumsq) or null
+  int stats_acc;    // accumulator mode (common.h): stats is double[MSML_ACC_ROWS][2][coutp]
   long M;
 };
 
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvArgs p) {
 #pragma unroll
       for (int w = 0; w < WGM; w++) v += red[(w * 2 + which) * BN + c];
       int col = n0 + c;
-      if (col < p.coutp) p.stats[((long)blockIdx.x * 2 + which) * p.coutp + col] = v;
+      if (col < p.coutp) stats_emit(p.stats, p.stats_acc, blockIdx.x, which, p.coutp, col, v);
     }
   }
 }
@@ -322,6 +323,8 @@ bool msml_deconv4_applies(int c0p, int c1p, int coutp, int N, int H, int W, int 
                           int pad_h, int pad_w, int transposed);
 bool msml_deconv4_dispatch(const void* in0, const void* in1, const void* wp, int kop, const float* bias, void* out, int N,
                            int H, hipStream_t st);
+
+thread_local int msml_tl_stats_acc = 0;
 
 extern "C" int msml_conv_tile_m(int coutp) { return coutp <= 64 ? 256 : 128; }
 extern "C" int msml_conv_tile_n(int coutp) { return coutp <= 32 ? 32 : (coutp <= 64 ? 64 : 128); }
@@ -359,6 +362,7 @@ extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, c
   a.stride_shift = stride == 1 ? 0 : (stride == 2 ? 1 : 2);
   a.pad_h = pad_h; a.pad_w = pad_w; a.transposed = transposed;
   a.wp = wp; a.out = out; a.coutp = coutp; a.bias = bias; a.stats = stats;
+  a.stats_acc = stats ? msml_tl_stats_acc : 0;
   a.M = (long)N * P * Q;
   const int bn = msml_conv_tile_n(coutp);
   MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE,
@@ -399,6 +403,21 @@ extern "C" int msml_conv2d(const void* in0, int c0p, const void* in1, int c1p, c
 #undef CONV_CASE
   MSML_LAUNCH_OK("conv2d");
   return MSML_OK;
+}
+
+
+// msml_conv2d whose per-channel (sum, sumsq) of the output go to an ACCUMULATOR (common.h): acc is a zero-initialised
+// double[MSML_ACC_ROWS][2][coutp]; consumed by msml_bn_fin_act_fwd without a finalize launch in between.
+extern "C" int msml_conv2d_acc(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
+                               const float* bias, void* out, int coutp, double* acc, int N, int H, int W, int P,
+                               int Q, int R, int S, int stride, int pad_h, int pad_w, int transposed, int in_dtype,
+                               int out_dtype, void* stream) {
+  MSML_CHECK(acc, MSML_ERR_SHAPE, "conv2d_acc: null accumulator");
+  msml_tl_stats_acc = 1;
+  const int rc = msml_conv2d(in0, c0p, in1, c1p, wp, kop, bias, out, coutp, reinterpret_cast<float*>(acc), N, H, W, P, Q,
+                             R, S, stride, pad_h, pad_w, transposed, in_dtype, out_dtype, stream);
+  msml_tl_stats_acc = 0;
+  return rc;
 }
 
 

@@ -32,6 +32,7 @@ struct ConvWsArgs {
   int res_first;
   float* stats;
   int stats_rows;
+  int stats_acc;      // accumulator mode (common.h)
   BnBwdFuse bnb;
   BnIn xin;           // xin.scale != nullptr: BatchNorm(+PReLU) applied to the input image in LDS (common.h)
 };
@@ -297,9 +298,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       for (int gm = 0; gm < 4; gm++)
 #pragma unroll 8
         for (int rr = 0; rr < 32; rr++) sum += red[gm * 2 * 64 * 33 + (hh * 32 + rr) * 33 + k];
-      p.stats[((long)blockIdx.x * 2 + which) * C + kg * 32 + kl] = sum;
+      stats_emit(p.stats, p.stats_acc, blockIdx.x, which, C, kg * 32 + kl, sum);
     }
-    for (int row = gridDim.x + blockIdx.x; row < p.stats_rows; row += gridDim.x)
+    for (int row = gridDim.x + blockIdx.x; !p.stats_acc && row < p.stats_rows; row += gridDim.x)
       for (int c = t; c < 2 * C; c += NT) p.stats[(long)row * 2 * C + c] = 0.f;
   }
 #endif
@@ -361,6 +362,7 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
   a.bias = bias; a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual;
   a.res_first = res_first; a.stats = stats;
   a.stats_rows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
+  a.stats_acc = stats ? msml_tl_stats_acc : 0;
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
   a.xin = BnIn{nullptr, nullptr, nullptr};

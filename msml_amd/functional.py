@@ -162,6 +162,18 @@ class _BnAct(torch.autograd.Function):
         dtype = DTYPE_OF[x.dtype]
         dev = x.device
         coef = torch.empty(4, c, dtype=torch.float32, device=dev)   # scale, shift, mean, invstd
+        if training and stats is not None and stats.dtype == torch.float64:
+            # accumulator-mode statistics (ops.ACC_STATS): finalize + apply in one launch
+            y = torch.empty_like(x)
+            with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
+                call("msml_bn_fin_act_fwd", stats, float(m), gamma, beta, rmean, rvar, momentum, eps, coef[0], coef[1],
+                     coef[2], coef[3], x, alpha, residual, int(res_first), y, m, c, None, dtype)
+            ctx.training = training
+            ctx.has = (gamma is not None, beta is not None, alpha is not None, residual is not None)
+            ctx.res_first = bool(res_first) and residual is not None and alpha is not None
+            ctx.params = (gamma, beta, alpha)
+            ctx.save_for_backward(x, coef, alpha, residual if ctx.res_first else None)
+            return y
         if training:
             if stats is None:
                 rows = ops.bn_stats_rows(m, c)

@@ -137,6 +137,52 @@ def bn_stats_rows(m, c):
     return _lib.value("msml_bn_stats_rows", m, c)
 
 
+# BatchNorm statistics in ACCUMULATOR mode (msml_conv2d_acc -> msml_bn_fin_act_fwd): the producer adds its
+# per-workgroup (sum, sumsq) into a zero-initialised f64 [8][2][C] block and the consumer folds it itself, so the
+# finalize launch between them disappears.  bf16 training path only; MSML_NO_ACC_STATS=1 restores partial rows.
+ACC_STATS = os.environ.get("MSML_NO_ACC_STATS") is None
+ACC_ROWS = 8
+
+
+class _AccArena:
+    """Zeroed f64 accumulators cut from chunks (one torch.zeros launch per ~250 BatchNorm uses instead of one per
+    use).  A chunk belongs to the stream that was current when it was created (its zero fill is ordered on that
+    stream; producer and consumer of an accumulator always share a stream) and to eager execution or to ONE graph
+    capture: a capture gets a chunk of its own, so that the captured fill re-zeroes exactly the slices the replay
+    uses (a capture is told from the previous one by the eager uses in between -- PyTorch's required warm-up)."""
+    CHUNK = 1 << 20            # doubles
+
+    def __init__(self):
+        self.chunks = {}
+        self.eager_uses = 0
+
+    def get(self, c, device):
+        n = ACC_ROWS * 2 * c
+        cap = torch.cuda.is_current_stream_capturing()
+        if not cap:
+            self.eager_uses += 1
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream, cap)
+        ent = self.chunks.get(key)
+        if ent is None or ent[1] + n > ent[0].numel() or (cap and ent[2] != self.eager_uses):
+            ent = [torch.zeros(max(self.CHUNK, n), dtype=torch.float64, device=device), 0, self.eager_uses]
+            self.chunks[key] = ent
+        out = ent[0][ent[1]:ent[1] + n].view(ACC_ROWS, 2, c)
+        ent[1] += n
+        return out
+
+
+ACC_ARENA = _AccArena()
+
+
+def acc_applies(c, dtype):
+    """Accumulator-mode statistics for a C-channel bf16 tensor (the fused consumer needs C / 8 | 256)."""
+    return ACC_STATS and dtype == BF16 and c % 8 == 0 and 256 % (c // 8) == 0
+
+
+def stats_acc(c, device):
+    return ACC_ARENA.get(c, device)
+
+
 def conv_out_size(h, r, stride, pad, transposed, out_pad=0):
     if transposed:
         return (h - 1) * stride - 2 * pad + r + out_pad
@@ -174,7 +220,10 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
     out_dtype = in_dtype if out_dtype is None else out_dtype
     out = torch.empty(n, p, q, coutp, dtype=TORCH_DTYPE[out_dtype], device=x0.device)
     stats = None
-    if want_stats:
+    acc = want_stats and out_dtype == BF16 and acc_applies(coutp, in_dtype)
+    if acc:
+        stats = stats_acc(coutp, x0.device)
+    elif want_stats:
         tiles = (n * p * q + tile_m(coutp) - 1) // tile_m(coutp)
         stats = torch.empty(tiles, 2, coutp, dtype=torch.float32, device=x0.device)
     cin, cout = real if real is not None else (c0p + c1p, coutp)
@@ -185,8 +234,8 @@ def conv2d(x0, x1, wp, bias, coutp, r, s, stride, pad_h, pad_w, transposed, p=No
         name = conv_label("T" if transposed else "N", c0p, c1p, coutp, n, h, w, p, q, r, s, stride, pad_h, pad_w,
                           transposed, in_dtype, out_dtype, want_stats)
     with PROFILE.rec(name, 2.0 * pix * cin * cout * r * s):
-        call("msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats, n, h, w, p,
-             q, r, s, stride, pad_h, pad_w, int(transposed), in_dtype, out_dtype)
+        call("msml_conv2d_acc" if acc else "msml_conv2d", x0, c0p, x1, c1p, wp, wp.shape[0], bias, out, coutp, stats,
+             n, h, w, p, q, r, s, stride, pad_h, pad_w, int(transposed), in_dtype, out_dtype)
     return out, stats
 
 

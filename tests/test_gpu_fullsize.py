@@ -36,7 +36,7 @@ def test_conv_full_size_properties(cin, cout, h, stride):
     err = (ys.float() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 2e-2, err
     # (3) epilogue statistics = statistics of the stored tensor (up to its bf16 rounding)
-    s = st.sum(0)
+    s = st.sum(0).float()              # partial rows (f32) or the f64 accumulator of ops.ACC_STATS
     yf = y1.float().reshape(-1, cout)
     assert torch.allclose(s[0], yf.sum(0), rtol=2e-2, atol=2.0 * yf.abs().max().item())
     assert torch.allclose(s[1], (yf * yf).sum(0), rtol=2e-2)
