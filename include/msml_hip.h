@@ -198,6 +198,27 @@ int msml_bn_fin_act_fwd(const double* acc, double count, const float* gamma, con
                         float* shift, float* save_mean, float* save_invstd, const void* x,
                         const float* alpha, const void* residual, int res_first, void* y, long M, int C,
                         double* acc_out, int dtype, void* stream);
+int msml_bn_stats_acc(const void* x, long M, int C, double* acc, int dtype, void* stream);
+/* Backward in accumulator mode (the three sums sum g, sum g*xhat, sum dy*min(z,0) as double[8][3][C], f64 atomics of
+ * the producer): msml_conv2d_bnbwd_acc is msml_conv2d_bnbwd with that output; msml_bn_fin_bwd_apply is
+ * k_bn_bwd_finalize + msml_bn_act_bwd_apply[_next][_s2] in one launch (add_h > 0: compact stride-2 `add`; next_acc:
+ * zero-initialised accumulator of the activation-free BatchNorm whose output gradient dx is); msml_bn_act_bwd_acc is
+ * msml_bn_act_bwd with its reduce pass adding into `acc`.  C / 8 must divide 256. */
+int msml_conv2d_bnbwd_acc(const void* in0, int c0p, const void* wp, int kop, void* out, int coutp, int N,
+                          int H, int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
+                          int transposed, const void* bn_x, const float* bn_scale, const float* bn_shift,
+                          const float* bn_alpha, const float* bn_mean, const float* bn_invstd, double* acc,
+                          void* stream);
+int msml_bn_fin_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
+                          const float* alpha, const float* save_mean, const float* save_invstd,
+                          const double* acc, const void* residual_first, const void* add, int add_h,
+                          int add_w, void* dx, void* dres, float* dgamma, float* dbeta, float* dalpha,
+                          int accumulate, long M, int C, const void* next_x, const float* next_mean,
+                          const float* next_invstd, double* next_acc, int dtype, void* stream);
+int msml_bn_act_bwd_acc(const void* dy, const void* x, const float* scale, const float* shift,
+                        const float* alpha, const float* save_mean, const float* save_invstd,
+                        const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,
+                        float* dalpha, int accumulate, long M, int C, double* acc, int dtype, void* stream);
 int msml_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
                     const float* alpha, const float* save_mean, const float* save_invstd,
                     const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,

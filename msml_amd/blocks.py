@@ -80,9 +80,20 @@ def _is_acc(stats):
     return stats is not None and stats.dtype == torch.float64
 
 
+def _own_stats(x, stats):
+    """No producer-side statistics: a standalone pass over x, into an accumulator when the mode applies."""
+    c = x.shape[-1]
+    if stats is None and ops.acc_applies(c, BF16):
+        stats = ops.stats_acc(c, x.device)
+        with ops.PROFILE.rec("bn_stats", 0.0, x.numel() * x.element_size()):
+            call("msml_bn_stats_acc", x, x.numel() // c, c, stats, BF16)
+    return stats
+
+
 def _bn_fwd(x, stats, bnp, alpha, residual, emit_stats=False):
     """Training-mode BatchNorm (+PReLU) (+residual after it) on raw NHWC tensors.
     Returns (y, coef[4][C] = scale, shift, mean, invstd[, partial statistics of y])."""
+    stats = _own_stats(x, stats)
     if _is_acc(stats):
         return _bn_fin_apply(x, stats, bnp, alpha, residual, emit_stats)
     coef = _bn_coef(x, stats, bnp)
@@ -108,6 +119,8 @@ def _bn_conv_fwd(x, stats, bnp, alpha, cp):
     """BatchNorm(+PReLU) -> conv.  When the conv's kernels can take the BatchNorm as an input
     transform (ops.bnin_applies) the normalised activation is never written: returns
     (None, coef, conv out, conv out statistics), else (activation, coef, conv out, statistics)."""
+    if not (ops.FUSE_BN_IN and stats is None):
+        stats = _own_stats(x, stats)
     if _is_acc(stats):
         o, coef = _bn_fin_apply(x, stats, bnp, alpha, None)
         y, st = _conv_fwd(o, cp)
@@ -206,7 +219,14 @@ def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None, add_s2=Fa
     dx = torch.empty_like(x)
     s2 = (add, x.shape[1], x.shape[2]) if add_s2 else (add,)
     sfx = "_s2" if add_s2 else ""
-    if partial is None:
+    if partial is None and ops.acc_applies(c, BF16):
+        # accumulator mode (ops.ACC_STATS): the reduce pass adds into a zeroed f64 block, finalize + apply are one launch
+        with ops.PROFILE.rec("bn_act_bwd", 0.0, x.numel() * x.element_size() * 5):
+            call("msml_bn_act_bwd_acc", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], None, dx, None,
+                 pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, ops.stats_acc(c, x.device, 3), BF16)
+        if add is not None:
+            call("msml_add", dx, add, dx, dx.numel(), BF16)
+    elif partial is None:
         rows = ops.bn_stats_rows(m, c)
         ws = ops.workspace((rows * 3 * c + 2 * c) * 4, x.device)
         with ops.PROFILE.rec("bn_act_bwd", 0.0, x.numel() * x.element_size() * 5):
@@ -214,6 +234,19 @@ def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None, add_s2=Fa
                  pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, ws, ws.numel() // 4, BF16)
         if add is not None:
             call("msml_add", dx, add, dx, dx.numel(), BF16)
+    elif partial.dtype == torch.float64:
+        ah, aw = (x.shape[1], x.shape[2]) if add_s2 else (0, 0)
+        if nxt is not None and 256 % (c // 8) == 0:
+            nacc = ops.stats_acc(c, x.device, 3)
+            with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (5 if add is not None else 4)):
+                call("msml_bn_fin_bwd_apply", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial, None, add, ah, aw,
+                     dx, None, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, nxt[0], nxt[1][2], nxt[1][3],
+                     nacc, BF16)
+            pgr.done()
+            return dx, nacc
+        with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (4 if add is not None else 3)):
+            call("msml_bn_fin_bwd_apply", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial, None, add, ah, aw,
+                 dx, None, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, None, None, None, None, BF16)
     else:
         cw = torch.empty(98 * c, dtype=torch.float32, device=x.device)
         if nxt is not None and 256 % (c // 8) == 0:
@@ -401,11 +434,15 @@ class _Bottle(torch.autograd.Function):
         c = c3.shape[-1]
         m = c3.numel() // c
         dc3, dres = torch.empty_like(c3), torch.empty_like(x)
-        rows = ops.bn_stats_rows(m, c)
-        ws = ops.workspace((rows * 3 * c + 2 * c) * 4, dev)
         with ops.PROFILE.rec("bn_act_bwd", 0.0, c3.numel() * c3.element_size() * 7):
-            call("msml_bn_act_bwd", dout, c3, k3[0], k3[1], bp["a3"], k3[2], k3[3], x, dc3, dres,
-                 g3.tg[0], g3.tg[1], g3.tg[2], int(g3.inplace), m, c, ws, ws.numel() // 4, BF16)
+            if ops.acc_applies(c, BF16):
+                call("msml_bn_act_bwd_acc", dout, c3, k3[0], k3[1], bp["a3"], k3[2], k3[3], x, dc3, dres,
+                     g3.tg[0], g3.tg[1], g3.tg[2], int(g3.inplace), m, c, ops.stats_acc(c, dev, 3), BF16)
+            else:
+                rows = ops.bn_stats_rows(m, c)
+                ws = ops.workspace((rows * 3 * c + 2 * c) * 4, dev)
+                call("msml_bn_act_bwd", dout, c3, k3[0], k3[1], bp["a3"], k3[2], k3[3], x, dc3, dres,
+                     g3.tg[0], g3.tg[1], g3.tg[2], int(g3.inplace), m, c, ws, ws.numel() // 4, BF16)
         g3.done()
         dw3 = _wgrad(dc3, o2, bp["c3"])
         do2, part2 = _dgrad(dc3, bp["c3"], h, w, c2, k2, bp["a2"])

@@ -21,7 +21,7 @@
 //   void f(const D& d, float (&q)[NQ][8])    adds its contribution.
 // PIPE: four pixels per trip (see below) -- for launches with few workgroups
 template <int NQ, bool PIPE, typename L, typename F>
-__device__ __forceinline__ void slab_reduce(long M, int C, float* __restrict__ partial, L ld, F f) {
+__device__ __forceinline__ void slab_reduce(long M, int C, float* __restrict__ partial, L ld, F f, int acc_mode = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);            // [PY][NQ][C]
   const int C8 = C / 8;
@@ -64,7 +64,10 @@ __device__ __forceinline__ void slab_reduce(long M, int C, float* __restrict__ p
   for (int i = t; i < NQ * C; i += blockDim.x) {
     float s = 0.f;
     for (int y = 0; y < PY; y++) s += red[y * NQ * C + i];
-    partial[(long)blockIdx.x * NQ * C + i] = s;
+    if (acc_mode)          // accumulator mode (common.h): partial is a zero-initialised double[MSML_ACC_ROWS][NQ][C]
+      unsafeAtomicAdd(reinterpret_cast<double*>(partial) + (long)(blockIdx.x & (MSML_ACC_ROWS - 1)) * NQ * C + i, (double)s);
+    else
+      partial[(long)blockIdx.x * NQ * C + i] = s;
   }
 }
 
@@ -85,7 +88,7 @@ static inline size_t red_lds(int NQ, int C) {
 #define RED_PIPE_MAX_ROWS 512
 template <typename T, bool PIPE>
 __global__ void __launch_bounds__(256) k_bn_stats(const T* __restrict__ x, long M, int C,
-                                                  float* __restrict__ partial) {
+                                                  float* __restrict__ partial, int acc_mode) {
   slab_reduce<2, PIPE>(M, C, partial, [&](long pix, int c8) { return load8<T>(x + pix * C + c8 * 8); },
                  [&](const Vec8& v, float(&q)[2][8]) {
 #pragma unroll
@@ -93,7 +96,7 @@ __global__ void __launch_bounds__(256) k_bn_stats(const T* __restrict__ x, long 
       q[0][j] += v.v[j];
       q[1][j] += v.v[j] * v.v[j];
     }
-  });
+  }, acc_mode);
 }
 
 extern "C" int msml_bn_stats_rows(long M, int C) { return red_rows(M, C); }
@@ -104,11 +107,20 @@ extern "C" int msml_bn_stats(const void* x, long M, int C, float* partial, int d
   int rows = red_rows(M, C);
   MSML_DISPATCH_DTYPE(dtype, "bn_stats",
                       if (rows <= RED_PIPE_MAX_ROWS)
-                        (k_bn_stats<DT, true>)<<<rows, 256, red_lds(2, C), (hipStream_t)stream>>>((const DT*)x, M, C, partial);
+                        (k_bn_stats<DT, true>)<<<rows, 256, red_lds(2, C), (hipStream_t)stream>>>((const DT*)x, M, C, partial, msml_tl_stats_acc);
                       else
-                        (k_bn_stats<DT, false>)<<<rows, 256, red_lds(2, C), (hipStream_t)stream>>>((const DT*)x, M, C, partial);)
+                        (k_bn_stats<DT, false>)<<<rows, 256, red_lds(2, C), (hipStream_t)stream>>>((const DT*)x, M, C, partial, msml_tl_stats_acc);)
   MSML_LAUNCH_OK("bn_stats");
   return MSML_OK;
+}
+
+// msml_bn_stats into an accumulator (zero-initialised double[8][2][C], common.h) for msml_bn_fin_act_fwd
+extern "C" int msml_bn_stats_acc(const void* x, long M, int C, double* acc, int dtype, void* stream) {
+  MSML_CHECK(acc, MSML_ERR_SHAPE, "bn_stats_acc: null accumulator");
+  msml_tl_stats_acc = 1;
+  const int rc = msml_bn_stats(x, M, C, reinterpret_cast<float*>(acc), dtype, stream);
+  msml_tl_stats_acc = 0;
+  return rc;
 }
 
 // ------------------------------------------------------------------ finalize (forward) -------
@@ -486,7 +498,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
                                                        const T* __restrict__ res, long M, int C,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, int acc_mode) {
   const int c0h = (threadIdx.x % (C / 8)) * 8;
   const Coef8 sc = ldc8(scale, c0h, 1.f), sh = ldc8(shift, c0h, 0.f), al = ldc8(alpha, c0h, 1.f);
   const Coef8 mu = ldc8(mean, c0h, 0.f), is = ldc8(invstd, c0h, 1.f);
@@ -516,7 +528,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const T* __restrict__ dy,
       q[0][j] += gg;
       q[1][j] += gg * xh;
     }
-  });
+  }, acc_mode);
 }
 
 // Many partial rows (a fused conv epilogue writes one per workgroup: up to ~50k) are first folded
@@ -670,11 +682,11 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
       if (rows <= RED_PIPE_MAX_ROWS)
         (k_bn_bwd_reduce<DT, true>)<<<rows, 256, red_lds(3, C), st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
                                                                       save_mean, save_invstd,
-                                                                      (const DT*)residual_first, M, C, partial);
+                                                                      (const DT*)residual_first, M, C, partial, 0);
       else
         (k_bn_bwd_reduce<DT, false>)<<<rows, 256, red_lds(3, C), st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
                                                                        save_mean, save_invstd,
-                                                                       (const DT*)residual_first, M, C, partial);
+                                                                       (const DT*)residual_first, M, C, partial, 0);
       MSML_LAUNCH_OK("bn_bwd_reduce");
       k_bn_bwd_finalize<<<cdiv(C, FIN_CPB), 1024, 0, st>>>(partial, rows, C, (double)M, dgamma, dbeta, dalpha, coef, accumulate);
       MSML_LAUNCH_OK("bn_bwd_finalize");
@@ -684,6 +696,173 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
           nullptr, nullptr, nullptr, 0, 0);)
   MSML_LAUNCH_OK("bn_bwd_apply");
   return MSML_OK;
+}
+
+// ------------------------------------------------------------------ backward, accumulator mode -------
+// k_bn_bwd_finalize + k_bn_bwd_apply in ONE launch: the three backward sums arrive in acc[MSML_ACC_ROWS][3][C] (f64
+// atomics of the producer: a backward-data conv's fused epilogue, the NEXT pass of another apply, or k_bn_bwd_reduce),
+// every workgroup folds them and keeps k1 = s0 / n, k2 = s1 / n of all channels in LDS, workgroup 0 writes the
+// parameter gradients.  NEXT / ADD_S2 as in k_bn_bwd_apply; NEXT adds into nacc (zero-initialised, same format).
+template <typename T, bool NEXT, bool ADD_S2>
+__global__ void __launch_bounds__(256) k_bn_fin_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ alpha, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const double* __restrict__ acc,
+                                                          double count, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, float* __restrict__ dalpha,
+                                                          int accumulate, const T* __restrict__ res,
+                                                          const T* __restrict__ add, T* __restrict__ dx,
+                                                          T* __restrict__ dres, long n8, int C8,
+                                                          const T* __restrict__ nx, const float* __restrict__ nmean,
+                                                          const float* __restrict__ ninvstd, double* __restrict__ nacc,
+                                                          int aH, int aW) {
+  extern __shared__ float ck[];                        // [2][C]: k1, k2
+  const int C = C8 * 8, t = threadIdx.x;
+  for (int c = t; c < C; c += 256) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < MSML_ACC_ROWS; r++) {
+      s0 += acc[(r * 3 + 0) * C + c];
+      s1 += acc[(r * 3 + 1) * C + c];
+      s2 += acc[(r * 3 + 2) * C + c];
+    }
+    ck[c] = (float)(s0 / count);
+    ck[C + c] = (float)(s1 / count);
+    if (blockIdx.x == 0) {
+      if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s0;
+      if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s1;
+      if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + (float)s2;
+    }
+  }
+  __syncthreads();
+  const long tid = blockIdx.x * (long)blockDim.x + t;
+  const int c0 = (int)(tid % C8) * 8;
+  const Coef8 sc = ldc8(scale, c0, 1.f), sh = ldc8(shift, c0, 0.f), al = ldc8(alpha, c0, 1.f);
+  const Coef8 mu = ldc8(mean, c0, 0.f), is = ldc8(invstd, c0, 1.f);
+  Coef8 k1, k2;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    k1.v[j] = ck[c0 + j];
+    k2.v[j] = ck[C + c0 + j];
+  }
+  const float rcpW = ADD_S2 ? 1.0f / (float)aW : 0.f, rcpH = ADD_S2 ? 1.0f / (float)aH : 0.f;
+  const int aPw = (aW + 1) >> 1, aPh = (aH + 1) >> 1;
+  const Coef8 nmu = ldc8(NEXT ? nmean : nullptr, c0, 0.f), nis = ldc8(NEXT ? ninvstd : nullptr, c0, 1.f);
+  float nq0[8], nq1[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) nq0[j] = nq1[j] = 0.f;
+  for (long i = tid; i < n8; i += (long)gridDim.x * blockDim.x) {
+    Vec8 g = load8<T>(dy + i * 8);
+    Vec8 v = load8<T>(x + i * 8);
+    Vec8 rr, ad;
+    if (res) rr = load8<T>(res + i * 8);
+    bool has_add = add != nullptr;
+    if (ADD_S2) {
+      const int pix = (int)(i / C8);
+      int row = (int)((float)pix * rcpW), xx = pix - row * aW;
+      if (xx < 0) { row--; xx += aW; } else if (xx >= aW) { row++; xx -= aW; }
+      int nn = (int)((float)row * rcpH), yy = row - nn * aH;
+      if (yy < 0) { nn--; yy += aH; } else if (yy >= aH) { nn++; yy -= aH; }
+      has_add = !((xx | yy) & 1);
+      if (has_add) ad = load8<T>(add + (((long)nn * aPh + (yy >> 1)) * aPw + (xx >> 1)) * C + c0);
+    } else if (add) {
+      ad = load8<T>(add + i * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float gg = g.v[j];
+      if (alpha) {
+        float z = v.v[j] * sc.v[j] + sh.v[j];
+        if (res) z += rr.v[j];
+        if (z <= 0.f) gg *= al.v[j];
+      }
+      float xh = (v.v[j] - mu.v[j]) * is.v[j];
+      v.v[j] = sc.v[j] * (gg - k1.v[j] - xh * k2.v[j]);
+      if (has_add) v.v[j] += ad.v[j];
+      g.v[j] = gg;
+    }
+    store8<T>(dx + i * 8, v);
+    if (dres) store8<T>(dres + i * 8, g);
+    if (NEXT) {
+      const Vec8 o = round8<T>(v), xn = load8<T>(nx + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        nq0[j] += o.v[j];
+        nq1[j] += o.v[j] * ((xn.v[j] - nmu.v[j]) * nis.v[j]);
+      }
+    }
+  }
+  if (NEXT) {
+    __shared__ float red[2][256][9];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      red[0][t][j] = nq0[j];
+      red[1][t][j] = nq1[j];
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * C; i += 256) {
+      const int q = i / C, c = i % C, cx = c >> 3, j = c & 7;
+      float sum = 0.f;
+      for (int k = cx; k < 256; k += C8) sum += red[q][k][j];
+      bnb_emit(reinterpret_cast<float*>(nacc), 1, blockIdx.x, q, C, c, sum);
+    }
+  }
+}
+
+// residual_first / dres: the PReLU-after-the-sum form of msml_bn_act_bwd (res_first blocks); add / add_h / add_w, next_*:
+// as msml_bn_act_bwd_apply[_next][_s2].  acc: double[8][3][C] filled by the producer; next_acc: zero-initialised.
+extern "C" int msml_bn_fin_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
+                                     const float* alpha, const float* save_mean, const float* save_invstd,
+                                     const double* acc, const void* residual_first, const void* add, int add_h,
+                                     int add_w, void* dx, void* dres, float* dgamma, float* dbeta, float* dalpha,
+                                     int accumulate, long M, int C, const void* next_x, const float* next_mean,
+                                     const float* next_invstd, double* next_acc, int dtype, void* stream) {
+  MSML_CHECK(dy && x && dx && scale && shift && save_mean && save_invstd && acc && M > 0 && C > 0 && C % 8 == 0,
+             MSML_ERR_SHAPE, "bn_fin_bwd_apply: bad args M=%ld C=%d", M, C);
+  MSML_CHECK(256 % (C / 8) == 0, MSML_ERR_UNSUPPORTED, "bn_fin_bwd_apply: C/8 = %d must divide 256", C / 8);
+  const bool s2 = add_h > 0;
+  MSML_CHECK(!s2 || (add && add_w > 0 && M % ((long)add_h * add_w) == 0 && M < (1L << 24)), MSML_ERR_SHAPE,
+             "bn_fin_bwd_apply: stride-2 add needs M = N*H*W < 2^24 (M=%ld H=%d W=%d)", M, add_h, add_w);
+  MSML_CHECK(!next_acc || (next_x && next_mean && next_invstd), MSML_ERR_SHAPE, "bn_fin_bwd_apply: next_* incomplete");
+  hipStream_t st = (hipStream_t)stream;
+  const long n8 = M * (C / 8);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+#define BN_FIN_LAUNCH(NEXT_, S2_)                                                                                   \
+  (k_bn_fin_bwd_apply<DT, NEXT_, S2_>)<<<ew_grid_c(n8, C / 8), 256, lds, st>>>(                                     \
+      (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, acc, (double)M, dgamma, dbeta, dalpha, \
+      accumulate, (const DT*)residual_first, (const DT*)add, (DT*)dx, (DT*)dres, n8, C / 8, (const DT*)next_x,      \
+      next_mean, next_invstd, next_acc, add_h, add_w);
+  MSML_DISPATCH_DTYPE(dtype, "bn_fin_bwd_apply",
+                      if (next_acc) { if (s2) { BN_FIN_LAUNCH(true, true) } else { BN_FIN_LAUNCH(true, false) } }
+                      else { if (s2) { BN_FIN_LAUNCH(false, true) } else { BN_FIN_LAUNCH(false, false) } })
+#undef BN_FIN_LAUNCH
+  MSML_LAUNCH_OK("bn_fin_bwd_apply");
+  return MSML_OK;
+}
+
+// msml_bn_act_bwd (no producer-side sums): reduce pass into the accumulator, then the fused finalize + apply.
+extern "C" int msml_bn_act_bwd_acc(const void* dy, const void* x, const float* scale, const float* shift,
+                                   const float* alpha, const float* save_mean, const float* save_invstd,
+                                   const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,
+                                   float* dalpha, int accumulate, long M, int C, double* acc, int dtype, void* stream) {
+  MSML_CHECK(dy && x && dx && scale && shift && save_mean && save_invstd && acc && M > 0 && C > 0 && C % 8 == 0 &&
+                 C <= 2048, MSML_ERR_SHAPE, "bn_act_bwd_acc: bad args M=%ld C=%d", M, C);
+  const int rows = red_rows(M, C);
+  hipStream_t st = (hipStream_t)stream;
+  MSML_DISPATCH_DTYPE(
+      dtype, "bn_act_bwd_acc",
+      if (rows <= RED_PIPE_MAX_ROWS)
+        (k_bn_bwd_reduce<DT, true>)<<<rows, 256, red_lds(3, C), st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
+                                                                      save_mean, save_invstd, (const DT*)residual_first,
+                                                                      M, C, reinterpret_cast<float*>(acc), 1);
+      else
+        (k_bn_bwd_reduce<DT, false>)<<<rows, 256, red_lds(3, C), st>>>((const DT*)dy, (const DT*)x, scale, shift, alpha,
+                                                                       save_mean, save_invstd, (const DT*)residual_first,
+                                                                       M, C, reinterpret_cast<float*>(acc), 1);)
+  MSML_LAUNCH_OK("bn_bwd_reduce(acc)");
+  return msml_bn_fin_bwd_apply(dy, x, scale, shift, alpha, save_mean, save_invstd, acc, residual_first, nullptr, 0, 0,
+                               dx, dres, dgamma, dbeta, dalpha, accumulate, M, C, nullptr, nullptr, nullptr, nullptr,
+                               dtype, stream);
 }
 
 // Second half of msml_bn_act_bwd for callers that already hold the partial sums (a backward-data
@@ -823,9 +1002,9 @@ extern "C" int msml_bias_grad(const void* dy, long M, int Cp, int Creal, float* 
   hipStream_t st = (hipStream_t)stream;
   MSML_DISPATCH_DTYPE(dtype, "bias_grad",
                       if (rows <= RED_PIPE_MAX_ROWS)
-                        (k_bn_stats<DT, true>)<<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace);
+                        (k_bn_stats<DT, true>)<<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace, 0);
                       else
-                        (k_bn_stats<DT, false>)<<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace);)
+                        (k_bn_stats<DT, false>)<<<rows, 256, red_lds(2, Cp), st>>>((const DT*)dy, M, Cp, workspace, 0);)
   MSML_LAUNCH_OK("bias_grad");
   k_colsum_finalize<<<cdiv(Creal, 32), 1024, 0, st>>>(workspace, rows, Cp, 2, db, Creal, accumulate);
   MSML_LAUNCH_OK("bias_grad_finalize");

@@ -126,6 +126,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// ... and of the three backward sums (rows [3][C])
+__device__ __forceinline__ void bnb_emit(float* partial, int acc_mode, long wg, int q, int C, int col, float v) {
+  if (acc_mode)
+    unsafeAtomicAdd(reinterpret_cast<double*>(partial) + ((wg & (MSML_ACC_ROWS - 1)) * 3 + q) * C + col, (double)v);
+  else
+    partial[(wg * 3 + q) * C + col] = v;
+}
+
 // one per-channel partial of a producer workgroup: a row store, or an f64 atomic add in accumulator mode
 __device__ __forceinline__ void stats_emit(float* stats, int acc_mode, long wg, int which, int C, int col, float v) {
   if (acc_mode)
@@ -222,6 +230,7 @@ struct BnBwdFuse {
   const float* mean;
   const float* invstd;
   float* partial;
+  int acc;                 // accumulator mode: partial is a zero-initialised double[MSML_ACC_ROWS][3][C]
 };
 
 struct BnbCoef {

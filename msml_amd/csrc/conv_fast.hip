@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
   if (m0 >= Mc) {
     if constexpr (FUSE)                                // empty tile of a small parity class
       for (int i = t; i < 3 * BN; i += NT)
-        if (n0 + i % BN < p.coutp) p.bnb.partial[(prow * 3 + i / BN) * p.coutp + n0 + i % BN] = 0.f;
+        if (n0 + i % BN < p.coutp && !p.bnb.acc) p.bnb.partial[(prow * 3 + i / BN) * p.coutp + n0 + i % BN] = 0.f;
     return;
   }
   const int taps = nr * ns;
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
         const int q = i / BN, c = i % BN;
         float sum = 0.f;
         for (int g = 0; g < G; g++) sum += red[(g * 3 + q) * BN + c];
-        if (n0 + c < p.coutp) p.bnb.partial[(prow * 3 + q) * p.coutp + n0 + c] = sum;
+        if (n0 + c < p.coutp) bnb_emit(p.bnb.partial, p.bnb.acc, prow, q, p.coutp, n0 + c, sum);
       }
     } else if constexpr (X3) {
       __syncthreads();

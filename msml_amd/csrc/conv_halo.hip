@@ -421,7 +421,7 @@ k_conv_halo(const ConvHaloArgs p) {
       const int q = i / BN, c = i % BN;
       float sum = 0.f;
       for (int g = 0; g < G; g++) sum += red[(g * 3 + q) * BN + c];
-      p.bnb.partial[((long)blockIdx.x * 3 + q) * p.coutp + n0 + c] = sum;
+      bnb_emit(p.bnb.partial, p.bnb.acc, blockIdx.x, q, p.coutp, n0 + c, sum);
     }
   }
   if (!FUSE && p.stats) {

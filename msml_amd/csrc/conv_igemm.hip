@@ -482,7 +482,7 @@ extern "C" int msml_conv2d_bnbwd(const void* in0, int c0p, const void* wp, int k
              "conv2d_bnbwd: partial buffer has %d rows, need %d", rows_cap, msml_conv2d_bnbwd_rows(coutp, N, P, Q));
   const int bn = msml_conv_tile_n(coutp);
   MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_bnbwd: packed weight rows");
-  BnBwdFuse f{(const unsigned short*)bn_x, bn_scale, bn_shift, bn_alpha, bn_mean, bn_invstd, partial};
+  BnBwdFuse f{(const unsigned short*)bn_x, bn_scale, bn_shift, bn_alpha, bn_mean, bn_invstd, partial, msml_tl_stats_acc};
   MSML_CHECK(msml_conv_fast_dispatch(in0, c0p, nullptr, 0, wp, kop, nullptr, out, coutp, nullptr, N, H, W, P, Q,
                                      R, S, stride, pad_h, pad_w, transposed, MSML_BF16, MSML_BF16, bn,
                                      (hipStream_t)stream, nullptr, nullptr, nullptr, 0, &f, rows_used),
@@ -491,6 +491,22 @@ extern "C" int msml_conv2d_bnbwd(const void* in0, int c0p, const void* wp, int k
   return MSML_OK;
 }
 
+// msml_conv2d_bnbwd with the three backward sums added into an accumulator (zero-initialised double[8][3][coutp])
+// instead of partial rows; consumed by msml_bn_fin_bwd_apply.
+extern "C" int msml_conv2d_bnbwd_acc(const void* in0, int c0p, const void* wp, int kop, void* out, int coutp, int N,
+                                     int H, int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
+                                     int transposed, const void* bn_x, const float* bn_scale, const float* bn_shift,
+                                     const float* bn_alpha, const float* bn_mean, const float* bn_invstd, double* acc,
+                                     void* stream) {
+  MSML_CHECK(acc, MSML_ERR_SHAPE, "conv2d_bnbwd_acc: null accumulator");
+  int used = 0;
+  msml_tl_stats_acc = 1;
+  const int rc = msml_conv2d_bnbwd(in0, c0p, wp, kop, out, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed,
+                                   bn_x, bn_scale, bn_shift, bn_alpha, bn_mean, bn_invstd, reinterpret_cast<float*>(acc),
+                                   1 << 30, &used, stream);
+  msml_tl_stats_acc = 0;
+  return rc;
+}
 
 bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                             int stride, int pad_h, int pad_w, bool want_stats);

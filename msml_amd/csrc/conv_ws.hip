@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       const int q = i / C, c = i % C;
       float sum = 0.f;
       for (int g = 0; g < G; g++) sum += red[(g * 3 + q) * C + c];
-      p.bnb.partial[((long)blockIdx.x * 3 + q) * C + c] = sum;
+      bnb_emit(p.bnb.partial, p.bnb.acc, blockIdx.x, q, C, c, sum);
     }
   }
   if (!FUSE && p.stats) {

@@ -162,6 +162,10 @@ class _BnAct(torch.autograd.Function):
         dtype = DTYPE_OF[x.dtype]
         dev = x.device
         coef = torch.empty(4, c, dtype=torch.float32, device=dev)   # scale, shift, mean, invstd
+        if training and stats is None and ops.acc_applies(c, dtype):
+            stats = ops.stats_acc(c, dev)
+            with ops.PROFILE.rec("bn_stats", 0.0, x.numel() * x.element_size()):
+                call("msml_bn_stats_acc", x, m, c, stats, dtype)
         if training and stats is not None and stats.dtype == torch.float64:
             # accumulator-mode statistics (ops.ACC_STATS): finalize + apply in one launch
             y = torch.empty_like(x)
@@ -221,8 +225,12 @@ class _BnAct(torch.autograd.Function):
         else:
             tg = [pg[0], pg[1], pg[2] if alpha is not None else None]
         with ops.PROFILE.rec("bn_act_bwd", 0.0, x.numel() * x.element_size() * (5 + (3 if ctx.res_first else 0))):
-            call("msml_bn_act_bwd", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, dx, dres,
-                 tg[0], tg[1], tg[2], int(inplace), m, c, ws, ws.numel() // 4, dtype)
+            if ops.acc_applies(c, dtype):
+                call("msml_bn_act_bwd_acc", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, dx, dres,
+                     tg[0], tg[1], tg[2], int(inplace), m, c, ops.stats_acc(c, x.device, 3), dtype)
+            else:
+                call("msml_bn_act_bwd", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, dx, dres,
+                     tg[0], tg[1], tg[2], int(inplace), m, c, ws, ws.numel() // 4, dtype)
         if ctx.res_first:
             dy = dres
         if inplace:

@@ -156,8 +156,8 @@ class _AccArena:
         self.chunks = {}
         self.eager_uses = 0
 
-    def get(self, c, device):
-        n = ACC_ROWS * 2 * c
+    def get(self, c, device, nq=2):
+        n = ACC_ROWS * nq * c
         cap = torch.cuda.is_current_stream_capturing()
         if not cap:
             self.eager_uses += 1
@@ -166,7 +166,7 @@ class _AccArena:
         if ent is None or ent[1] + n > ent[0].numel() or (cap and ent[2] != self.eager_uses):
             ent = [torch.zeros(max(self.CHUNK, n), dtype=torch.float64, device=device), 0, self.eager_uses]
             self.chunks[key] = ent
-        out = ent[0][ent[1]:ent[1] + n].view(ACC_ROWS, 2, c)
+        out = ent[0][ent[1]:ent[1] + n].view(ACC_ROWS, nq, c)
         ent[1] += n
         return out
 
@@ -179,8 +179,9 @@ def acc_applies(c, dtype):
     return ACC_STATS and dtype == BF16 and c % 8 == 0 and 256 % (c // 8) == 0
 
 
-def stats_acc(c, device):
-    return ACC_ARENA.get(c, device)
+def stats_acc(c, device, nq=2):
+    """Zeroed f64 [8][nq][c]: nq = 2 forward (sum, sumsq), 3 backward (sum g, sum g * xhat, sum dy * min(z, 0))."""
+    return ACC_ARENA.get(c, device, nq)
 
 
 def conv_out_size(h, r, stride, pad, transposed, out_pad=0):
@@ -310,14 +311,20 @@ def conv_dgrad_bnbwd(dy, wp, coutp, r, s, stride, pad_h, pad_w, p, q, bn_x, coef
     n, h, w, c0p = dy.shape
     if dy.dtype != torch.bfloat16:
         return None
-    cap = _lib.value("msml_conv2d_bnbwd_rows", coutp, n, p, q)
-    partial = torch.empty(cap, 3, coutp, dtype=torch.float32, device=dy.device)
     out = torch.empty(n, p, q, coutp, dtype=torch.bfloat16, device=dy.device)
-    used = ctypes.c_int(0)
     cin, cout = real if real is not None else (c0p, coutp)
     name = "conv_igemm"
     if PROFILE.on:
         name = conv_label("T+bnb", c0p, 0, coutp, n, h, w, p, q, r, s, stride, pad_h, pad_w, 1, BF16, BF16, False)
+    if acc_applies(coutp, BF16):
+        acc = stats_acc(coutp, dy.device, 3)
+        with PROFILE.rec(name, 2.0 * n * h * w * cin * cout * r * s):
+            rc = try_call("msml_conv2d_bnbwd_acc", dy, c0p, wp, wp.shape[0], out, coutp, n, h, w, p, q, r, s, stride,
+                          pad_h, pad_w, 1, bn_x, coef[0], coef[1], alpha, coef[2], coef[3], acc)
+        return (out, acc) if rc == 0 else None
+    cap = _lib.value("msml_conv2d_bnbwd_rows", coutp, n, p, q)
+    partial = torch.empty(cap, 3, coutp, dtype=torch.float32, device=dy.device)
+    used = ctypes.c_int(0)
     with PROFILE.rec(name, 2.0 * n * h * w * cin * cout * r * s):
         rc = try_call("msml_conv2d_bnbwd", dy, c0p, wp, wp.shape[0], out, coutp, n, h, w, p, q, r, s, stride,
                       pad_h, pad_w, 1, bn_x, coef[0], coef[1], alpha, coef[2], coef[3], partial, cap,

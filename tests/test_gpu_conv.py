@@ -341,11 +341,14 @@ def _bn_bwd_unfused(dy, x, coef, alpha, m, c):
 BNBWD = [(128, 64, 256, 14, 1), (40, 128, 128, 28, 1), (3, 64, 64, 14, 1), (20, 64, 64, 56, 1), (5, 128, 64, 9, 1), (4, 64, 128, 14, 2), (3, 128, 64, 9, 2)]
 
 
+@pytest.mark.parametrize("acc_mode", [True, False])
 @pytest.mark.parametrize("with_alpha", [False, True])
 @pytest.mark.parametrize("shape", BNBWD)
-def test_conv_dgrad_fused_bn_backward_reduce(shape, with_alpha):
+def test_conv_dgrad_fused_bn_backward_reduce(shape, with_alpha, acc_mode, monkeypatch):
     """msml_conv2d_bnbwd + msml_bn_act_bwd_apply == msml_conv2d (dgrad) + msml_bn_act_bwd, and the
-    `add` operand of the apply step is summed into dx."""
+    `add` operand of the apply step is summed into dx.  acc_mode: the same through the f64 accumulator protocol
+    (msml_conv2d_bnbwd_acc + msml_bn_fin_bwd_apply: no finalize launch)."""
+    monkeypatch.setattr(ops, "ACC_STATS", acc_mode)
     n, k, c, h, stride = shape
     g = torch.Generator().manual_seed(sum(shape))
     ho = (h + 2 - 3) // stride + 1
@@ -369,8 +372,13 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, with_alpha):
         dx = torch.empty_like(xbn)
         pg = torch.zeros(3, c, device="cuda")
         cw = torch.empty(98 * c, device="cuda")
-        _lib.call("msml_bn_act_bwd_apply", dxc, xbn, coef[0], coef[1], alpha, coef[2], coef[3], partial,
-                  partial.shape[0], addt, dx, pg[0], pg[1], pg[2] if with_alpha else None, 0, m, c, cw, _lib.BF16)
+        if acc_mode:
+            assert partial.dtype == torch.float64 and partial.shape == (8, 3, c)
+            _lib.call("msml_bn_fin_bwd_apply", dxc, xbn, coef[0], coef[1], alpha, coef[2], coef[3], partial, None, addt, 0, 0,
+                      dx, None, pg[0], pg[1], pg[2] if with_alpha else None, 0, m, c, None, None, None, None, _lib.BF16)
+        else:
+            _lib.call("msml_bn_act_bwd_apply", dxc, xbn, coef[0], coef[1], alpha, coef[2], coef[3], partial,
+                      partial.shape[0], addt, dx, pg[0], pg[1], pg[2] if with_alpha else None, 0, m, c, cw, _lib.BF16)
         ref = want_dx.float() + (addt.float() if addt is not None else 0)
         scale = ref.abs().max().item()
         assert (dx.float() - ref).abs().max().item() <= 1e-2 * scale
@@ -612,3 +620,46 @@ def test_fc_wgrad_window(n, c, e, k, boff, btot, acc):
     assert (got - want).abs().max().item() <= 2e-3 * ref.abs().max().item()
     rest = torch.cat([dw[:, :boff], dw[:, boff + c:]], 1)
     assert (rest == 0.25).all()                     # columns of other segments are left alone
+
+
+@pytest.mark.parametrize("n,k,c,h,stride,fold", [(64, 64, 64, 56, 1, False), (256, 256, 256, 14, 1, False),
+                                                 (64, 64, 128, 56, 1, True), (64, 128, 64, 56, 2, True)])
+def test_bn_backward_row_and_accumulator_protocols_agree(n, k, c, h, stride, fold, monkeypatch):
+    """The two hand-offs of the fused BatchNorm backward sums -- one partial row per workgroup + finalize launch, or f64
+    atomics into 8 accumulator rows folded by the apply kernel (ops.ACC_STATS) -- carry the same numbers: the f64
+    totals are EQUAL (f64 sums of f32 partials are exact), and so are dx and the parameter gradients bit for bit while
+    the row protocol sums its rows directly (<= 512 rows).  Beyond that the row protocol first folds to 32 rows rounded
+    to f32, which costs it ~1e-5 in the parameter gradients and a handful of 1-ulp flips in dx."""
+    g = torch.Generator().manual_seed(n + c)
+    ho = (h + 2 - 3) // stride + 1
+    dyd = ops.to_nhwc(torch.randn(n, k, ho, ho, generator=g).cuda(), _lib.BF16)
+    w = (torch.randn(k, c, 3, 3, generator=g) * 0.05).cuda()
+    xbn = ops.to_nhwc(torch.randn(n, c, h, h, generator=g).cuda(), _lib.BF16)
+    coef = torch.stack([torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3,
+                        torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5]).cuda()
+    alpha = (torch.rand(c, generator=g) * 0.5).cuda()
+    wp = ops.pack_weight(w, True, k, 0, _lib.BF16)
+    m = n * h * h
+    out = {}
+    for acc in (False, True):
+        monkeypatch.setattr(ops, "ACC_STATS", acc)
+        dxc, partial = ops.conv_dgrad_bnbwd(dyd, wp, c, 3, 3, stride, 1, 1, h, h, xbn, coef, alpha)
+        dx, pg = torch.empty_like(xbn), torch.zeros(3, c, device="cuda")
+        if acc:
+            assert partial.dtype == torch.float64 and tuple(partial.shape) == (8, 3, c)
+            _lib.call("msml_bn_fin_bwd_apply", dxc, xbn, coef[0], coef[1], alpha, coef[2], coef[3], partial, None, None, 0, 0,
+                      dx, None, pg[0], pg[1], pg[2], 0, m, c, None, None, None, None, _lib.BF16)
+        else:
+            assert (partial.shape[0] > 512) == fold
+            cw = torch.empty(98 * c, device="cuda")
+            _lib.call("msml_bn_act_bwd_apply", dxc, xbn, coef[0], coef[1], alpha, coef[2], coef[3], partial,
+                      partial.shape[0], None, dx, pg[0], pg[1], pg[2], 0, m, c, cw, _lib.BF16)
+        out[acc] = (dxc, dx, pg, partial.double().sum(0))
+    a, b = out[True], out[False]
+    assert torch.equal(a[0], b[0])
+    assert torch.equal(a[3], b[3])                     # the three sums, in f64: identical totals
+    if not fold:
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    else:
+        assert ((a[2] - b[2]).abs() <= 1e-4 * b[2].abs() + 1e-6).all()
+        assert int((a[1] != b[1]).sum()) < 1e-5 * a[1].numel()
