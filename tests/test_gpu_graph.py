@@ -1,0 +1,72 @@
+"""hipGraph capture of the whole training step (what `bench.py --launch graph` replays): replays must walk the same
+trajectory as eager steps.  Besides the kernels this pins the per-step host-side state that a replay does not re-run:
+the pack-cache refresh, the padded-bias refresh and the zero fill of the BatchNorm accumulator arena (ops._AccArena) --
+an accumulator that a replay did not re-zero would add the statistics of consecutive steps."""
+import pytest
+import torch
+
+from msml_amd import ops, synthetic
+from msml_amd.backbones import MSML
+from msml_amd.optim import FlatSGD
+from msml_amd.tricks.consensus_loss import StructureConsensuLossFunction
+from oracle.fill import fill_module
+
+pytestmark = pytest.mark.gpu
+PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
+
+
+def _run(use_graph, steps=3):
+    torch.manual_seed(0)
+    m = fill_module(MSML("iresnet18", "unet", (1, 1, 1, 1), 50, fp16=True, fm_params=(3, 2, "sigmoid", "mul"),
+                         header_type="AMArcFace", peer_params=dict(PEER_OFF))).cuda().train()
+    opt = FlatSGD([{"params": [p for p in m.parameters() if p.requires_grad], "lr": 0.01}], 0.9, 5e-4, 5.0)
+    x = synthetic.images(8, seed=5)
+    x, msk = synthetic.rect_occlusion(x, seed=5)
+    x, msk, lab = x.cuda(), msk.cuda(), synthetic.labels(8, 50, seed=5).cuda()
+    crit = StructureConsensuLossFunction(10.0, 5.0)
+
+    def step():
+        opt.zero_grad()
+        cls, seg, _ = m(x, lab)
+        loss = torch.nn.functional.cross_entropy(cls, lab) + crit(seg, msk, msk)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    try:
+        side = torch.cuda.Stream()                       # PyTorch's capture recipe: warm up on a side stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        losses = []
+        if use_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step()
+            losses.append(float(out))                    # (the capture itself does not run the step)
+            losses.clear()
+            for _ in range(steps):
+                graph.replay()
+                losses.append(float(out))
+        else:
+            for _ in range(steps):
+                losses.append(float(step()))
+        torch.cuda.synchronize()
+        return losses, opt.flat_w.clone(), {n: b.clone() for n, b in m.named_buffers() if "running_var" in n}
+    finally:
+        opt.release()
+
+
+def test_graph_replay_walks_the_eager_trajectory():
+    assert ops.ACC_STATS
+    le, we, re_ = _run(False)
+    lg, wg, rg = _run(True)
+    print("eager losses", le, "graph losses", lg)
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(le, lg)), (le, lg)
+    assert le[-1] < le[0]                                # and it trains
+    assert float((we - wg).abs().max()) <= 1e-6 * float(we.abs().max())
+    for n in re_:
+        assert torch.allclose(re_[n], rg[n], rtol=1e-5, atol=1e-7), n
