@@ -217,8 +217,9 @@ int msml_bn_fin_bwd_apply(const void* dy, const void* x, const float* scale, con
                           const float* next_invstd, double* next_acc, int dtype, void* stream);
 int msml_bn_act_bwd_acc(const void* dy, const void* x, const float* scale, const float* shift,
                         const float* alpha, const float* save_mean, const float* save_invstd,
-                        const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,
-                        float* dalpha, int accumulate, long M, int C, double* acc, int dtype, void* stream);
+                        const void* residual_first, const void* add, void* dx, void* dres, float* dgamma,
+                        float* dbeta, float* dalpha, int accumulate, long M, int C, double* acc, int dtype,
+                        void* stream);
 int msml_bn_act_bwd(const void* dy, const void* x, const float* scale, const float* shift,
                     const float* alpha, const float* save_mean, const float* save_invstd,
                     const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,

@@ -220,12 +220,11 @@ def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None, add_s2=Fa
     s2 = (add, x.shape[1], x.shape[2]) if add_s2 else (add,)
     sfx = "_s2" if add_s2 else ""
     if partial is None and ops.acc_applies(c, BF16):
+        assert not add_s2, "a compact stride-2 `add` needs the producer-side sums (docstring)"
         # accumulator mode (ops.ACC_STATS): the reduce pass adds into a zeroed f64 block, finalize + apply are one launch
         with ops.PROFILE.rec("bn_act_bwd", 0.0, x.numel() * x.element_size() * 5):
-            call("msml_bn_act_bwd_acc", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], None, dx, None,
+            call("msml_bn_act_bwd_acc", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], None, add, dx, None,
                  pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, ops.stats_acc(c, x.device, 3), BF16)
-        if add is not None:
-            call("msml_add", dx, add, dx, dx.numel(), BF16)
     elif partial is None:
         rows = ops.bn_stats_rows(m, c)
         ws = ops.workspace((rows * 3 * c + 2 * c) * 4, x.device)
@@ -436,7 +435,7 @@ class _Bottle(torch.autograd.Function):
         dc3, dres = torch.empty_like(c3), torch.empty_like(x)
         with ops.PROFILE.rec("bn_act_bwd", 0.0, c3.numel() * c3.element_size() * 7):
             if ops.acc_applies(c, BF16):
-                call("msml_bn_act_bwd_acc", dout, c3, k3[0], k3[1], bp["a3"], k3[2], k3[3], x, dc3, dres,
+                call("msml_bn_act_bwd_acc", dout, c3, k3[0], k3[1], bp["a3"], k3[2], k3[3], x, None, dc3, dres,
                      g3.tg[0], g3.tg[1], g3.tg[2], int(g3.inplace), m, c, ops.stats_acc(c, dev, 3), BF16)
             else:
                 rows = ops.bn_stats_rows(m, c)

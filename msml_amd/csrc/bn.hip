@@ -840,11 +840,13 @@ extern "C" int msml_bn_fin_bwd_apply(const void* dy, const void* x, const float*
   return MSML_OK;
 }
 
-// msml_bn_act_bwd (no producer-side sums): reduce pass into the accumulator, then the fused finalize + apply.
+// msml_bn_act_bwd (no producer-side sums): reduce pass into the accumulator, then the fused finalize + apply
+// (`add`, optional: another gradient path that joins at the BatchNorm input, summed into dx by the apply pass).
 extern "C" int msml_bn_act_bwd_acc(const void* dy, const void* x, const float* scale, const float* shift,
                                    const float* alpha, const float* save_mean, const float* save_invstd,
-                                   const void* residual_first, void* dx, void* dres, float* dgamma, float* dbeta,
-                                   float* dalpha, int accumulate, long M, int C, double* acc, int dtype, void* stream) {
+                                   const void* residual_first, const void* add, void* dx, void* dres, float* dgamma,
+                                   float* dbeta, float* dalpha, int accumulate, long M, int C, double* acc, int dtype,
+                                   void* stream) {
   MSML_CHECK(dy && x && dx && scale && shift && save_mean && save_invstd && acc && M > 0 && C > 0 && C % 8 == 0 &&
                  C <= 2048, MSML_ERR_SHAPE, "bn_act_bwd_acc: bad args M=%ld C=%d", M, C);
   const int rows = red_rows(M, C);
@@ -860,7 +862,7 @@ extern "C" int msml_bn_act_bwd_acc(const void* dy, const void* x, const float* s
                                                                        save_mean, save_invstd, (const DT*)residual_first,
                                                                        M, C, reinterpret_cast<float*>(acc), 1);)
   MSML_LAUNCH_OK("bn_bwd_reduce(acc)");
-  return msml_bn_fin_bwd_apply(dy, x, scale, shift, alpha, save_mean, save_invstd, acc, residual_first, nullptr, 0, 0,
+  return msml_bn_fin_bwd_apply(dy, x, scale, shift, alpha, save_mean, save_invstd, acc, residual_first, add, 0, 0,
                                dx, dres, dgamma, dbeta, dalpha, accumulate, M, C, nullptr, nullptr, nullptr, nullptr,
                                dtype, stream);
 }

@@ -226,7 +226,7 @@ class _BnAct(torch.autograd.Function):
             tg = [pg[0], pg[1], pg[2] if alpha is not None else None]
         with ops.PROFILE.rec("bn_act_bwd", 0.0, x.numel() * x.element_size() * (5 + (3 if ctx.res_first else 0))):
             if ops.acc_applies(c, dtype):
-                call("msml_bn_act_bwd_acc", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, dx, dres,
+                call("msml_bn_act_bwd_acc", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, None, dx, dres,
                      tg[0], tg[1], tg[2], int(inplace), m, c, ops.stats_acc(c, x.device, 3), dtype)
             else:
                 call("msml_bn_act_bwd", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, dx, dres,
