@@ -361,13 +361,15 @@ int msml_pair_hist(const double* dist, const unsigned char* same, int n_pairs, c
 /* ---------------------------------------------------------------- device input pipeline ----------
  * Replaces the per-sample CPU augmentation of FaceByRandOccMask.__getitem__ (datasets/load_dataset.py:
  * 101-139) for the occluders that need no dataset assets: RandomRect (datasets/augment/rand_occ.py:103-139),
- * RandomEllipse (:148-203, analytic ellipse), NoneOcc (:80-90), RandomBlock (:43-72, evaluation), the random
+ * RandomEllipse (:148-203, analytic ellipse), RandomConnectedPolygon (:217-322, even-odd point-in-polygon test),
+ * NoneOcc (:80-90), RandomBlock (:43-72, evaluation), the random
  * horizontal flip (load_dataset.py:119-123), the Gaussian light of _add_gauss_to_face (:183-201, _get_gauss
  * :282-339) and ToTensor + Normalize(0.5, 0.5).
- * msml_occ_draw: per-image descriptors desc[N][16] int32 {kind (0 none, 1 rect, 2 ellipse, 3 block),
- *   x0|cx, y0|cy, w|aw, h|ah, r, g, b, flip, light cx / cy / scale (f32 bits), 0...} from a counter-based
- *   generator keyed by (seed, offset + image index): mode 0 = training mix {rect, ellipse, none}, 1 = rect
- *   (lo..hi percent), 2 = black block (lo..hi percent), 3 = none.
+ * msml_occ_draw: per-image descriptors desc[N][64] int32 {kind (0 none, 1 rect, 2 ellipse, 3 block, 4 polygon),
+ *   x0|cx, y0|cy, w|aw, h|ah, r, g, b, flip, light cx / cy / scale (f32 bits), polygon vertex count, 0, 0, 0,
+ *   up to 24 polygon vertices (x, y)} from a counter-based generator keyed by (seed, offset + image index):
+ *   mode 0 = training mix {rect, ellipse, polygon, none}, 1 = rect (lo..hi percent), 2 = black block (lo..hi
+ *   percent), 3 = none, 4 = polygon.
  * msml_occ_apply: src [N][H][W][3] uint8 (decoded RGB) -> img [N][3][H][W] f32 in [-1, 1] (occluded,
  *   flipped, lit when light != 0, normalised), msk [N][H][W] int64 (0 occluded / 1 clean,
  *   load_dataset.py:37), ori [N][3][H][W] (clean, flipped, normalised; optional). */

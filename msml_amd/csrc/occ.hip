@@ -3,13 +3,14 @@
 //
 // Replaces the per-sample CPU work of FaceByRandOccMask.__getitem__ (datasets/load_dataset.py:101-139):
 //   _get_occluded_face_and_mask  -> RandomRect (datasets/augment/rand_occ.py:103-139), RandomEllipse
-//                                   (:148-203, analytic ellipse instead of cv2's rasteriser), NoneOcc (:80-90),
-//                                   RandomBlock (:43-72, evaluation)
+//                                   (:148-203, analytic ellipse instead of cv2's rasteriser), RandomConnectedPolygon
+//                                   (:217-322, even-odd point-in-polygon test instead of cv2.fillPoly), NoneOcc
+//                                   (:80-90), RandomBlock (:43-72, evaluation)
 //   random horizontal flip       -> load_dataset.py:119-123
 //   _add_gauss_to_face           -> load_dataset.py:183-201 with _get_gauss :282-339 (Euclidean, radius 128)
 //   Msk2Tenser / Normalize       -> mask 0 = occluded, 1 = clean (load_dataset.py:37); (x - 0.5) / 0.5
-// Facial-mask records (mask_out.rec), polygon / glasses / scarf / real-object occluders need the dataset's
-// assets and are not synthesised.
+// Facial-mask records (mask_out.rec), glasses / scarf / real-object occluders need the dataset's assets and are
+// not synthesised.
 //
 // Random draws come from a counter-based generator (splitmix64 of seed, image index, draw index): the
 // same (seed, offset) gives the same batch on any launch geometry, and the CPU oracle regenerates it.
@@ -21,10 +22,12 @@
 // contraction, so that truncations to int agree bit for bit
 #pragma clang fp contract(off)
 
-#define OCC_DESC 16      // int32 words per image
-enum { OCC_NONE = 0, OCC_RECT = 1, OCC_ELLIPSE = 2, OCC_BLOCK = 3 };
+#define OCC_DESC 64      // int32 words per image
+#define OCC_MAXV 24      // polygon vertices (at most 1 + 2 * 10)
+enum { OCC_NONE = 0, OCC_RECT = 1, OCC_ELLIPSE = 2, OCC_BLOCK = 3, OCC_POLY = 4 };
 // desc: 0 kind | 1 x0 / cx | 2 y0 / cy | 3 w / aw | 4 h / ah | 5,6,7 r g b | 8 flip | 9 light cx (f32 bits)
-//       10 light cy (f32 bits) | 11 light scale (f32 bits) | 12..15 reserved
+//       10 light cy (f32 bits) | 11 light scale (f32 bits) | 12 polygon vertex count | 13..15 reserved
+//       16 + 2 v, 17 + 2 v: polygon vertex v (x, y)
 
 __host__ __device__ inline unsigned long long occ_mix(unsigned long long z) {
   z += 0x9E3779B97F4A7C15ULL;
@@ -42,8 +45,27 @@ __host__ __device__ inline int occ_randint(unsigned int u, int a, int b) {
 // uniform f32 in [0, 1) with 24 bits
 __host__ __device__ inline float occ_unif(unsigned int u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
 
-// mode 0: training mix -- kind uniform over {rect, ellipse, none}; mode 1: RandomRect only;
-// mode 2: RandomBlock(lo, hi, 'black') (evaluation); mode 3: no occlusion.
+// sin / cos for the polygon vertices, written out operation by operation (quadrant reduction + Taylor polynomials in
+// f32, no FMA) so that the CPU oracle reproduces the truncated integer coordinates bit for bit; |error| < 2e-6
+__host__ __device__ inline void occ_sincos(float a, float* s, float* c) {
+  const int q = (int)(a * 0.63661977236758134f + 0.5f);            // nearest multiple of pi / 2 (a >= 0)
+  const float r = (a - (float)q * 1.5707963705062866f) - (float)q * -4.371138828673793e-08f;
+  const float r2 = r * r;
+  float sp = -1.9841270114e-04f + r2 * 2.7557314297e-06f;
+  sp = 8.3333337680e-03f + r2 * sp;
+  sp = -1.6666667163e-01f + r2 * sp;
+  sp = r + r * (r2 * sp);
+  float cp = -1.3888889225e-03f + r2 * (2.4801587642e-05f + r2 * -2.7557314297e-07f);
+  cp = 4.1666667908e-02f + r2 * cp;
+  cp = -0.5f + r2 * cp;
+  cp = 1.0f + r2 * cp;
+  const int m = q & 3;
+  *s = m == 0 ? sp : (m == 1 ? cp : (m == 2 ? -sp : -cp));
+  *c = m == 0 ? cp : (m == 1 ? -sp : (m == 2 ? -cp : sp));
+}
+
+// mode 0: training mix -- kind uniform over {rect, ellipse, polygon, none}; mode 1: RandomRect only;
+// mode 2: RandomBlock(lo, hi, 'black') (evaluation); mode 3: no occlusion; mode 4: RandomConnectedPolygon only.
 __global__ void k_occ_draw(unsigned long long seed, unsigned long long offset, int N, int H, int W, int mode, int lo,
                            int hi, int flip_on, int* __restrict__ desc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,10 +75,11 @@ __global__ void k_occ_draw(unsigned long long seed, unsigned long long offset, i
   for (int k = 0; k < OCC_DESC; k++) d[k] = 0;
   int kind = OCC_NONE;
   if (mode == 0) {
-    const int pick = occ_randint(occ_u32(seed, img, 0), 0, 3);
-    kind = pick == 0 ? OCC_RECT : (pick == 1 ? OCC_ELLIPSE : OCC_NONE);
+    const int pick = occ_randint(occ_u32(seed, img, 0), 0, 4);
+    kind = pick == 0 ? OCC_RECT : (pick == 1 ? OCC_ELLIPSE : (pick == 2 ? OCC_POLY : OCC_NONE));
   } else if (mode == 1) kind = OCC_RECT;
   else if (mode == 2) kind = OCC_BLOCK;
+  else if (mode == 4) kind = OCC_POLY;
   if (kind == OCC_RECT) {                       // rand_occ.py:113-121
     const int pct = occ_randint(occ_u32(seed, img, 1), lo, hi);
     const float ratio = (float)pct * 0.01f;
@@ -77,6 +100,34 @@ __global__ void k_occ_draw(unsigned long long seed, unsigned long long offset, i
     const float ratio = 0.2f + (0.4f - 0.2f) * occ_unif(occ_u32(seed, img, 4));
     const int aw = (int)((float)(H * W) * ratio / (3.14f * (float)ah));
     d[1] = cw; d[2] = ch; d[3] = aw; d[4] = ah;
+    for (int c = 0; c < 3; c++) d[5 + c] = occ_randint(occ_u32(seed, img, 5 + c), 1, 256);
+  } else if (kind == OCC_POLY) {                // rand_occ.py:262-322: a star between a big and a small circle
+    const int cnt = occ_randint(occ_u32(seed, img, 1), 4, 11);
+    const int cx = occ_randint(occ_u32(seed, img, 2), H / 5, 4 * H / 5);
+    const int cy = occ_randint(occ_u32(seed, img, 3), W / 5, 4 * W / 5);
+    const int big = occ_randint(occ_u32(seed, img, 4), H / 5, (int)(1.3f * (float)H) / 5);
+    const float small = (float)big / (1.3f + (2.6f - 1.3f) * occ_unif(occ_u32(seed, img, 12)));
+    const float step = 6.2831854820251465f / (float)cnt;
+    float ab = 0.f, as = 0.f, sn, cs;
+    int nv = 0;
+    d[16] = (int)((float)cx + (float)big);                 // angle 0 on the big circle
+    d[17] = cy;
+    nv = 1;
+    for (int i = 0; i < cnt; i++) {
+      ab = ab + step * (0.7f + (1.3f - 0.7f) * occ_unif(occ_u32(seed, img, 16 + 3 * i)));
+      occ_sincos(ab, &sn, &cs);
+      d[16 + 2 * nv] = (int)((float)cx + (float)big * cs);
+      d[17 + 2 * nv] = (int)((float)cy + (float)big * sn);
+      nv++;
+      if (occ_unif(occ_u32(seed, img, 17 + 3 * i)) > 0.5f) {
+        as = as + step * (0.6f + (1.4f - 0.6f) * occ_unif(occ_u32(seed, img, 18 + 3 * i)));
+        occ_sincos(as, &sn, &cs);
+        d[16 + 2 * nv] = (int)((float)cx + small * cs);
+        d[17 + 2 * nv] = (int)((float)cy + small * sn);
+        nv++;
+      }
+    }
+    d[12] = nv;
     for (int c = 0; c < 3; c++) d[5 + c] = occ_randint(occ_u32(seed, img, 5 + c), 1, 256);
   } else if (kind == OCC_BLOCK) {               // rand_occ.py:36-70
     const int pct = occ_randint(occ_u32(seed, img, 1), lo, hi);
@@ -104,6 +155,18 @@ __device__ __forceinline__ bool occ_inside(const int* d, int x, int y) {
     const float dx = (float)(x - d[1]), dy = (float)(y - d[2]);
     const float aw = (float)d[3], ah = (float)d[4];
     return dx * dx * ah * ah + dy * dy * aw * aw <= aw * aw * ah * ah;
+  }
+  if (kind == OCC_POLY) {                       // even-odd rule on the integer lattice, exact integer arithmetic
+    const int nv = d[12];
+    bool in = false;
+    for (int i = 0, j = nv - 1; i < nv; j = i++) {
+      const int xi = d[16 + 2 * i], yi = d[17 + 2 * i], xj = d[16 + 2 * j], yj = d[17 + 2 * j];
+      if ((yi > y) != (yj > y)) {
+        const int dyv = yj - yi, lhs = (x - xi) * dyv, rhs = (xj - xi) * (y - yi);
+        if (dyv > 0 ? lhs < rhs : lhs > rhs) in = !in;
+      }
+    }
+    return in;
   }
   return false;
 }
@@ -166,7 +229,7 @@ __global__ void __launch_bounds__(256) k_occ_apply(const unsigned char* __restri
 
 extern "C" int msml_occ_draw(long seed, long offset, int N, int H, int W, int mode, int lo, int hi,
                              int flip, int* desc, void* stream) {
-  MSML_CHECK(desc && N > 0 && H >= 32 && W >= 32 && mode >= 0 && mode <= 3 && lo >= 0 && hi > lo && hi <= 101,
+  MSML_CHECK(desc && N > 0 && H >= 32 && W >= 32 && mode >= 0 && mode <= 4 && lo >= 0 && hi > lo && hi <= 101,
              MSML_ERR_SHAPE, "occ_draw: bad arguments N=%d H=%d W=%d mode=%d lo=%d hi=%d", N, H, W, mode, lo, hi);
   k_occ_draw<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>((unsigned long long)seed, (unsigned long long)offset, N, H, W, mode, lo, hi, flip, desc);
   MSML_LAUNCH_OK("occ_draw");

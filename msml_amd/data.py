@@ -20,12 +20,12 @@ import torch
 
 from ._lib import call
 
-MODES = {"train": 0, "rect": 1, "block": 2, "none": 3}
-DESC_WORDS = 16
+MODES = {"train": 0, "rect": 1, "block": 2, "none": 3, "polygon": 4}
+DESC_WORDS = 64
 
 
 def draw(n, seed, offset, mode="train", lo=0, hi=36, flip=True, size=112, device="cuda"):
-    """Per-image occlusion / flip / light descriptors (msml_occ_draw), int32 [n, 16] on the device."""
+    """Per-image occlusion / flip / light descriptors (msml_occ_draw), int32 [n, 64] on the device."""
     desc = torch.empty(n, DESC_WORDS, dtype=torch.int32, device=device)
     call("msml_occ_draw", int(seed), int(offset), n, size, size, MODES[mode], lo, hi, int(flip), desc)
     return desc

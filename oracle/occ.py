@@ -2,7 +2,8 @@
 
 Restates, for numpy arrays, the reference's per-sample augmentation (datasets/load_dataset.py:101-139):
 RandomRect (datasets/augment/rand_occ.py:103-139), RandomEllipse (:148-203; analytic ellipse instead of
-cv2.ellipse, which is not installed here), NoneOcc (:80-90), RandomBlock (:43-72), the random flip
+cv2.ellipse, which is not installed here), RandomConnectedPolygon (:217-322; even-odd point-in-polygon test on the
+integer lattice instead of cv2.fillPoly), NoneOcc (:80-90), RandomBlock (:43-72), the random flip
 (load_dataset.py:119-123), _add_gauss_to_face (:183-201) with _get_gauss (:282-339) and ToTensor +
 Normalize(0.5, 0.5).  The reference's dataset module cannot be imported in the build container
 (mxnet, cv2, torchvision absent), so this part is parity-unpinned by execution: the geometry is pinned
@@ -13,7 +14,8 @@ uint64 arithmetic so that the CPU regenerates exactly the batch the GPU drew.
 """
 import numpy as np
 
-OCC_NONE, OCC_RECT, OCC_ELLIPSE, OCC_BLOCK = 0, 1, 2, 3
+OCC_NONE, OCC_RECT, OCC_ELLIPSE, OCC_BLOCK, OCC_POLY = 0, 1, 2, 3, 4
+DESC_WORDS = 64
 M64 = (1 << 64) - 1
 f32 = np.float32
 
@@ -37,20 +39,42 @@ def unif(u):
     return f32(u >> 8) * f32(1.0 / 16777216.0)
 
 
+def sincos(a):
+    """occ_sincos of csrc/occ.hip, operation by operation in f32 (quadrant reduction + Taylor polynomials)."""
+    a = f32(a)
+    q = int(f32(f32(a * f32(0.63661977236758134)) + f32(0.5)))
+    r = f32(f32(a - f32(f32(q) * f32(1.5707963705062866))) - f32(f32(q) * f32(-4.371138828673793e-08)))
+    r2 = f32(r * r)
+    sp = f32(f32(-1.9841270114e-04) + f32(r2 * f32(2.7557314297e-06)))
+    sp = f32(f32(8.3333337680e-03) + f32(r2 * sp))
+    sp = f32(f32(-1.6666667163e-01) + f32(r2 * sp))
+    sp = f32(r + f32(r * f32(r2 * sp)))
+    cp = f32(f32(-1.3888889225e-03) + f32(r2 * f32(f32(2.4801587642e-05) + f32(r2 * f32(-2.7557314297e-07)))))
+    cp = f32(f32(4.1666667908e-02) + f32(r2 * cp))
+    cp = f32(f32(-0.5) + f32(r2 * cp))
+    cp = f32(f32(1.0) + f32(r2 * cp))
+    m = q & 3
+    s = sp if m == 0 else (cp if m == 1 else (f32(-sp) if m == 2 else f32(-cp)))
+    c = cp if m == 0 else (f32(-sp) if m == 1 else (f32(-cp) if m == 2 else sp))
+    return s, c
+
+
 def draw(seed, offset, n, h, w, mode, lo=0, hi=36, flip=True):
-    """desc[n][16] int32, the same words as msml_occ_draw."""
-    out = np.zeros((n, 16), np.int32)
+    """desc[n][64] int32, the same words as msml_occ_draw."""
+    out = np.zeros((n, DESC_WORDS), np.int32)
     for i in range(n):
         img = offset + i
         d = out[i]
         kind = OCC_NONE
         if mode == 0:
-            pick = randint(u32(seed, img, 0), 0, 3)
-            kind = OCC_RECT if pick == 0 else (OCC_ELLIPSE if pick == 1 else OCC_NONE)
+            pick = randint(u32(seed, img, 0), 0, 4)
+            kind = (OCC_RECT, OCC_ELLIPSE, OCC_POLY, OCC_NONE)[pick]
         elif mode == 1:
             kind = OCC_RECT
         elif mode == 2:
             kind = OCC_BLOCK
+        elif mode == 4:
+            kind = OCC_POLY
         if kind == OCC_RECT:
             pct = randint(u32(seed, img, 1), lo, hi)
             ratio = f32(pct) * f32(0.01)
@@ -72,6 +96,28 @@ def draw(seed, offset, n, h, w, mode, lo=0, hi=36, flip=True):
             ratio = f32(0.2) + (f32(0.4) - f32(0.2)) * unif(u32(seed, img, 4))
             aw = int(f32(h * w) * ratio / (f32(3.14) * f32(ah)))
             d[1], d[2], d[3], d[4] = cw, ch, aw, ah
+            for c in range(3):
+                d[5 + c] = randint(u32(seed, img, 5 + c), 1, 256)
+        elif kind == OCC_POLY:                     # rand_occ.py:262-322
+            cnt = randint(u32(seed, img, 1), 4, 11)
+            cx = randint(u32(seed, img, 2), h // 5, 4 * h // 5)
+            cy = randint(u32(seed, img, 3), w // 5, 4 * w // 5)
+            big = randint(u32(seed, img, 4), h // 5, int(f32(1.3) * f32(h)) // 5)
+            small = f32(f32(big) / f32(f32(1.3) + f32(f32(f32(2.6) - f32(1.3)) * unif(u32(seed, img, 12)))))
+            step = f32(f32(6.2831854820251465) / f32(cnt))
+            ab, as_ = f32(0), f32(0)
+            verts = [(int(f32(f32(cx) + f32(big))), cy)]
+            for i in range(cnt):
+                ab = f32(ab + f32(step * f32(f32(0.7) + f32(f32(f32(1.3) - f32(0.7)) * unif(u32(seed, img, 16 + 3 * i))))))
+                sn, cs = sincos(ab)
+                verts.append((int(f32(f32(cx) + f32(f32(big) * cs))), int(f32(f32(cy) + f32(f32(big) * sn)))))
+                if unif(u32(seed, img, 17 + 3 * i)) > f32(0.5):
+                    as_ = f32(as_ + f32(step * f32(f32(0.6) + f32(f32(f32(1.4) - f32(0.6)) * unif(u32(seed, img, 18 + 3 * i))))))
+                    sn, cs = sincos(as_)
+                    verts.append((int(f32(f32(cx) + f32(small * cs))), int(f32(f32(cy) + f32(small * sn)))))
+            d[12] = len(verts)
+            for v, (vx, vy) in enumerate(verts):
+                d[16 + 2 * v], d[17 + 2 * v] = vx, vy
             for c in range(3):
                 d[5 + c] = randint(u32(seed, img, 5 + c), 1, 256)
         elif kind == OCC_BLOCK:
@@ -101,6 +147,19 @@ def inside(d, h, w):
         dx, dy = (xs - d[1]).astype(f32), (ys - d[2]).astype(f32)
         aw, ah = f32(d[3]), f32(d[4])
         return dx * dx * ah * ah + dy * dy * aw * aw <= aw * aw * ah * ah
+    if d[0] == OCC_POLY:                           # even-odd rule, exact integer arithmetic (csrc/occ.hip occ_inside)
+        nv = int(d[12])
+        ins = np.zeros((h, w), bool)
+        xs, ys = xs.astype(np.int64), ys.astype(np.int64)
+        j = nv - 1
+        for i in range(nv):
+            xi, yi, xj, yj = int(d[16 + 2 * i]), int(d[17 + 2 * i]), int(d[16 + 2 * j]), int(d[17 + 2 * j])
+            cross = (yi > ys) != (yj > ys)
+            dyv = yj - yi
+            lhs, rhs = (xs - xi) * dyv, (xj - xi) * (ys - yi)
+            ins ^= cross & ((lhs < rhs) if dyv > 0 else (lhs > rhs))
+            j = i
+        return ins
     return np.zeros((h, w), bool)
 
 

@@ -18,7 +18,7 @@ def test_oracle_rect_geometry_is_synthetic_py():
     x = torch.from_numpy(((src.astype(np.float32) / np.float32(255) - np.float32(0.5)) / np.float32(0.5))
                          .transpose(0, 3, 1, 2).copy())
     xs, msk_s = synthetic.rect_occlusion(x, seed=3, lo=5, hi=36)
-    desc = np.zeros((b, 16), np.int32)
+    desc = np.zeros((b, oo.DESC_WORDS), np.int32)
     for i in range(b):                       # the draw order of synthetic.rect_occlusion
         ratio = rng.randint(5, 36) * 0.01
         area = int(w * h * ratio)
@@ -35,7 +35,7 @@ def test_oracle_rect_geometry_is_synthetic_py():
 
 
 def test_oracle_hand_cases():
-    d = np.zeros(16, np.int32)
+    d = np.zeros(oo.DESC_WORDS, np.int32)
     d[:5] = [oo.OCC_BLOCK, 10, 20, 70, 70]
     occ = oo.inside(d, 112, 112)
     assert occ.sum() == 4900 and occ[20, 10] and occ[89, 79] and not occ[90, 79] and not occ[20, 80]
@@ -50,15 +50,34 @@ def test_oracle_hand_cases():
     # training mix: every kind appears, rectangles obey RandomRect's constraints
     desc = oo.draw(7, 100, 400, 112, 112, 0)
     kinds = set(desc[:, 0].tolist())
-    assert kinds == {0, 1, 2}
+    assert kinds == {0, 1, 2, 4}
     r = desc[desc[:, 0] == oo.OCC_RECT]
     assert (r[:, 1] + r[:, 3] <= 112).all() and (r[:, 2] + r[:, 4] <= 112).all()
     assert (r[:, 3] * r[:, 4] <= 0.36 * 112 * 112).all()
     assert 0.4 < desc[:, 8].mean() < 0.8                     # P{flip} = 6/10 (randint(1, 11) >= 5)
+    # RandomConnectedPolygon: a hand-made square, and the drawn stars (rand_occ.py:262-322: 4..10 big-circle points
+    # of radius 22..28 around a centre in the middle three fifths, a small-circle point after each with P = 1/2)
+    d = np.zeros(oo.DESC_WORDS, np.int32)
+    d[0], d[12] = oo.OCC_POLY, 4
+    d[16:24] = [10, 10, 50, 10, 50, 40, 10, 40]
+    sq = oo.inside(d, 112, 112)
+    assert sq[10, 10] and sq[39, 49] and not sq[40, 20] and not sq[20, 50] and sq.sum() == 40 * 30
+    s, c = oo.sincos(np.float32(2.5))
+    assert abs(float(s) - np.sin(2.5)) < 2e-6 and abs(float(c) - np.cos(2.5)) < 2e-6
+    assert all(abs(float(oo.sincos(np.float32(a))[0]) - np.sin(np.float32(a))) < 2e-6 for a in np.linspace(0, 9, 200))
+    p = desc[desc[:, 0] == oo.OCC_POLY]
+    assert len(p) > 50 and (p[:, 12] >= 5).all() and (p[:, 12] <= 21).all()
+    for dd in p[:40]:
+        v = dd[16:16 + 2 * dd[12]].reshape(-1, 2)
+        r = np.hypot(v[:, 0] - v[0, 0], v[:, 1] - v[0, 1])                   # distances from the first vertex (angle 0)
+        assert r.max() <= 2 * 28 + 2                                          # every vertex within the big circle's diameter
+        area = oo.inside(dd, 112, 112).sum()
+        assert 150 < area < np.pi * 29 * 29                                   # a star inside the big circle
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,lo,hi", [("train", 0, 36), ("rect", 0, 36), ("block", 40, 41), ("none", 0, 36)])
+@pytest.mark.parametrize("mode,lo,hi", [("train", 0, 36), ("rect", 0, 36), ("block", 40, 41), ("none", 0, 36),
+                                        ("polygon", 0, 36)])
 def test_device_pipeline_matches_oracle(mode, lo, hi):
     from msml_amd import data
     n = 64
