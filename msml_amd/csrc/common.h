@@ -12,7 +12,9 @@
 // f64 sum of f32 partials is exact unless two partials differ by more than 2^29, so the result does not depend on
 // the order of the adds (and equals the fixed-order f64 sum of the row format).  The mode travels from the C entry
 // point to the launch sites in a thread-local (set and reset inside one call: the library stays reentrant).
+#ifndef MSML_ACC_ROWS
 #define MSML_ACC_ROWS 8
+#endif
 extern thread_local int msml_tl_stats_acc;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
