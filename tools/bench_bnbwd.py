@@ -11,7 +11,7 @@ from msml_amd import _lib, ops  # noqa: E402
 from tools.bench_conv import timeit  # noqa: E402
 
 SHAPES = [(256, 256, 14, 1), (128, 128, 28, 1), (64, 64, 56, 1), (64, 64, 112, 1), (512, 512, 7, 1),
-          (128, 128, 56, 2), (256, 256, 28, 2)]
+          (64, 64, 112, 2), (128, 128, 56, 2), (256, 256, 28, 2)]
 
 
 def main():
@@ -36,8 +36,13 @@ def main():
                                         None, pg[0], pg[1], pg[2], 0, m, c, ws, ws.numel(), _lib.BF16))
         t_fconv = timeit(lambda: ops.conv_dgrad_bnbwd(dy, wp, c, 3, 3, stride, 1, 1, h, h, x, coef, alpha))
         dxc, part = ops.conv_dgrad_bnbwd(dy, wp, c, 3, 3, stride, 1, 1, h, h, x, coef, alpha)
-        t_app = timeit(lambda: _lib.call("msml_bn_act_bwd_apply", dxc, x, coef[0], coef[1], alpha, coef[2], coef[3],
-                                         part, part.shape[0], None, dxb, pg[0], pg[1], pg[2], 0, m, c, cw, _lib.BF16))
+        if part.dtype == torch.float64:            # accumulator protocol (ops.ACC_STATS): finalize + apply in one launch
+            t_app = timeit(lambda: _lib.call("msml_bn_fin_bwd_apply", dxc, x, coef[0], coef[1], alpha, coef[2], coef[3], part,
+                                             None, None, 0, 0, dxb, None, pg[0], pg[1], pg[2], 0, m, c, None, None, None,
+                                             None, _lib.BF16))
+        else:
+            t_app = timeit(lambda: _lib.call("msml_bn_act_bwd_apply", dxc, x, coef[0], coef[1], alpha, coef[2], coef[3],
+                                             part, part.shape[0], None, dxb, pg[0], pg[1], pg[2], 0, m, c, cw, _lib.BF16))
         print("%4d->%4d @%3d s%d  conv %6.1f us  bn_bwd %6.1f us | fused conv %6.1f us  apply %6.1f us (rows %d) | %6.1f -> %6.1f"
               % (k, c, h, stride, t_conv * 1e6, t_bn * 1e6, t_fconv * 1e6, t_app * 1e6, part.shape[0],
                  (t_conv + t_bn) * 1e6, (t_fconv + t_app) * 1e6))
