@@ -48,6 +48,11 @@ enum { MSML_ARITH_ADD = 0, MSML_ARITH_SUB = 1, MSML_ARITH_MUL = 2, MSML_ARITH_DI
 
 int msml_version(void);
 const char* msml_last_error(void);
+/* Id of the graph capture `stream` is currently part of (hipStreamGetCaptureInfo; every stream forked into
+ * one capture reports the same id), 0 when the stream is not capturing, negative on a HIP error.  The host
+ * side keys per-capture scratch state on it (zeroed accumulator chunks: a second capture must not inherit the
+ * first one's slices, whose zero fill only the first graph replays). */
+long msml_stream_capture_id(void* stream);
 
 /* ---------------------------------------------------------------- layout (boundary) ------
  * The reference keeps NCHW f32 tensors end to end (backbones/msml.py:150); the HIP path

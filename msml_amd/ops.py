@@ -148,23 +148,25 @@ class _AccArena:
     """Zeroed f64 accumulators cut from chunks (one torch.zeros launch per ~250 BatchNorm uses instead of one per
     use).  A chunk belongs to the stream that was current when it was created (its zero fill is ordered on that
     stream; producer and consumer of an accumulator always share a stream) and to eager execution or to ONE graph
-    capture: a capture gets a chunk of its own, so that the captured fill re-zeroes exactly the slices the replay
-    uses (a capture is told from the previous one by the eager uses in between -- PyTorch's required warm-up)."""
+    capture, identified by the capture id of the stream (msml_stream_capture_id): a capture always opens chunks of
+    its own, so that the fill it captures re-zeroes exactly the slices its replay uses -- also when two captures
+    follow each other with no eager step in between (the second graph otherwise kept cutting slices
+    from the first graph's chunk, whose fill only the first graph replays)."""
     CHUNK = 1 << 20            # doubles
 
     def __init__(self):
         self.chunks = {}
-        self.eager_uses = 0
 
     def get(self, c, device, nq=2):
         n = ACC_ROWS * nq * c
-        cap = torch.cuda.is_current_stream_capturing()
-        if not cap:
-            self.eager_uses += 1
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream, cap)
+        raw = _lib.raw_stream()
+        cap = _lib.value("msml_stream_capture_id", raw) if torch.cuda.is_current_stream_capturing() else 0
+        if cap < 0:
+            raise RuntimeError("msml_stream_capture_id failed: %s" % _lib.load().msml_last_error().decode())
+        key = (device.index, raw, cap != 0)
         ent = self.chunks.get(key)
-        if ent is None or ent[1] + n > ent[0].numel() or (cap and ent[2] != self.eager_uses):
-            ent = [torch.zeros(max(self.CHUNK, n), dtype=torch.float64, device=device), 0, self.eager_uses]
+        if ent is None or ent[1] + n > ent[0].numel() or ent[2] != cap:
+            ent = [torch.zeros(max(self.CHUNK, n), dtype=torch.float64, device=device), 0, cap]
             self.chunks[key] = ent
         out = ent[0][ent[1]:ent[1] + n].view(ACC_ROWS, nq, c)
         ent[1] += n

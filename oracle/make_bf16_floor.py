@@ -1,0 +1,90 @@
+"""Record the bf16 error FLOOR of the training step: the CPU oracle run under the bf16 rounding model of
+oracle/bf16_emul.py (plain PyTorch, no HIP code) against the f32 reference goldens G4 / G4c.
+
+    python oracle/make_bf16_floor.py            -> tests/golden/bf16_floor.npz
+
+Needs neither the reference nor a GPU (the goldens it compares with were recorded from the reference by
+oracle/make_golden.py).  Keys: "<case>/loss_seg", "<case>/loss_cls", "<case>/gnorm" (relative errors),
+"<case>/grad/<parameter>" (norm-wise relative error of the picked gradient elements, clip factor of the golden
+applied exactly as tests/test_gpu_parity2.py does), "<case>/stat/<buffer>".  The GPU tests derive their tolerances
+from these numbers (2 x the per-group maximum) instead of fitting them to the HIP path's own error.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from msml_amd import synthetic  # noqa: E402
+from oracle import bf16_emul, model as om  # noqa: E402
+from oracle.fill import fill_module  # noqa: E402
+from oracle.inputs import eval_inputs, refinit_frb_convs  # noqa: E402
+from tests.helpers import load, pick, rel_err  # noqa: E402
+
+CASES = [  # (key, golden file, frb, batch, refinit)
+    ("ires18_b4_fill", "g4_train_fill.npz", "iresnet18", 4, False),
+    ("ires18_b4_refinit", "g4_train_refinit.npz", "iresnet18", 4, True),
+    ("ires18_b32", "g4_train_fill_b32.npz", "iresnet18", 32, False),
+    ("ires50_b8", "g4_train_ires50_b8.npz", "iresnet50", 8, False),
+    ("ires50_b32", "g4_train_ires50_b32.npz", "iresnet50", 32, False),
+    ("ires100_b4", "g4_train_ires100_b4.npz", "iresnet100", 4, False),
+    ("ires100_b16", "g4_train_ires100_b16.npz", "iresnet100", 16, False),
+]
+
+
+def emulated_step(frb, bs, refinit, C=1000):
+    torch.manual_seed(0)
+    m = fill_module(om.MSML(frb, "unet", (1, 1, 1, 1), C, fm_params=(3, 2, "sigmoid", "mul"),
+                            header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0)))
+    if refinit:
+        refinit_frb_convs(m)
+    bf16_emul.emulate(m)
+    x, msk = eval_inputs(bs)
+    label = synthetic.labels(bs, C, seed=1)
+    m.train()
+    final_cls, final_seg, _ = m(bf16_emul._r(x), label, None)
+    seg_loss = om.consensus_loss(final_seg, msk)
+    cls_loss = torch.nn.functional.cross_entropy(final_cls, label)
+    (cls_loss + seg_loss).backward()
+    gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+    return m, float(seg_loss), float(cls_loss), gnorm
+
+
+def main():
+    torch.set_num_threads(8)
+    rec = {}
+    for key, fname, frb, bs, refinit in CASES:
+        g = load(fname)
+        m, seg_loss, cls_loss, gnorm = emulated_step(frb, bs, refinit)
+        rec[key + "/loss_seg"] = np.float64(abs(seg_loss / g["seg_loss"] - 1))
+        rec[key + "/loss_cls"] = np.float64(abs(cls_loss / g["cls_loss"] - 1))
+        rec[key + "/gnorm"] = np.float64(abs(gnorm / g["grad_norm"] - 1))
+        params = dict(m.named_parameters())
+        clip = float(5.0 / (g["grad_norm"] + 1e-6))
+        groups = {}
+        for k in g.files:
+            if k.startswith("grad_pick/"):
+                n = k.split("/", 1)[1]
+                if n == "frb.fc.bias":
+                    continue
+                e = rel_err(pick(params[n].grad, g[k].size) * clip, g[k])
+                rec["%s/grad/%s" % (key, n)] = np.float64(e)
+                grp = bf16_emul.param_group(n)
+                groups[grp] = max(groups.get(grp, 0.0), e)
+        sd = m.state_dict()
+        for k in g.files:
+            if k.startswith("stat/"):
+                n = k.split("/", 1)[1]
+                # running statistics after the step: momentum 0.1 of the batch statistics
+                rec["%s/stat/%s" % (key, n)] = np.float64(rel_err(sd[n].numpy(), g[k]))
+        print("%-18s seg %.2e cls %.2e gnorm %.2e | %s" % (key, rec[key + "/loss_seg"], rec[key + "/loss_cls"],
+              rec[key + "/gnorm"], "  ".join("%s %.3f" % kv for kv in sorted(groups.items()))), flush=True)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "bf16_floor.npz"), **rec)
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ Goldens:
   g2c eval ires18 at the sqrt(2/fan_in) fill with calibrated running statistics + f32-vs-f64 gain check
   g4  one full train step ires18 bs=4 (train-mode BN, reference conv init AND key fill)
   g4b the g4 step at batch 32 (gauge of the bf16 training path)
+  g4c the train step of the deep FRBs: ires50 at batch 8 / 32, ires100-variant at batch 4 / 16
   g5  AMArcFace / AMCosFace / Softmax heads incl. -1 labels
   g6  PartialFC.forward_backward under gloo, W in {1,2,4,8}, B=8, C=1003 + one SGD step
   g6s the same with negative sampling (sample_rate 0.3 / 0.005): index, step, update()
@@ -130,7 +131,17 @@ def g2():
     np.savez_compressed(os.path.join(OUT, "g2_ires100_eval.npz"), **eval_record(m, 2))
 
 
-def train_step_record(m, bs, num_classes):
+DEEP_PICKS = {      # extra picked gradients of the deep FRBs: one early / middle / last block per stage
+    "iresnet50": ["frb.layer1.2.conv2.weight", "frb.layer2.3.conv1.weight", "frb.layer3.0.conv2.weight",
+                  "frb.layer3.6.conv1.weight", "frb.layer3.13.conv2.weight", "frb.layer3.13.bn3.weight",
+                  "frb.layer4.2.conv1.weight", "frb.fm_ops.2.res_block.0.conv2.weight"],
+    "iresnet100": ["frb.layer1.2.conv2.weight", "frb.layer2.12.conv1.weight", "frb.layer3.0.conv2.weight",
+                   "frb.layer3.14.conv1.weight", "frb.layer3.29.conv2.weight", "frb.layer3.29.bn3.weight",
+                   "frb.layer4.2.conv1.weight", "frb.fm_ops.2.res_block.0.conv2.weight"],
+}
+
+
+def train_step_record(m, bs, num_classes, extra_names=(), npick=32):
     from tricks.consensus_loss import StructureConsensuLossFunction
     x, msk = eval_inputs(bs)
     label = synthetic.labels(bs, num_classes, seed=1)
@@ -157,12 +168,12 @@ def train_step_record(m, bs, num_classes):
                 "frb.layer3.1.prelu.weight", "frb.fc.weight", "frb.fc.bias",
                 "osb.conv1.weight", "osb.layer4.1.conv2.weight", "osb.gcm1.conv_l1.weight",
                 "osb.gcm5.conv_r2.bias", "osb.deconv1.weight", "osb.deconv5.weight",
-                "osb.layer1.0.bn1.bias", "classification.weight"]
+                "osb.layer1.0.bn1.bias", "classification.weight"] + list(extra_names)
     params = dict(m.named_parameters())
     for n in sd_names:
         g = params[n].grad
         rec["grad_cs/" + n] = checksum(g)
-        rec["grad_pick/" + n] = pick(g, 32)
+        rec["grad_pick/" + n] = pick(g, npick)
     opt.step()
     for n in ("frb.conv1.weight", "osb.deconv5.weight"):
         rec["new_cs/" + n] = checksum(params[n])
@@ -199,6 +210,21 @@ def g4b():
     torch.manual_seed(0)
     m = fill_module(ref_msml("iresnet18", C))
     np.savez_compressed(os.path.join(OUT, "g4_train_fill_b32.npz"), **train_step_record(m, 32, C))
+
+
+def g4c():
+    """The training step of the DEEP FRBs: ires50 (config 3's network,
+    iresnet.py:470-481 -> layers [3,4,14,3]) at batch 8 and batch 32, the ires100-variant [3,13,30,3] (F8,
+    config 4) at batch 4 and batch 16; train-mode BatchNorm, key fill, same recorder as g4 plus one early /
+    middle / last block of every stage among the picked gradients (64 elements each)."""
+    C = 1000
+    for frb, bs in (("iresnet50", 8), ("iresnet50", 32), ("iresnet100", 4), ("iresnet100", 16)):
+        torch.manual_seed(0)
+        m = fill_module(ref_msml(frb, C) if frb != "iresnet100" else ref_msml100(C))
+        rec = train_step_record(m, bs, C, DEEP_PICKS[frb], npick=64)
+        np.savez_compressed(os.path.join(OUT, "g4_train_%s_b%d.npz" % (frb.replace("iresnet", "ires"), bs)), **rec)
+        print("  ", frb, bs, "cls %.5f seg %.5f gnorm %.4f" % (rec["cls_loss"], rec["seg_loss"], rec["grad_norm"]),
+              flush=True)
 
 
 KD_PEER = {"use_ori": True, "use_conv": True, "mask_trans": "conv", "use_decoder": True}

@@ -1,0 +1,242 @@
+"""The training step of the DEEP networks (config 3: ires50, config 4: the ires100-variant) under pytest.
+
+* exact-f32 op graph and the bf16 fused path (one-node blocks, side streams, FlatSGD) against the reference's
+  own training-step goldens G4c (oracle/make_golden.py g4c: train.py:252-277 on iresnet.py:470-481 / the
+  [3,13,30,3] variant), with one early / middle / last block of every stage among the picked gradients;
+* bf16 tolerances are DERIVED: 2 x the error floor that the CPU oracle shows under the bf16 rounding model of
+  oracle/bf16_emul.py (tests/golden/bf16_floor.npz, recorded by oracle/make_bf16_floor.py), per parameter group;
+* one FULL-SIZE step of the headline workload (ires50 + 85 742-id PartialFC, batch 256): bf16 fused path against
+  the exact-f32 HIP path on the same inputs, and hipGraph replay == eager issue.
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from msml_amd import ops, synthetic
+from msml_amd.backbones import MSML
+from msml_amd.optim import FlatSGD
+from msml_amd.tricks.consensus_loss import StructureConsensuLossFunction
+from oracle.bf16_emul import param_group
+from oracle.fill import fill_module
+from oracle.inputs import eval_inputs
+from tests.helpers import assert_cs, load, pick, rel_err
+
+pytestmark = pytest.mark.gpu
+PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
+
+
+def hip_msml(frb, C=1000, fp16=False):
+    torch.manual_seed(0)
+    m = MSML(frb, "unet", (1, 1, 1, 1), C, fp16=fp16, fm_params=(3, 2, "sigmoid", "mul"),
+             header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(PEER_OFF))
+    return fill_module(m).cuda()
+
+
+def bf16_tolerances(case):
+    """{loss, gnorm, stat, <group>: tol} = 2 x the emulated bf16 floor of `case` (absolute minima keep a bound
+    meaningful where the emulated error happens to be tiny)."""
+    fl = load("bf16_floor.npz")
+    groups = {}
+    for k in fl.files:
+        if k.startswith(case + "/grad/"):
+            grp = param_group(k.split("/", 2)[2])
+            groups[grp] = max(groups.get(grp, 0.0), float(fl[k]))
+    stat = max([float(fl[k]) for k in fl.files if k.startswith(case + "/stat/")] + [0.0])
+    tol = {g: 2.0 * v for g, v in groups.items()}
+    tol["loss"] = max(2.0 * max(float(fl[case + "/loss_seg"]), float(fl[case + "/loss_cls"])), 2e-3)
+    tol["gnorm"] = max(2.0 * float(fl[case + "/gnorm"]), 5e-3)
+    tol["stat"] = max(2.0 * stat, 5e-3)
+    return tol
+
+
+def elem_err(a, b):
+    """Element-wise companion of rel_err: the worst single element against the largest reference element."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("frb,bs", [("iresnet50", 8), ("iresnet100", 4)])
+def test_deep_train_step_f32(frb, bs):
+    """Exact-f32 path: losses, grad norm, 26 picked gradients (norm-wise AND element-wise), running statistics."""
+    g = load("g4_train_%s_b%d.npz" % (frb.replace("iresnet", "ires"), bs))
+    m = hip_msml(frb, 1000)
+    x, msk = eval_inputs(bs)
+    label = synthetic.labels(bs, 1000, seed=1)
+    m.train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1 / 512 * bs, momentum=0.9, weight_decay=5e-4)
+    final_cls, final_seg, kd = m(x.cuda(), label.cuda(), None)
+    seg_loss = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")(final_seg, msk.cuda(), msk.cuda())
+    cls_loss = torch.nn.functional.cross_entropy(final_cls, label.cuda())
+    (cls_loss + seg_loss).backward()
+    gnorm = torch.nn.utils.clip_grad_norm_(m.parameters(), 5, 2)
+    assert abs(seg_loss.item() - g["seg_loss"]) < 1e-3 * abs(g["seg_loss"])
+    assert abs(cls_loss.item() - g["cls_loss"]) < 1e-3 * abs(g["cls_loss"])
+    assert abs(float(gnorm) - g["grad_norm"]) < 5e-3 * abs(g["grad_norm"])
+    assert_cs(final_cls, g["final_cls_cs"], 1e-3, "final_cls")
+    params = dict(m.named_parameters())
+    worst, worst_el, n = 0.0, 0.0, 0
+    for key in g.files:
+        if key.startswith("grad_pick/"):
+            name = key.split("/", 1)[1]
+            got = pick(params[name].grad, g[key].size)
+            if name == "frb.fc.bias":           # exact gradient 0 (train-mode BatchNorm1d follows): noise on both sides
+                assert np.abs(got).max() < 1e-5 and np.abs(g[key]).max() < 1e-5
+                continue
+            e, ee = rel_err(got, g[key]), elem_err(got, g[key])
+            worst, worst_el, n = max(worst, e), max(worst_el, ee), n + 1
+            assert e < 1e-2 and ee < 1e-2, (name, e, ee)
+    print("f32 deep train step %s b%d: %d picked gradients, worst norm-wise %.3e, worst element-wise %.3e"
+          % (frb, bs, n, worst, worst_el))
+    assert n >= 25
+    opt.step()
+    for key in g.files:
+        if key.startswith("stat/"):
+            name = key.split("/", 1)[1]
+            assert rel_err(m.state_dict()[name].cpu().numpy(), g[key]) < 1e-3, name
+
+
+@pytest.mark.parametrize("frb,bs", [("iresnet50", 8), ("iresnet50", 32), ("iresnet100", 4), ("iresnet100", 16)])
+def test_deep_train_step_bf16_fused(frb, bs):
+    """The path bench.py times (bf16, one-node blocks, BatchNorm backward sums from the backward-data epilogues,
+    side streams, FlatSGD) on the deep FRBs against the reference golden, at tolerances derived from the
+    emulated bf16 floor."""
+    short = frb.replace("iresnet", "ires")
+    g = load("g4_train_%s_b%d.npz" % (short, bs))
+    tol = bf16_tolerances("%s_b%d" % (short, bs))
+    assert ops.BLOCK_FUNCTION and ops.FUSE_BN_BWD and ops.BOTTLE_FUNCTION
+    m = hip_msml(frb, 1000, fp16=True)
+    x, msk = eval_inputs(bs)
+    label = synthetic.labels(bs, 1000, seed=1)
+    m.train()
+    opt = FlatSGD([{"params": [p for p in m.parameters() if p.requires_grad], "lr": 0.1 / 512 * bs}], 0.9, 5e-4, 5.0)
+    ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
+    hits0 = ops.COUNTERS["bn3_partial_hits"]
+    try:
+        opt.zero_grad()
+        final_cls, final_seg, kd = m(x.cuda(), label.cuda(), None)
+        seg_loss = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")(final_seg, msk.cuda(), msk.cuda())
+        cls_loss = torch.nn.functional.cross_entropy(final_cls, label.cuda())
+        (cls_loss + seg_loss).backward()
+        ops.wgrad_stream_join()
+        grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        opt.step()
+        torch.cuda.synchronize()
+    finally:
+        ops.WGRAD_STREAM = ops.OSB_STREAM = None
+        opt.release()
+    # the chained blocks handed their bn3 sums over: every non-first block of the FRB stages and of the OSB
+    assert ops.COUNTERS["bn3_partial_hits"] - hits0 >= (16 if frb == "iresnet50" else 40)
+    assert abs(seg_loss.item() - g["seg_loss"]) < tol["loss"] * abs(g["seg_loss"])
+    assert abs(cls_loss.item() - g["cls_loss"]) < tol["loss"] * abs(g["cls_loss"])
+    gnorm = float(opt.grad_norm())
+    clip = float(5.0 / (g["grad_norm"] + 1e-6))
+    report, bad = [], []
+    for key in g.files:
+        if key.startswith("grad_pick/"):
+            n = key.split("/", 1)[1]
+            if n == "frb.fc.bias":
+                continue
+            e = rel_err(pick(grads[n], g[key].size) * clip, g[key])
+            t = tol[param_group(n)]
+            report.append((e / t, e, t, n))
+            if e >= t:
+                bad.append((n, e, t))
+    report.sort(reverse=True)
+    print("bf16 fused deep step %s b%d: gnorm %.4f vs %.4f (%.2e, tol %.1e); seg %.5f / %.5f cls %.5f / %.5f (tol %.1e)"
+          % (frb, bs, gnorm, g["grad_norm"], abs(gnorm / g["grad_norm"] - 1), tol["gnorm"], seg_loss.item(),
+             g["seg_loss"], cls_loss.item(), g["cls_loss"], tol["loss"]))
+    for r, e, t, n in report:
+        print("   %-46s rel err %.3e = %.2f x tol (tol %.3f = 2 x emulated floor of %s)" % (n, e, r, t, param_group(n)))
+    assert abs(gnorm - g["grad_norm"]) < tol["gnorm"] * abs(g["grad_norm"]), (gnorm, g["grad_norm"])
+    assert not bad, bad
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("stat/"):
+            n = key.split("/", 1)[1]
+            assert rel_err(sd[n].cpu().numpy(), g[key]) < tol["stat"], (n, rel_err(sd[n].cpu().numpy(), g[key]))
+
+
+def _bench_args(dtype):
+    return argparse.Namespace(frb="iresnet50", batch=256, classes=85742, dtype=dtype, emulate_world=1, data="resident")
+
+
+STAGE_PICKS = ["frb.conv1.weight", "frb.layer1.2.conv2.weight", "frb.layer2.3.conv1.weight",
+               "frb.layer3.6.conv1.weight", "frb.layer3.13.conv2.weight", "frb.layer4.2.conv1.weight",
+               "frb.fm_ops.0.same_conv.weight", "frb.fm_ops.2.res_block.0.conv2.weight", "frb.fc.weight",
+               "osb.conv1.weight", "osb.layer4.1.conv2.weight", "osb.gcm1.conv_l1.weight", "osb.deconv5.weight"]
+
+
+def test_full_size_step_bf16_vs_f32_and_graph_replay():
+    """Config 3 at its full single-GPU size -- ires50-MSML + 85 742-id PartialFC, batch 256, the step of bench.py
+    (train.py:282-318): (1) the bf16 fused path against the exact-f32 HIP path on the same weights and batch
+    (head loss, seg loss, clipped-gradient norm, one picked gradient per stage, the head's dW), bounded by 2 x the
+    emulated bf16 floor of the batch-32 ires50 golden; (2) three hipGraph replays of the bf16 step equal three
+    eager steps."""
+    import bench
+    tol = bf16_tolerances("ires50_b32")
+
+    def run(dtype, steps=1, graph=False, streams=True):
+        torch.manual_seed(0)
+        tr = bench.Trainer(_bench_args(dtype), 0, 0, 1)
+        batch = tr.batches[0]
+        if streams and dtype == "bf16":
+            ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
+        try:
+            losses = []
+            if graph:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        tr.step(batch)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    out = tr.step(batch)
+                for _ in range(steps):
+                    gr.replay()
+                    losses.append((float(out[0]), float(out[1])))
+            else:
+                for _ in range(steps + (2 if steps > 1 else 0)):
+                    lv, sl = tr.step(batch)
+                    losses.append((float(lv), float(sl)))
+                losses = losses[-steps:]
+            torch.cuda.synchronize()
+            names = dict(tr.model.named_parameters())
+            picks = {n: pick(names[n].grad, 256) for n in STAGE_PICKS}
+            picks["pfc.sub_weight"] = pick(tr.pfc.sub_weight.grad, 1024)
+            res = {"losses": losses, "gnorm": float(tr.opt.grad_norm()), "picks": picks,
+                   "w": tr.opt.flat_w.clone(), "hw": pick(tr.opt_pfc.flat_w, 4096)}
+        finally:
+            ops.WGRAD_STREAM = ops.OSB_STREAM = None
+            tr.opt.release()
+            tr.opt_pfc.release()
+        del tr
+        torch.cuda.empty_cache()
+        return res
+
+    f32 = run("f32")
+    b16 = run("bf16")
+    (lv32, sl32), (lv16, sl16) = f32["losses"][0], b16["losses"][0]
+    print("full-size step: head loss f32 %.5f bf16 %.5f | seg loss %.5f / %.5f | gnorm %.4f / %.4f"
+          % (lv32, lv16, sl32, sl16, f32["gnorm"], b16["gnorm"]))
+    assert abs(lv16 - lv32) < tol["loss"] * abs(lv32)
+    assert abs(sl16 - sl32) < tol["loss"] * abs(sl32)
+    assert abs(b16["gnorm"] - f32["gnorm"]) < max(tol["gnorm"], 2e-2) * f32["gnorm"]
+    for n, ref in f32["picks"].items():
+        e = rel_err(b16["picks"][n], ref)
+        t = tol["head"] if n == "pfc.sub_weight" else tol[param_group(n)]
+        print("   %-46s bf16 vs f32 rel err %.3e (tol %.3f)" % (n, e, t))
+        assert e < t, (n, e, t)
+    # (2) graph replay == eager issue, three steps from identical state
+    eg = run("bf16", steps=3)
+    gr = run("bf16", steps=3, graph=True)
+    print("eager losses", eg["losses"], "graph losses", gr["losses"])
+    # both runs took 2 warm-up steps + 3 steps on the same batch: same trajectory
+    for (a, b), (c, d) in zip(eg["losses"], gr["losses"]):
+        assert abs(a - c) <= 1e-4 * abs(a) and abs(b - d) <= 1e-4 * abs(b), (eg["losses"], gr["losses"])
+    assert float((eg["w"] - gr["w"]).abs().max()) <= 1e-5 * float(eg["w"].abs().max())
+    assert rel_err(gr["hw"], eg["hw"]) < 1e-5

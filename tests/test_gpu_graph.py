@@ -43,6 +43,10 @@ def _run(use_graph, steps=3):
         torch.cuda.synchronize()
         losses = []
         if use_graph:
+            if use_graph == "second":                    # a first capture that is never replayed, then -- with no
+                first = torch.cuda.CUDAGraph()           # eager step in between -- the capture that is
+                with torch.cuda.graph(first):
+                    step()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = step()
@@ -70,3 +74,14 @@ def test_graph_replay_walks_the_eager_trajectory():
     assert float((we - wg).abs().max()) <= 1e-6 * float(we.abs().max())
     for n in re_:
         assert torch.allclose(re_[n], rg[n], rtol=1e-5, atol=1e-7), n
+
+
+def test_second_capture_gets_its_own_accumulators():
+    """Two captures back to back: the second graph's BatchNorm accumulators must come from a chunk whose
+    zero fill the SECOND graph replays; cut from the first capture's chunk they would keep the sums of the previous
+    replay and corrupt mean / var from the second replay on."""
+    le, we, _ = _run(False)
+    lg, wg, _ = _run("second")
+    print("eager losses", le, "second-graph losses", lg)
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(le, lg)), (le, lg)
+    assert float((we - wg).abs().max()) <= 1e-6 * float(we.abs().max())

@@ -105,6 +105,37 @@ def test_g4_train_step(variant, bs):
             assert rel_err(m.state_dict()[n].numpy(), g[key]) < 1e-4, n
 
 
+@pytest.mark.parametrize("frb,bs", [("iresnet50", 8), ("iresnet50", 32), ("iresnet100", 4), ("iresnet100", 16)])
+def test_g4c_deep_train_step(frb, bs):
+    """The oracle's training step of the DEEP FRBs (ires50 = config 3's network, the ires100-variant =
+    config 4's) against the reference's own step: losses, grad norm, every picked gradient incl. one early /
+    middle / last block per stage, running statistics (train.py:252-277, iresnet.py:470-481)."""
+    g = load("g4_train_%s_b%d.npz" % (frb.replace("iresnet", "ires"), bs))
+    m = oracle_msml(frb, 1000)
+    m, opt, final_cls, final_seg, seg_loss, cls_loss, total, gnorm = run_train_step(m, bs, 1000)
+    tol = 2e-4
+    assert abs(seg_loss.item() - g["seg_loss"]) < tol * abs(g["seg_loss"])
+    assert abs(cls_loss.item() - g["cls_loss"]) < tol * abs(g["cls_loss"])
+    assert abs(float(gnorm) - g["grad_norm"]) < 1e-3 * abs(g["grad_norm"])
+    assert_cs(final_cls, g["final_cls_cs"], tol, "final_cls")
+    params = dict(m.named_parameters())
+    npicked = 0
+    for key in g.files:
+        if key.startswith("grad_pick/"):
+            n = key.split("/", 1)[1]
+            if n == "frb.fc.bias":          # exact gradient is 0 (train-mode BatchNorm1d follows): noise only
+                continue
+            got = pick(params[n].grad, 64)
+            assert rel_err(got, g[key]) < 5e-3, (n, rel_err(got, g[key]))
+            npicked += 1
+    assert npicked >= 25
+    opt.step()
+    for key in g.files:
+        if key.startswith("stat/"):
+            n = key.split("/", 1)[1]
+            assert rel_err(m.state_dict()[n].numpy(), g[key]) < 1e-4, n
+
+
 def test_g5_heads():
     g = load("g5_heads.npz")
     emb, w, label = head_inputs()
