@@ -154,6 +154,18 @@ int msml_conv_wgrad(const void* u, int up, const void* v, int vp, float* dw, int
                     int stride, int pad_h, int pad_w, int accumulate, void* workspace,
                     long ws_bytes, int dtype, void* stream);
 
+/* Weight gradients of `group` same-shape 3x3 / stride-1 / pad-1 conv layers in ONE launch pair (backbones/frb/
+ * iresnet.py:40-67: consecutive IBasicBlocks of a stage share every dimension).  u / v / dw are HOST arrays of `group`
+ * device pointers (dY, X, dW of each layer); everything else as msml_conv_wgrad.  The split-K slab traffic per layer
+ * falls by the factor `group`.  MSML_ERR_UNSUPPORTED when the strip / halo kernel does not cover the shape.
+ * msml_conv_wgrad_group_max: the largest useful group for a shape (1 = call msml_conv_wgrad instead). */
+int msml_conv_wgrad_group_max(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
+                              int stride, int pad_h, int pad_w);
+int msml_conv_wgrad_group(const void* const* u, const void* const* v, float* const* dw, int group, int up, int vp,
+                          int A, int Breal, int Btot, int boff, int N, int H, int W, int P, int Q, int R, int S,
+                          int stride, int pad_h, int pad_w, int accumulate, void* workspace, long ws_bytes, int dtype,
+                          void* stream);
+
 /* 1 when msml_conv_wgrad (bf16) runs this shape on the narrow-operand kernel (wgrad_n32.hip: both operands
  * 32 stored channels, 4x4 / stride-2 transposed convs of the OSB decoder or 3x3 / stride-1). */
 int msml_conv_wgrad_kernel_is_n32(int up, int vp, int N, int H, int W, int P, int Q, int R, int S, int stride,
@@ -382,6 +394,29 @@ int msml_occ_draw(long seed, long offset, int N, int H, int W, int mode, int lo,
                   void* stream);
 int msml_occ_apply(const unsigned char* src, const int* desc, float* img, long* msk, float* ori, int N, int H,
                    int W, int light, void* stream);
+
+/* Texture occluders of the reference's training mix: RandomGlasses / RandomGlassesList (datasets/augment/rand_occ.py:
+ * 337-428), RandomScarf (:431-517), RandomRealObject (:520-600), selected as datasets/load_dataset.py:72-85,155-163.
+ * The RGBA images come from the CALLER (atlas: every set's entries [num][h0][w0][4] uint8, preloaded from the user's
+ * checkout exactly as the reference's constructors do; nothing ships with this library).
+ *   meta[nsets][16] int32: byte offset of the set in `atlas`, entries, h0, w0, kind (5 glasses, 6 scarf, 7 object),
+ *     wmin, wmax, hmin, hmax (resampled sizes the tables cover), wdir, hdir, 0...;
+ *   dir / rtab: PIL's bicubic resampling coefficients (ImagingResample precompute_coeffs + normalize_coeffs_8bpc,
+ *     22-bit fixed point), built on the host: rtab[dir[wdir + w' - wmin] + x * 10 + {0: first tap, 1: taps, 2..9: k}].
+ * msml_occ_draw_tex: msml_occ_draw plus modes 5 (ms1m mix: uniform over rect, ellipse, polygon, glasses, scarf, object,
+ *   none), 6 (casia mix: none with probability 1/2, else one of the six), 7 / 8 / 9 (glasses / scarf / object only);
+ *   texture descriptors: kind, x, y of the paste, resampled w', h', set (word 13), entry (word 14).
+ * msml_occ_resize: per image of a texture kind, Image.resize((w', h')) of its RGBA entry, bit for bit (RGBA -> RGBa,
+ *   horizontal + vertical fixed-point pass, RGBa -> RGBA) into patch[n][patch_stride] (rows of w' RGBA pixels);
+ *   lds_bytes >= (h0 * w0 + h0 * wmax) * 4 of the largest set.
+ * msml_occ_apply_tex: msml_occ_apply with the paste: glasses replace the face where alpha > 10, scarf / object where
+ *   alpha != 0, the mask is 0 where alpha != 0 (all three), cropped at the image border. */
+int msml_occ_draw_tex(long seed, long offset, int N, int H, int W, int mode, int lo, int hi, int flip,
+                      const int* meta, int nsets, int* desc, void* stream);
+int msml_occ_resize(const unsigned char* atlas, const int* meta, const int* dir, const int* rtab, const int* desc,
+                    unsigned char* patch, long patch_stride, int N, int lds_bytes, void* stream);
+int msml_occ_apply_tex(const unsigned char* src, const int* desc, const unsigned char* patch, long patch_stride,
+                       float* img, long* msk, float* ori, int N, int H, int W, int light, void* stream);
 
 /* Backward-data of the OSB decoder's ConvTranspose2d(36 -> 18, k 4, s 2, p 1) on cat(seg, gcm) (backbones/osb/unet.py:
  * 140-156, autograd of deconv2..5) for BOTH input segments from one pass over dY (bf16):

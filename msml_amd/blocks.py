@@ -155,6 +155,10 @@ def _wgrad(dy, x, cp, xin=None):
             xin[0].record_stream(side)
     if xin is not None:
         ops.conv_wgrad_bnin(dy, x, xin[0], xin[1], dw, cout, cin, cin, 0, accumulate=inplace, stream=side)
+    elif inplace and r == 3 and s == 3 and stride == 1 and ph == 1 and pw == 1:
+        # same-shape layers of consecutive blocks share a launch (ops.conv_wgrad_queued reports the parameter)
+        ops.conv_wgrad_queued(dy, x, dw, cout, cin, cin, 0, side, wparam)
+        return None
     else:
         ops.conv_wgrad(dy, x, dw, cout, cin, cin, 0, r, s, stride, ph, pw, accumulate=inplace, stream=side)
     if inplace:

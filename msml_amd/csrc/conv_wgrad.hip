@@ -222,11 +222,16 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(const WgradArgs p) {
 // loads in flight per wave: the first version kept two, and the kernel is bound by bytes in flight,
 // not by bandwidth), the four lanes are combined through LDS.  Every addition has a fixed place in
 // the tree: deterministic.
-__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dst,
+// (blockIdx.y = layer of a grouped launch: its slabs start at ws + layer * splits * slab, its gradient is dsts.p[layer])
+#define WR_MAXGROUP 8
+struct DwPtrs { float* p[WR_MAXGROUP]; };
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ ws, const DwPtrs dsts,
                                                       int splits, int arows, int taps, int vp, int A,
                                                       int Breal, int Btot, int boff, int accumulate) {
   __shared__ float red[4][64];
   const long slab = (long)arows * taps * vp;
+  ws += (long)blockIdx.y * splits * slab;
+  float* __restrict__ dst = dsts.p[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bblocks = (vp + 63) >> 6;
   const int at = blockIdx.x / bblocks, b = ((blockIdx.x - at * bblocks) << 6) + lane;   // at = a * taps + tap
@@ -263,11 +268,13 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 // dst[a][b0 .. b0 + 63][0 .. taps) leaves as one contiguous stream instead of 4-B elements `taps` floats
 // apart.  256 -> 256 @ 14x14: weight gradient + reduce 97 -> 87 us (the per-tap kernel: 89).
 #define WR_MAXTAPS 49
-__global__ void __launch_bounds__(256) k_wgrad_reduce_rows(const float* __restrict__ ws, float* __restrict__ dst,
+__global__ void __launch_bounds__(256) k_wgrad_reduce_rows(const float* __restrict__ ws, const DwPtrs dsts,
                                                            int splits, int arows, int taps, int vp, int A,
                                                            int Breal, int Btot, int boff, int accumulate) {
   __shared__ float tile[WR_MAXTAPS * 65];
   const long slab = (long)arows * taps * vp;
+  ws += (long)blockIdx.y * splits * slab;
+  float* __restrict__ dst = dsts.p[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bblocks = (vp + 63) >> 6;
   const int a = blockIdx.x / bblocks, b0 = (blockIdx.x - a * bblocks) << 6;
@@ -303,13 +310,21 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce_rows(const float* __restri
 }
 
 // (the choice depends on the layer shape only, so a layer always sums in the same order)
-static void wgrad_reduce_launch(const float* ws, float* dw, int splits, int up, int taps, int vp, int A, int Breal,
-                                int Btot, int boff, int accumulate, hipStream_t st) {
+static void wgrad_reduce_launch_group(const float* ws, float* const* dw, int group, int splits, int up, int taps, int vp,
+                                      int A, int Breal, int Btot, int boff, int accumulate, hipStream_t st) {
+  DwPtrs d;
+  for (int i = 0; i < WR_MAXGROUP; i++) d.p[i] = dw[i < group ? i : 0];
   const int rowblocks = A * ((vp + 63) / 64);
   if (rowblocks >= 512 && taps > 1 && taps <= WR_MAXTAPS)
-    k_wgrad_reduce_rows<<<rowblocks, 256, 0, st>>>(ws, dw, splits, up, taps, vp, A, Breal, Btot, boff, accumulate);
+    k_wgrad_reduce_rows<<<dim3(rowblocks, group), 256, 0, st>>>(ws, d, splits, up, taps, vp, A, Breal, Btot, boff, accumulate);
   else
-    k_wgrad_reduce<<<rowblocks * taps, 256, 0, st>>>(ws, dw, splits, up, taps, vp, A, Breal, Btot, boff, accumulate);
+    k_wgrad_reduce<<<dim3(rowblocks * taps, group), 256, 0, st>>>(ws, d, splits, up, taps, vp, A, Breal, Btot, boff,
+                                                                 accumulate);
+}
+
+static void wgrad_reduce_launch(const float* ws, float* dw, int splits, int up, int taps, int vp, int A, int Breal,
+                                int Btot, int boff, int accumulate, hipStream_t st) {
+  wgrad_reduce_launch_group(ws, &dw, 1, splits, up, taps, vp, A, Breal, Btot, boff, accumulate, st);
 }
 
 bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
@@ -321,6 +336,10 @@ int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W
                            int stride, int pad_h, int pad_w);
 bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
                             int splits, hipStream_t st, const BnIn* xin = nullptr);
+int msml_wgrad_halo_group_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
+                                 int stride, int pad_h, int pad_w, int group);
+bool msml_wgrad_halo_launch_group(const void* const* u, int up, const void* const* v, int vp, float* ws, int N, int H,
+                                  int W, int group, int splits, hipStream_t st, const BnIn* xin);
 
 int msml_fc_wgrad_launch(const void* u, int up, const void* v, int vp, float* dw, int A, int Breal, int Btot, int boff,
                          int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
@@ -482,6 +501,42 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   MSML_LAUNCH_OK("conv_wgrad");
   wgrad_reduce_launch(a.ws, dw, splits, up, taps, vp, A, Breal, Btot, boff, accumulate, st);
   MSML_LAUNCH_OK("conv_wgrad_reduce");
+  return MSML_OK;
+}
+
+// Largest number of same-shape layers msml_conv_wgrad_group accepts for this shape (1: no grouping).
+extern "C" int msml_conv_wgrad_group_max(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R,
+                                         int S, int stride, int pad_h, int pad_w) {
+  int g = 1;
+  while (g * 2 <= WR_MAXGROUP &&
+         msml_wgrad_halo_group_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w, g * 2) >= 2)
+    g *= 2;
+  return msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0 ? g : 1;
+}
+
+// Weight gradients of `group` layers of ONE shape in one launch pair (strip / halo kernel + fixed-order reduce):
+// every layer gets 1 / group of the workgroups, so the split-K slab bytes written and re-read PER LAYER fall by
+// the same factor (256 -> 256 @ 14x14: 75 MB of slabs for a 2.4 MB gradient at group 1).  u / v / dw: host arrays of
+// `group` device pointers.  Results depend on `group` only through the split partition (fixed for a given group).
+extern "C" int msml_conv_wgrad_group(const void* const* u, const void* const* v, float* const* dw, int group, int up,
+                                     int vp, int A, int Breal, int Btot, int boff, int N, int H, int W, int P, int Q,
+                                     int R, int S, int stride, int pad_h, int pad_w, int accumulate, void* workspace,
+                                     long ws_bytes, int dtype, void* stream) {
+  MSML_CHECK(u && v && dw && workspace && group >= 1 && group <= WR_MAXGROUP, MSML_ERR_SHAPE,
+             "conv_wgrad_group: bad arguments (group %d)", group);
+  for (int i = 0; i < group; i++)
+    MSML_CHECK(u[i] && v[i] && dw[i], MSML_ERR_SHAPE, "conv_wgrad_group: null pointer in layer %d", i);
+  MSML_CHECK(dtype == MSML_BF16, MSML_ERR_UNSUPPORTED, "conv_wgrad_group: bf16 only");
+  MSML_CHECK(boff >= 0 && boff + Breal <= Btot, MSML_ERR_SHAPE, "conv_wgrad_group: bad column range");
+  const int per = msml_wgrad_halo_group_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w, group);
+  MSML_CHECK(per > 0, MSML_ERR_UNSUPPORTED, "conv_wgrad_group: shape not covered by the strip / halo kernel");
+  const long need = (long)group * per * up * 9 * vp * (long)sizeof(float);
+  MSML_CHECK(ws_bytes >= need, MSML_ERR_WORKSPACE, "conv_wgrad_group: workspace %ld < %ld bytes", ws_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  msml_wgrad_halo_launch_group(u, up, v, vp, (float*)workspace, N, H, W, group, per, st, nullptr);
+  MSML_LAUNCH_OK("conv_wgrad_group(halo)");
+  wgrad_reduce_launch_group((const float*)workspace, dw, group, per, up, 9, vp, A, Breal, Btot, boff, accumulate, st);
+  MSML_LAUNCH_OK("conv_wgrad_group_reduce");
   return MSML_OK;
 }
 

@@ -9,8 +9,13 @@
 //   random horizontal flip       -> load_dataset.py:119-123
 //   _add_gauss_to_face           -> load_dataset.py:183-201 with _get_gauss :282-339 (Euclidean, radius 128)
 //   Msk2Tenser / Normalize       -> mask 0 = occluded, 1 = clean (load_dataset.py:37); (x - 0.5) / 0.5
-// Facial-mask records (mask_out.rec), glasses / scarf / real-object occluders need the dataset's assets and are
-// not synthesised.
+//   RandomGlasses / RandomGlassesList (rand_occ.py:337-428), RandomScarf (:431-517), RandomRealObject (:520-600):
+//                                   texture occluders pasted from a CALLER-SUPPLIED RGBA atlas (the reference's PNGs are
+//                                   read from the user's checkout at run time, msml_amd/data.py load_occluder_sets);
+//                                   per sample: random entry, random rescale with PIL's bicubic resampling restated
+//                                   bit for bit (premultiplied alpha, two fixed-point passes, coefficient tables built
+//                                   on the host), placement rule of each class, alpha-keyed paste and mask
+// Facial-mask records (mask_out.rec) need the dataset's 3D-mask renders and are not synthesised.
 //
 // Random draws come from a counter-based generator (splitmix64 of seed, image index, draw index): the
 // same (seed, offset) gives the same batch on any launch geometry, and the CPU oracle regenerates it.
@@ -24,10 +29,17 @@
 
 #define OCC_DESC 64      // int32 words per image
 #define OCC_MAXV 24      // polygon vertices (at most 1 + 2 * 10)
-enum { OCC_NONE = 0, OCC_RECT = 1, OCC_ELLIPSE = 2, OCC_BLOCK = 3, OCC_POLY = 4 };
+enum { OCC_NONE = 0, OCC_RECT = 1, OCC_ELLIPSE = 2, OCC_BLOCK = 3, OCC_POLY = 4, OCC_GLASSES = 5, OCC_SCARF = 6, OCC_OBJECT = 7 };
 // desc: 0 kind | 1 x0 / cx | 2 y0 / cy | 3 w / aw | 4 h / ah | 5,6,7 r g b | 8 flip | 9 light cx (f32 bits)
-//       10 light cy (f32 bits) | 11 light scale (f32 bits) | 12 polygon vertex count | 13..15 reserved
-//       16 + 2 v, 17 + 2 v: polygon vertex v (x, y)
+//       10 light cy (f32 bits) | 11 light scale (f32 bits) | 12 polygon vertex count | 13 texture set | 14 texture entry
+//       15 reserved | 16 + 2 v, 17 + 2 v: polygon vertex v (x, y)
+// Texture kinds (5-7): 1, 2 = top-left corner of the paste, 3, 4 = resampled width / height of the occluder.
+// Occluder sets: meta[set][OCC_META] int32 = 0 byte offset of the set in the atlas | 1 entries | 2 h0 | 3 w0 | 4 kind
+//   | 5 wmin | 6 wmax | 7 hmin | 8 hmax (resampled sizes the tables cover) | 9 wdir | 10 hdir: dir[wdir + w' - wmin] is
+//   the offset in rtab of the horizontal table w0 -> w' (w' rows of OCC_RT ints: first tap, taps, 8 fixed-point
+//   coefficients), dir[hdir + h' - hmin] of the vertical one.
+#define OCC_META 16
+#define OCC_RT 10
 
 __host__ __device__ inline unsigned long long occ_mix(unsigned long long z) {
   z += 0x9E3779B97F4A7C15ULL;
@@ -66,8 +78,21 @@ __host__ __device__ inline void occ_sincos(float a, float* s, float* c) {
 
 // mode 0: training mix -- kind uniform over {rect, ellipse, polygon, none}; mode 1: RandomRect only;
 // mode 2: RandomBlock(lo, hi, 'black') (evaluation); mode 3: no occlusion; mode 4: RandomConnectedPolygon only.
+// modes 5-9 need occluder sets: 5 = the reference's ms1m mix (load_dataset.py:155-157: uniform over rect, ellipse,
+// polygon, glasses, scarf, real object, none), 6 = its casia mix (:158-163: none with probability 1/2, else uniform
+// over the six occluders), 7 / 8 / 9 = glasses / scarf / real object only.
+__device__ inline int occ_pick_set(const int* meta, int nsets, int kind, unsigned int u) {
+  int cnt = 0;
+  for (int s = 0; s < nsets; s++) cnt += meta[s * OCC_META + 4] == kind;
+  if (cnt == 0) return -1;
+  int want = occ_randint(u, 0, cnt);                    // RandomGlassesList: uniform over its folders
+  for (int s = 0; s < nsets; s++)
+    if (meta[s * OCC_META + 4] == kind && want-- == 0) return s;
+  return -1;
+}
+
 __global__ void k_occ_draw(unsigned long long seed, unsigned long long offset, int N, int H, int W, int mode, int lo,
-                           int hi, int flip_on, int* __restrict__ desc) {
+                           int hi, int flip_on, const int* __restrict__ meta, int nsets, int* __restrict__ desc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const unsigned long long img = offset + (unsigned long long)i;
@@ -80,6 +105,46 @@ __global__ void k_occ_draw(unsigned long long seed, unsigned long long offset, i
   } else if (mode == 1) kind = OCC_RECT;
   else if (mode == 2) kind = OCC_BLOCK;
   else if (mode == 4) kind = OCC_POLY;
+  else if (mode == 5 || mode == 6) {
+    const int six = mode == 5 ? occ_randint(occ_u32(seed, img, 0), 0, 7)
+                              : (occ_randint(occ_u32(seed, img, 0), 0, 8) >= 4 ? occ_randint(occ_u32(seed, img, 13), 0, 6) : 6);
+    kind = six == 0 ? OCC_RECT : six == 1 ? OCC_ELLIPSE : six == 2 ? OCC_POLY : six == 3 ? OCC_GLASSES
+         : six == 4 ? OCC_SCARF : six == 5 ? OCC_OBJECT : OCC_NONE;
+  } else if (mode >= 7 && mode <= 9) kind = OCC_GLASSES + (mode - 7);
+  if (kind >= OCC_GLASSES) {
+    const int set = occ_pick_set(meta, nsets, kind, occ_u32(seed, img, 1));
+    if (set < 0) kind = OCC_NONE;
+    else {
+      const int* m = meta + set * OCC_META;
+      const float w0 = (float)m[3], h0 = (float)m[2];
+      const float u3 = occ_unif(occ_u32(seed, img, 3)), u4 = occ_unif(occ_u32(seed, img, 4));
+      int ow, oh, x0, y0;
+      if (kind == OCC_GLASSES) {                 // rand_occ.py:371-387
+        const float bw = (float)W * (w0 / 120.0f), bh = (float)H * (h0 / 120.0f);
+        const float lo_s = 1.0f / 1.1f;
+        ow = (int)(bw * (lo_s + (1.1f - lo_s) * u3));
+        oh = (int)(bh * (lo_s + (1.1f - lo_s) * u4));
+        x0 = (int)((0.12f + (float)occ_randint(occ_u32(seed, img, 5), -5, 6) * 0.02f) * (float)W);
+        y0 = (int)((0.3f + (float)occ_randint(occ_u32(seed, img, 6), -5, 6) * 0.01f) * (float)H);
+      } else if (kind == OCC_SCARF) {            // :466-479 (both offsets scale with the image WIDTH)
+        const float lo_s = 1.0f / 1.1f;
+        ow = (int)(w0 * (lo_s + (1.0f - lo_s) * u3));
+        oh = (int)(h0 * (lo_s + (1.0f - lo_s) * u4));
+        x0 = (int)((0.1f + (float)occ_randint(occ_u32(seed, img, 5), -5, 5) * 0.01f) * (float)W);
+        y0 = (int)((0.6f + (float)occ_randint(occ_u32(seed, img, 6), -5, 5) * 0.01f) * (float)W);
+      } else {                                   // :563-575
+        ow = (int)(w0 * (1.0f + (2.0f - 1.0f) * u3));
+        oh = (int)(h0 * (1.0f + (2.0f - 1.0f) * u4));
+        x0 = (int)(((float)occ_randint(occ_u32(seed, img, 5), 15, 51) * 0.01f) * (float)W);
+        y0 = (int)(((float)occ_randint(occ_u32(seed, img, 6), 15, 51) * 0.01f) * (float)H);
+      }
+      ow = ow < m[5] ? m[5] : (ow > m[6] ? m[6] : ow);          // the tables cover [wmin, wmax] x [hmin, hmax]
+      oh = oh < m[7] ? m[7] : (oh > m[8] ? m[8] : oh);
+      d[1] = x0; d[2] = y0; d[3] = ow; d[4] = oh;
+      d[13] = set;
+      d[14] = occ_randint(occ_u32(seed, img, 2), 0, m[1]);
+    }
+  }
   if (kind == OCC_RECT) {                       // rand_occ.py:113-121
     const int pct = occ_randint(occ_u32(seed, img, 1), lo, hi);
     const float ratio = (float)pct * 0.01f;
@@ -173,9 +238,95 @@ __device__ __forceinline__ bool occ_inside(const int* d, int x, int y) {
 
 // One workgroup per image.  src: [N][H][W][3] uint8 (decoded RGB, HWC).  img / ori: [N][3][H][W] f32,
 // msk: [N][H][W] int64.  light != 0: Gaussian light on img (not on ori, load_dataset.py:126-127).
+// PIL's Image.resize of an RGBA image (the call rand_occ.py:375,466,562 makes), bit for bit: RGBA -> premultiplied
+// RGBa (MULDIV255), horizontal then vertical pass with the precomputed 22-bit fixed-point bicubic coefficients
+// (ImagingResample: ss = 1 << 21; ss += pixel * k; clip8(ss >> 22)), u8 intermediate, back to straight alpha
+// (255 * c / a).  An unchanged size is a plain copy (Image.resize returns self.copy()), an unchanged axis skips its
+// pass.  One workgroup per image; only texture kinds do anything.  patch: [N][pstride] bytes, rows of w' RGBA pixels.
+__device__ __forceinline__ unsigned char occ_clip8(int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ void __launch_bounds__(256) k_occ_resize(const unsigned char* __restrict__ atlas, const int* __restrict__ meta,
+                                                    const int* __restrict__ dir, const int* __restrict__ rtab,
+                                                    const int* __restrict__ desc, unsigned char* __restrict__ patch,
+                                                    long pstride) {
+  extern __shared__ unsigned char sm[];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const int* d = desc + n * OCC_DESC;
+  if (d[0] < OCC_GLASSES) return;
+  const int* m = meta + d[13] * OCC_META;
+  const int h0 = m[2], w0 = m[3], ow = d[3], oh = d[4];
+  const unsigned char* e = atlas + (long)m[0] + (long)d[14] * h0 * w0 * 4;
+  unsigned char* out = patch + (long)n * pstride;
+  if (ow == w0 && oh == h0) {
+    for (int i = t; i < h0 * w0 * 4; i += 256) out[i] = e[i];
+    return;
+  }
+  unsigned char* A = sm;                       // [h0][w0][4] premultiplied
+  unsigned char* B = sm + h0 * w0 * 4;         // [h0][ow][4] after the horizontal pass
+  for (int i = t; i < h0 * w0; i += 256) {
+    const unsigned int a = e[i * 4 + 3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const unsigned int tmp = (unsigned int)e[i * 4 + c] * a + 128u;
+      A[i * 4 + c] = (unsigned char)(((tmp >> 8) + tmp) >> 8);
+    }
+    A[i * 4 + 3] = (unsigned char)a;
+  }
+  __syncthreads();
+  const unsigned char* Hsrc = A;
+  if (ow != w0) {
+    const int* tw = rtab + dir[m[9] + ow - m[5]];
+    for (int i = t; i < h0 * ow; i += 256) {
+      const int y = i / ow, xx = i - y * ow;
+      const int* k = tw + xx * OCC_RT;
+      const int xmin = k[0], cnt = k[1];
+      int ss[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+      for (int j = 0; j < cnt; j++) {
+        const unsigned char* px = A + (y * w0 + xmin + j) * 4;
+        const int kk = k[2 + j];
+#pragma unroll
+        for (int c = 0; c < 4; c++) ss[c] += (int)px[c] * kk;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) B[i * 4 + c] = occ_clip8(ss[c] >> 22);
+    }
+    __syncthreads();
+    Hsrc = B;
+  }
+  const int* th = oh != h0 ? rtab + dir[m[10] + oh - m[7]] : nullptr;
+  for (int i = t; i < oh * ow; i += 256) {
+    const int yy = i / ow, xx = i - yy * ow;
+    int v[4];
+    if (th) {
+      const int* k = th + yy * OCC_RT;
+      const int ymin = k[0], cnt = k[1];
+      int ss[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+      for (int j = 0; j < cnt; j++) {
+        const unsigned char* px = Hsrc + ((ymin + j) * ow + xx) * 4;
+        const int kk = k[2 + j];
+#pragma unroll
+        for (int c = 0; c < 4; c++) ss[c] += (int)px[c] * kk;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[c] = occ_clip8(ss[c] >> 22);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[c] = Hsrc[i * 4 + c];
+    }
+    const int a = v[3];
+    if (a != 255 && a != 0) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) v[c] = occ_clip8((255 * v[c]) / a);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) out[i * 4 + c] = (unsigned char)v[c];
+  }
+}
+
 __global__ void __launch_bounds__(256) k_occ_apply(const unsigned char* __restrict__ src, const int* __restrict__ desc,
                                                    float* __restrict__ img, long* __restrict__ msk,
-                                                   float* __restrict__ ori, int H, int W, int light) {
+                                                   float* __restrict__ ori, int H, int W, int light,
+                                                   const unsigned char* __restrict__ patch, long pstride) {
   __shared__ int d[OCC_DESC];
   __shared__ float red[4];
   const int n = blockIdx.x, t = threadIdx.x;
@@ -199,15 +350,30 @@ __global__ void __launch_bounds__(256) k_occ_apply(const unsigned char* __restri
   for (int p = t; p < HW; p += 256) {
     const int y = p / W, x = p - y * W;
     const int sx = flip ? W - 1 - x : x;          // occlude -> flip: tests run in source coordinates
-    const bool in = occ_inside(d, sx, y);
+    bool in = occ_inside(d, sx, y);
     const unsigned char* q = s + ((long)y * W + sx) * 3;
+    // texture kinds: the resampled RGBA occluder at (d[1], d[2]); the paste is cropped at the image border
+    // (rand_occ.py:486-489,582-585).  Pixel: glasses replace where alpha > 10 (:390), scarf / object where alpha != 0
+    // (:495, :591); the mask marks alpha != 0 for all three (:400-401, :504-505, :600-601).
+    const unsigned char* tp = nullptr;
+    bool paste = false;
+    if (d[0] >= OCC_GLASSES) {
+      const int px = sx - d[1], py = y - d[2];
+      if (px >= 0 && px < d[3] && py >= 0 && py < d[4]) {
+        tp = patch + (long)n * pstride + ((long)py * d[3] + px) * 4;
+        in = tp[3] != 0;
+        paste = d[0] == OCC_GLASSES ? tp[3] > 10 : tp[3] != 0;
+      }
+    }
     msk[(long)n * HW + p] = in ? 0 : 1;
     const float l = light ? lightmap(x, y) : 1.f;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       const float clean = (float)q[c] / 255.0f;                       // ToTensor
       if (ori) ori[((long)n * 3 + c) * HW + p] = (clean - 0.5f) / 0.5f;
-      float v = in ? (d[0] == OCC_BLOCK ? 0.f : (float)d[5 + c] / 255.0f) : clean;
+      float v;
+      if (d[0] >= OCC_GLASSES) v = paste ? (float)tp[c] / 255.0f : clean;
+      else v = in ? (d[0] == OCC_BLOCK ? 0.f : (float)d[5 + c] / 255.0f) : clean;
       v *= l;
       o[(long)c * HW + p] = v;
       vmax = fmaxf(vmax, v);
@@ -231,15 +397,51 @@ extern "C" int msml_occ_draw(long seed, long offset, int N, int H, int W, int mo
                              int flip, int* desc, void* stream) {
   MSML_CHECK(desc && N > 0 && H >= 32 && W >= 32 && mode >= 0 && mode <= 4 && lo >= 0 && hi > lo && hi <= 101,
              MSML_ERR_SHAPE, "occ_draw: bad arguments N=%d H=%d W=%d mode=%d lo=%d hi=%d", N, H, W, mode, lo, hi);
-  k_occ_draw<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>((unsigned long long)seed, (unsigned long long)offset, N, H, W, mode, lo, hi, flip, desc);
+  k_occ_draw<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>((unsigned long long)seed, (unsigned long long)offset, N, H, W, mode, lo, hi, flip, nullptr, 0, desc);
   MSML_LAUNCH_OK("occ_draw");
+  return MSML_OK;
+}
+
+extern "C" int msml_occ_draw_tex(long seed, long offset, int N, int H, int W, int mode, int lo, int hi, int flip,
+                                 const int* meta, int nsets, int* desc, void* stream) {
+  MSML_CHECK(desc && N > 0 && H >= 32 && W >= 32 && mode >= 0 && mode <= 9 && lo >= 0 && hi > lo && hi <= 101,
+             MSML_ERR_SHAPE, "occ_draw_tex: bad arguments N=%d H=%d W=%d mode=%d lo=%d hi=%d", N, H, W, mode, lo, hi);
+  MSML_CHECK(mode < 5 || (meta && nsets > 0 && nsets <= 16), MSML_ERR_SHAPE,
+             "occ_draw_tex: modes 5-9 need 1..16 occluder sets (got %d)", nsets);
+  k_occ_draw<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>((unsigned long long)seed, (unsigned long long)offset, N, H, W, mode, lo, hi, flip, meta, nsets, desc);
+  MSML_LAUNCH_OK("occ_draw_tex");
+  return MSML_OK;
+}
+
+extern "C" int msml_occ_resize(const unsigned char* atlas, const int* meta, const int* dir, const int* rtab,
+                               const int* desc, unsigned char* patch, long patch_stride, int N, int lds_bytes,
+                               void* stream) {
+  MSML_CHECK(atlas && meta && dir && rtab && desc && patch && N > 0 && patch_stride > 0 && lds_bytes > 0 &&
+                 lds_bytes <= 160 * 1024, MSML_ERR_SHAPE, "occ_resize: bad arguments");
+  static int attr_lds = 0;
+  if (lds_bytes > attr_lds) {                   // (monotonic; racing callers set the same or a larger value)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_occ_resize), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              lds_bytes);
+    attr_lds = lds_bytes;
+  }
+  k_occ_resize<<<N, 256, lds_bytes, (hipStream_t)stream>>>(atlas, meta, dir, rtab, desc, patch, patch_stride);
+  MSML_LAUNCH_OK("occ_resize");
   return MSML_OK;
 }
 
 extern "C" int msml_occ_apply(const unsigned char* src, const int* desc, float* img, long* msk, float* ori, int N,
                               int H, int W, int light, void* stream) {
   MSML_CHECK(src && desc && img && msk && N > 0 && H > 0 && W > 0, MSML_ERR_SHAPE, "occ_apply: bad arguments");
-  k_occ_apply<<<N, 256, 0, (hipStream_t)stream>>>(src, desc, img, msk, ori, H, W, light);
+  k_occ_apply<<<N, 256, 0, (hipStream_t)stream>>>(src, desc, img, msk, ori, H, W, light, nullptr, 0);
   MSML_LAUNCH_OK("occ_apply");
+  return MSML_OK;
+}
+
+extern "C" int msml_occ_apply_tex(const unsigned char* src, const int* desc, const unsigned char* patch,
+                                  long patch_stride, float* img, long* msk, float* ori, int N, int H, int W, int light,
+                                  void* stream) {
+  MSML_CHECK(src && desc && patch && img && msk && N > 0 && H > 0 && W > 0, MSML_ERR_SHAPE, "occ_apply_tex: bad arguments");
+  k_occ_apply<<<N, 256, 0, (hipStream_t)stream>>>(src, desc, img, msk, ori, H, W, light, patch, patch_stride);
+  MSML_LAUNCH_OK("occ_apply_tex");
   return MSML_OK;
 }

@@ -30,12 +30,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define WH_OOB 0x78000000u
 
+#define WH_MAXGROUP 8
 struct WgradHaloArgs {
-  const unsigned short* u; int up; unsigned int u_bytes;     // dY [N][H][W][up]
-  const unsigned short* v; int vp; unsigned int v_bytes;     // X  [N][H][W][vp]
+  const unsigned short* u[WH_MAXGROUP]; int up; unsigned int u_bytes;     // dY [N][H][W][up], one per grouped layer
+  const unsigned short* v[WH_MAXGROUP]; int vp; unsigned int v_bytes;     // X  [N][H][W][vp]
   int N, H, W, spy, spx;      // strips per image column / row (7 rows x 14 columns each)
   int nstrips, chunk;         // total strips, strips per split
-  float* ws;                  // [split][up][9][vp]
+  int zper;                   // splits per layer: grid.z = layers x zper, z = layer * zper + split
+  int remap;                  // 1: XCD-aware workgroup order (all dW tiles of one z on one XCD's L2)
+  float* ws;                  // [z][up][9][vp]
   BnIn xin;                   // xin.scale != nullptr: X is PReLU(v * scale + shift), applied in LDS (common.h)
 };
 
@@ -50,14 +53,29 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int mp = wave & 1, nh = (wave >> 1) & 1, tg = wave >> 2;   // Cout tile pair, Cin half, tap group
-  const int a0 = blockIdx.x * CO, b0 = blockIdx.y * 64, split = blockIdx.z;
+  // Several layers of one shape share a launch (grid.z = layers x zper): the split-K slab traffic per layer falls
+  // with the number of workgroups a layer gets.  XCD-aware order: hardware deals consecutive workgroups round-robin
+  // to the 8 XCDs; re-numbering them so that the gx * gy dW tiles of one z (same dY / X strips) sit on ONE XCD
+  // makes their operand re-reads L2 hits.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.remap) {
+    const int T = gridDim.x * gridDim.y, total = T * gridDim.z;
+    const int L = bx + gridDim.x * (by + gridDim.y * bz);
+    const int Lp = (L & 7) * (total >> 3) + (L >> 3);
+    const int tile = Lp % T;
+    bz = Lp / T;
+    bx = tile % gridDim.x;
+    by = tile / gridDim.x;
+  }
+  const int layer = __builtin_amdgcn_readfirstlane(bz / p.zper);
+  const int a0 = bx * CO, b0 = by * 64, split = bz - layer * p.zper;
   const int s_begin = split * p.chunk;
   int s_end = s_begin + p.chunk;
   if (s_end > p.nstrips) s_end = p.nstrips;
   const int spi = p.spy * p.spx;
 
-  __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, (int)p.u_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)p.v, 0, (int)p.v_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)p.u[layer], 0, (int)p.u_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)p.v[layer], 0, (int)p.v_bytes, 0x00020000);
 
   // DMA slot of a lane inside a 1-KB block [16 px][64 B]: pixel lane / 4, 16-B chunk lane % 4
   const int lp = lane >> 2, lc = lane & 3;
@@ -214,7 +232,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #ifdef WH_ABLATE_EPI
   if (p.N >= 0) return;
 #endif
-  // slab [split][a][tap][b] (k_wgrad_reduce sums the splits in a fixed order)
+  // slab [z][a][tap][b] (k_wgrad_reduce sums the zper splits of a layer in a fixed order)
   const int h = lane >> 5, c32 = lane & 31;
   const int b = b0 + nh * 32 + c32;
 #pragma unroll
@@ -225,7 +243,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int a = a0 + (mp * NI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        p.ws[(((long)split * p.up + a) * 9 + tap0 + k) * p.vp + b] = acc[i][k][e];
+        p.ws[(((long)bz * p.up + a) * 9 + tap0 + k) * p.vp + b] = acc[i][k][e];
       }
     }
 #endif
@@ -278,23 +296,48 @@ static void wh_launch(const WgradHaloArgs& a, dim3 grid, hipStream_t st) {
   k_wgrad_halo<CO, XF><<<grid, dim3(512), lds, st>>>(a);
 }
 
-bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
-                            int splits, hipStream_t st, const BnIn* xin) {
+// splits per layer when `group` layers of this shape share one launch (0: not covered)
+int msml_wgrad_halo_group_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
+                                 int stride, int pad_h, int pad_w, int group) {
+  const int hs = msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w);
+  if (hs <= 0 || group < 1 || group > WH_MAXGROUP) return 0;
+  const int per = hs / group;
+  return per < 1 ? 0 : per;
+}
+
+// group: number of layers (u[i], v[i]), i < group, of ONE shape; splits = splits per layer; slabs land in
+// ws[(layer * splits + split)][up][9][vp]
+bool msml_wgrad_halo_launch_group(const void* const* u, int up, const void* const* v, int vp, float* ws, int N, int H,
+                                  int W, int group, int splits, hipStream_t st, const BnIn* xin) {
+  static const bool no_remap = getenv("MSML_WGRAD_HALO_NO_REMAP") != nullptr;
   WgradHaloArgs a;
-  a.u = (const unsigned short*)u; a.up = up; a.u_bytes = (unsigned int)((long)N * H * W * up * 2);
-  a.v = (const unsigned short*)v; a.vp = vp; a.v_bytes = (unsigned int)((long)N * H * W * vp * 2);
+  for (int i = 0; i < WH_MAXGROUP; i++) {
+    a.u[i] = (const unsigned short*)u[i < group ? i : 0];
+    a.v[i] = (const unsigned short*)v[i < group ? i : 0];
+  }
+  a.up = up; a.u_bytes = (unsigned int)((long)N * H * W * up * 2);
+  a.vp = vp; a.v_bytes = (unsigned int)((long)N * H * W * vp * 2);
   a.N = N; a.H = H; a.W = W; a.spy = cdiv(H, 7); a.spx = cdiv(W, 14);
   a.nstrips = N * a.spy * a.spx;
   a.chunk = cdiv(a.nstrips, splits);
+  a.zper = splits;
   a.ws = ws;
   a.xin = BnIn{nullptr, nullptr, nullptr};
   if (xin) a.xin = *xin;
+  const int gz = group * splits;
+  const int tiles = (wh_wide(up) ? up / 128 : up / 64) * (vp / 64);
+  a.remap = (!no_remap && tiles >= 4 && gz % 8 == 0) ? 1 : 0;
   if (wh_wide(up)) {
-    if (xin) wh_launch<128, true>(a, dim3(up / 128, vp / 64, splits), st);
-    else wh_launch<128, false>(a, dim3(up / 128, vp / 64, splits), st);
+    if (xin) wh_launch<128, true>(a, dim3(up / 128, vp / 64, gz), st);
+    else wh_launch<128, false>(a, dim3(up / 128, vp / 64, gz), st);
   } else {
-    if (xin) wh_launch<64, true>(a, dim3(up / 64, vp / 64, splits), st);
-    else wh_launch<64, false>(a, dim3(up / 64, vp / 64, splits), st);
+    if (xin) wh_launch<64, true>(a, dim3(up / 64, vp / 64, gz), st);
+    else wh_launch<64, false>(a, dim3(up / 64, vp / 64, gz), st);
   }
   return true;
+}
+
+bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
+                            int splits, hipStream_t st, const BnIn* xin) {
+  return msml_wgrad_halo_launch_group(&u, up, &v, vp, ws, N, H, W, 1, splits, st, xin);
 }

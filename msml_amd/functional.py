@@ -544,7 +544,10 @@ class _FlatFc(torch.autograd.Function):
         ctx.save_for_backward(x, weight, bias)
         ctx.grad_param = grad_param
         ctx.wp = wp
-        return y.to(x.dtype).reshape(n, 1, 1, e)
+        # The embedding tail stays f32 in every mode: the GEMM accumulates in f32 anyway, and BatchNorm1d
+        # (`features`, iresnet.py:232) subtracts the batch mean -- a bf16 rounding of its INPUT is amplified
+        # by |y| / |y - mean| (measured: 2.2 x the emulated bf16 floor on the fc gradient at batch 4).
+        return y.contiguous().reshape(n, 1, 1, e)
 
     @staticmethod
     def backward(ctx, dy):
@@ -552,7 +555,7 @@ class _FlatFc(torch.autograd.Function):
         n, h, w, c = x.shape
         e = weight.shape[0]
         dtype = DTYPE_OF[x.dtype]
-        dy = dy.contiguous()
+        dy = dy.contiguous().to(x.dtype)         # the MFMA operand of the two backward GEMMs (f32 tail -> bf16)
         k = h * w * c
         dx = None
         if ctx.needs_input_grad[0]:

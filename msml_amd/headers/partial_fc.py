@@ -164,6 +164,7 @@ class PartialFC(Module):
         else:
             self.sub_weight = Parameter(torch.empty((0, 0), device=self.device))
             self.sub_weight_mom = None
+        self._k = None                # sampled mode on a flat-arena optimizer: rows of sub_weight in use this step
         if backend is None:
             from .._lib import BF16, F32
             backend = HipBackend(BF16 if fp16 else F32)
@@ -191,7 +192,16 @@ class PartialFC(Module):
         weight / weight_mom / sub_weight_mom at the arena views and seed the arena momentum from
         the (possibly resumed) momentum, so that save_params() and resume see the trained state."""
         if not self.full:
-            raise NotImplementedError("flat-arena optimizer with negative sampling: use torch.optim.SGD")
+            # negative sampling (partial_fc.py:82-94,101-116 swaps the optimizer's parameter and momentum buffer for
+            # the sampled rows every step): here the optimizer keeps ONE fixed-capacity parameter in its arenas
+            # (flat_parameter()), sample() gathers the sampled rows and their momentum into the arena views and
+            # update() scatters them back -- no re-registration, no host sync on the static branch
+            if tuple(self.sub_weight.shape) != (self.flat_capacity(), self.embedding_size):
+                raise ValueError("negative sampling on a flat-arena optimizer: build it over pfc.flat_parameter()")
+            self._flat_mom = opt.momentum_view(self.sub_weight)
+            opt.steps = max(opt.steps, 1)          # the gathered momentum is never a "first step" buffer
+            self._flat = opt
+            return
         mview = opt.momentum_view(self.sub_weight)
         mview.copy_(self.weight_mom)
         if self.weight_mom.abs().sum().item() != 0:
@@ -199,6 +209,28 @@ class PartialFC(Module):
         self.weight = self.sub_weight.data
         self.weight_mom = self.sub_weight_mom = mview
         self._flat = opt
+
+    def flat_capacity(self):
+        """Rows a flat-arena optimizer must hold in sampled mode: num_sample, or the number of positives a batch can
+        bring when that is larger (the reference then keeps exactly the positives, partial_fc.py:89-90)."""
+        return max(self.num_sample, min(self.batch_size * self.world_size, self.num_local))
+
+    def flat_parameter(self):
+        """Sampled mode on the fast optimizer: the fixed-capacity parameter to build FlatSGD over
+        (`FlatSGD([{'params': [pfc.flat_parameter()], ...}])`, then `pfc.adopt_flat_optimizer(opt)`); it becomes
+        `pfc.sub_weight`, whose first len(index) rows are the sampled classes of the current step."""
+        if self.full:
+            return self.sub_weight
+        self.sub_weight = Parameter(torch.zeros((self.flat_capacity(), self.embedding_size), device=self.device))
+        return self.sub_weight
+
+    def _active(self):
+        """(weight, grad) of the classes in use this step: the whole parameter, or the first k rows of the
+        fixed-capacity arena parameter in sampled + flat mode."""
+        w = self.sub_weight
+        if self._flat is None or self.full or self._k is None or self._k == w.shape[0]:
+            return w, w.grad
+        return w.data[:self._k], (w.grad[:self._k] if w.grad is not None else None)
 
     # ---- label mapping / negative sampling ------------------------------------------------------
     @torch.no_grad()
@@ -233,6 +265,13 @@ class PartialFC(Module):
         self.index = index
         mapped = torch.searchsorted(index, local.clamp_min(0))
         total_label.copy_(torch.where(index_positive, mapped, torch.full_like(total_label, -1)))
+        if self._flat is not None:
+            # fast optimizer: gather the rows and their momentum into the arena views of the fixed parameter
+            k = self._k = int(index.shape[0])      # static on the first branch; the second one already synchronised
+            torch.index_select(self.weight, 0, index, out=self.sub_weight.data[:k])
+            torch.index_select(self.weight_mom, 0, index, out=self._flat_mom[:k])
+            self.sub_weight_mom = self._flat_mom[:k]
+            return
         self.sub_weight = Parameter(self.weight[index])
         self.sub_weight_mom = self.weight_mom[index]
 
@@ -240,6 +279,10 @@ class PartialFC(Module):
     def update(self):
         """Write the sampled rows back (partial_fc.py:101-104); nothing to do at sample_rate 1."""
         if self.full or self.index is None:
+            return 0
+        if self._flat is not None:
+            self.weight_mom.index_copy_(0, self.index, self._flat_mom[:self._k])
+            self.weight.index_copy_(0, self.index, self.sub_weight.data[:self._k])
             return 0
         self.weight_mom[self.index] = self.sub_weight_mom
         self.weight[self.index] = self.sub_weight.data
@@ -304,6 +347,10 @@ class PartialFC(Module):
         self._label_job = (id(label), total, ev, label)
 
     def prepare(self, label, optimizer):
+        if optimizer is not None and self._flat is not optimizer:
+            from ..optim import FlatSGD
+            if isinstance(optimizer, FlatSGD):       # before sample(): it gathers into the optimizer's arenas
+                self.adopt_flat_optimizer(optimizer)
         job, self._label_job = self._label_job, None
         if job is None or job[3].data_ptr() != label.data_ptr():
             self.prefetch_labels(label)
@@ -328,8 +375,8 @@ class PartialFC(Module):
         total_label = self.prepare(label, optimizer)
         total_features = self._all_gather(features.data.float())
         n_total = self.batch_size * self.world_size
-        state, rowmax, rowsum = self.backend.local_stats(total_features, self.sub_weight, total_label,
-                                                         self.margin_softmax)
+        sub_w, g = self._active()
+        state, rowmax, rowsum = self.backend.local_stats(total_features, sub_w, total_label, self.margin_softmax)
         if self._dist():
             # ONE collective for the softmax denominator: gather every rank's (max, sum-exp) pair and
             # combine locally (same value on every rank, fixed summation order r = 0..W-1)
@@ -339,10 +386,9 @@ class PartialFC(Module):
             gsum = (allp[:, :, 1] * torch.exp(allp[:, :, 0] - gmax)).sum(0)
         else:
             gmax, gsum = rowmax, rowsum
-        g = self.sub_weight.grad
-        dw_out = g if (self._flat is not None and g is not None and g.shape == self.sub_weight.shape
+        dw_out = g if (self._flat is not None and g is not None and g.shape == sub_w.shape
                        and g.is_contiguous()) else None       # straight into the flat gradient arena
-        ptarget, dx_total, dw = self.backend.local_grads(state, self.sub_weight, total_label,
+        ptarget, dx_total, dw = self.backend.local_grads(state, sub_w, total_label,
                                                         self.margin_softmax, gmax, gsum, n_total,
                                                         self.eps_ls, dw_out=dw_out)
         if dw_out is None:

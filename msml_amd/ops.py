@@ -414,6 +414,7 @@ def grad_ready(*params):
 
 def wgrad_stream_join():
     """Make the current stream wait for every side stream that may still be writing gradients."""
+    wgrad_flush()
     cur = torch.cuda.current_stream()
     if OSB_STREAM is not None:
         cur.wait_stream(OSB_STREAM)
@@ -448,6 +449,86 @@ def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accum
     call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, p, q, r, s, stride,
          pad_h, pad_w, int(accumulate), ws, ws.numel(), DTYPE_OF[u.dtype], raw)
     return dw
+
+
+# ---- grouped weight gradients -------------------------------------------------------------------------------------
+# Consecutive IBasicBlocks of a stage have identical conv shapes (iresnet.py:164-188), and a weight gradient has no
+# consumer before the optimizer step: up to WGRAD_GROUP of them are collected and issued as ONE launch pair
+# (msml_conv_wgrad_group), which divides the split-K slab traffic per layer by the group size.  Only in-place
+# gradients (FlatSGD arena views) can wait; a shape change, a full group, wgrad_flush() or wgrad_stream_join() issue
+# what is pending.  The group size is a function of the layer sequence only, so results are reproducible.
+WGRAD_GROUP = int(os.environ.get("MSML_WGRAD_GROUP", "4"))
+_GROUP_MAX = {}
+
+
+class _WgradQueue:
+    def __init__(self):
+        self.key = None
+        self.items = []          # (u, v, dw, param)
+        self.stream = None
+        self.limit = 1
+
+
+_WQ = _WgradQueue()
+
+
+def wgrad_flush():
+    """Issue the pending grouped weight gradients (on the stream they were queued for)."""
+    q = _WQ
+    if not q.items:
+        return
+    items, key, stream = q.items, q.key, q.stream
+    q.items, q.key, q.stream = [], None, None
+    up, vp, n, h, w, a, breal, btot, boff, raw = key
+    g = len(items)
+    need = _WGRAD_WS_NEED.get((up, vp, n, h, w, 3, 3))
+    if need is None:
+        need = _WGRAD_WS_NEED[(up, vp, n, h, w, 3, 3)] = _lib.value("msml_conv_wgrad_workspace", up, vp, n, h, w, 3, 3)
+    ws = workspace(need, items[0][0].device, "wgrad", stream)
+    arr = ctypes.c_void_p * g
+    us, vs, dws = arr(*[it[0].data_ptr() for it in items]), arr(*[it[1].data_ptr() for it in items]), \
+        arr(*[it[2].data_ptr() for it in items])
+    if g == 1:
+        u, v, dw = items[0][:3]
+        call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, h, w, 3, 3, 1, 1, 1, 1, ws, ws.numel(),
+             BF16, raw)
+    elif PROFILE.on and stream is None:
+        with PROFILE.rec("wgrad u%d v%d %dx%d k3x3 s1 n%d x%d" % (up, vp, h, w, n, g), 2.0 * n * h * w * a * breal * 9 * g):
+            call("msml_conv_wgrad_group", us, vs, dws, g, up, vp, a, breal, btot, boff, n, h, w, h, w, 3, 3, 1, 1, 1, 1,
+                 ws, ws.numel(), BF16, raw)
+    else:
+        call("msml_conv_wgrad_group", us, vs, dws, g, up, vp, a, breal, btot, boff, n, h, w, h, w, 3, 3, 1, 1, 1, 1,
+             ws, ws.numel(), BF16, raw)
+    for it in items:
+        if it[3] is not None:
+            grad_ready(it[3])
+
+
+def conv_wgrad_queued(u, v, dw, a, breal, btot, boff, stream, param):
+    """3x3 / stride-1 / pad-1 bf16 weight gradient accumulated into `dw` (an arena view): queued for a grouped launch
+    when the shape allows, else issued at once.  `param` is reported through grad_ready() once its kernel is enqueued."""
+    n, p, q, up = u.shape
+    vp = v.shape[3]
+    skey = (up, vp, n, p, q, a, breal, btot, boff)
+    gmax = _GROUP_MAX.get(skey)
+    if gmax is None:
+        gmax = _GROUP_MAX[skey] = min(WGRAD_GROUP, _lib.value("msml_conv_wgrad_group_max", up, vp, a, breal, n, p, q, p, q,
+                                                              3, 3, 1, 1, 1)) if WGRAD_GROUP > 1 else 1
+    if gmax <= 1 or u.dtype != torch.bfloat16:
+        conv_wgrad(u, v, dw, a, breal, btot, boff, 3, 3, 1, 1, 1, accumulate=True, stream=stream)
+        grad_ready(param)
+        return
+    wq = _WQ
+    key = skey + (stream.cuda_stream if stream is not None else _lib.raw_stream(),)
+    if wq.items and wq.key != key:
+        wgrad_flush()
+    if not wq.items:
+        # whatever is still pending when this backward pass ends is issued then (callers may read .grad right after)
+        torch.autograd.Variable._execution_engine.queue_callback(wgrad_flush)
+    wq.key, wq.stream = key, stream
+    wq.items.append((u, v, dw, param))
+    if len(wq.items) >= gmax:
+        wgrad_flush()
 
 
 def gemm_splitk(a, wp, coutp):

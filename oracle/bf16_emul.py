@@ -25,8 +25,19 @@ import torch.nn.functional as F
 from . import model as om
 
 
+GRID_SHIFT = 0.0      # draw selector, see _r
+
+
 def _r(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    """Round to bf16 (nearest-even).  GRID_SHIFT = u != 0 selects another DRAW of the same rounding noise: the
+    quantiser grid is shifted by u ulp (q_u(x) = rne(x + u ulp(x)) - u ulp(x)), which keeps the error distribution
+    (uniform in +-ulp/2) but decorrelates the individual errors from the u = 0 draw.  The floor a test tolerance is
+    derived from is the maximum over a few draws: one draw of a heavy-tailed error (BatchNorm1d over 4 samples in
+    front of the s = 64 head) says little about the next."""
+    if GRID_SHIFT == 0.0:
+        return t.to(torch.bfloat16).to(torch.float32)
+    ulp = torch.exp2(torch.floor(torch.log2(t.abs().clamp_min(1e-30))) - 7.0) * GRID_SHIFT
+    return (t + ulp).to(torch.bfloat16).to(torch.float32) - ulp
 
 
 class _RoundBoth(torch.autograd.Function):

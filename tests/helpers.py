@@ -38,3 +38,29 @@ def assert_cs(t, cs, tol, what=""):
     assert abs(got[1] - cs[1]) <= tol * abs(cs[1]) + 1e-12, (what, got, cs)
     assert abs(got[2] - cs[2]) <= tol * abs(cs[2]) + 1e-12, (what, got, cs)
     assert abs(got[0] - cs[0]) <= tol * abs(cs[1]) + 1e-12, (what, got, cs)
+
+
+def elem_err(a, b):
+    """Element-wise companion of rel_err: the worst single element against the largest reference element."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def bf16_tolerances(case):
+    """Tolerances of a bf16 training-step test, DERIVED from the bf16 error floor of the CPU oracle under the rounding
+    model of oracle/bf16_emul.py (tests/golden/bf16_floor.npz, recorded by oracle/make_bf16_floor.py: maximum over
+    five draws of the rounding noise): {loss, gnorm, stat, osb, head, frb_early, frb_late} = 2 x floor, per parameter
+    group (oracle.bf16_emul.param_group); absolute minima keep a bound meaningful where the emulated error is tiny."""
+    from oracle.bf16_emul import param_group
+    fl = load("bf16_floor.npz")
+    groups = {}
+    for k in fl.files:
+        if k.startswith(case + "/grad/"):
+            grp = param_group(k.split("/", 2)[2])
+            groups[grp] = max(groups.get(grp, 0.0), float(fl[k]))
+    stat = max([float(fl[k]) for k in fl.files if k.startswith(case + "/stat/")] + [0.0])
+    tol = {g: 2.0 * v for g, v in groups.items()}
+    tol["loss"] = max(2.0 * max(float(fl[case + "/loss_seg"]), float(fl[case + "/loss_cls"])), 2e-3)
+    tol["gnorm"] = max(2.0 * float(fl[case + "/gnorm"]), 5e-3)
+    tol["stat"] = max(2.0 * stat, 5e-3)
+    return tol

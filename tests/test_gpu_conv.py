@@ -408,6 +408,55 @@ def test_conv_wgrad_halo(shape, accumulate):
     assert (dw.cpu() - want).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("group", [2, 3, 4, 8])
+@pytest.mark.parametrize("shape", [(16, 256, 256, 14, 14), (12, 128, 128, 28, 28), (6, 64, 64, 56, 56), (9, 128, 64, 21, 28)])
+def test_conv_wgrad_group(shape, group):
+    """msml_conv_wgrad_group: `group` same-shape layers in one launch pair (each layer gets 1 / group of the
+    workgroups, XCD-aware order for the many-tile shapes) -- every layer's gradient against f64 torch, accumulated
+    onto existing values, through the raw entry point and through the host-side queue."""
+    import ctypes
+    n, cin, cout, h, w_ = shape
+    gmax = _lib.value("msml_conv_wgrad_group_max", cout, cin, cout, cin, n, h, w_, h, w_, 3, 3, 1, 1, 1)
+    if group > gmax:
+        pytest.skip("shape groups at most %d layers" % gmax)
+    g = torch.Generator().manual_seed(sum(shape) + group)
+    xs = [torch.randn(n, cin, h, w_, generator=g).bfloat16().float() for _ in range(group)]
+    dys = [torch.randn(n, cout, h, w_, generator=g).bfloat16().float() for _ in range(group)]
+    refs = []
+    for x, dy in zip(xs, dys):
+        w = torch.zeros(cout, cin, 3, 3, dtype=torch.double, requires_grad=True)
+        F.conv2d(x.double(), w, None, 1, 1).backward(dy.double())
+        refs.append(w.grad.float())
+    us = [ops.to_nhwc(dy.cuda(), _lib.BF16) for dy in dys]
+    vs = [ops.to_nhwc(x.cuda(), _lib.BF16) for x in xs]
+    dws = [torch.full((cout, cin, 3, 3), 1.0 + i, device="cuda") for i in range(group)]
+    need = _lib.value("msml_conv_wgrad_workspace", cout, cin, n, h, w_, 3, 3)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    arr = ctypes.c_void_p * group
+    _lib.call("msml_conv_wgrad_group", arr(*[t.data_ptr() for t in us]), arr(*[t.data_ptr() for t in vs]),
+              arr(*[t.data_ptr() for t in dws]), group, cout, cin, cout, cin, cin, 0, n, h, w_, h, w_, 3, 3, 1, 1, 1, 1,
+              ws, ws.numel(), _lib.BF16)
+    for i in range(group):
+        assert (dws[i].cpu() - (refs[i] + 1.0 + i)).abs().max().item() <= 1.5e-2 * refs[i].abs().max().item(), i
+    # the host-side queue: `group` queued layers -> one grouped launch; a shorter tail is issued by wgrad_flush()
+    old = ops.WGRAD_GROUP
+    ops.WGRAD_GROUP, ops._GROUP_MAX = group, {}
+    try:
+        dq = [torch.zeros(cout, cin, 3, 3, device="cuda") for _ in range(group + 1)]
+        # (outside a backward pass there is no engine callback to register: fill the queue directly)
+        for i in range(group):
+            ops._WQ.items.append((us[i], vs[i], dq[i], None))
+        ops._WQ.key = (cout, cin, n, h, w_, cout, cin, cin, 0, _lib.raw_stream())
+        ops._WQ.stream = None
+        ops.wgrad_flush()
+        assert not ops._WQ.items
+        for i in range(group):
+            assert (dq[i].cpu() - refs[i]).abs().max().item() <= 1.5e-2 * refs[i].abs().max().item(), i
+            assert torch.equal(dq[i] + (1.0 + i), dws[i]) or (dq[i] + (1.0 + i) - dws[i]).abs().max().item() <= 1e-5 * refs[i].abs().max().item()
+    finally:
+        ops.WGRAD_GROUP, ops._GROUP_MAX = old, {}
+
+
 # (N, Cin, Cout, H, W): BatchNorm(+PReLU) applied to the conv input inside the halo-tile kernels
 # (msml_conv2d_bnin / msml_conv_wgrad_bnin): must equal msml_bn_act_fwd -> msml_conv2d / msml_conv_wgrad
 # bit for bit (same rounding of the normalised activation, same MFMA order)

@@ -21,7 +21,7 @@ from msml_amd.tricks.consensus_loss import StructureConsensuLossFunction
 from oracle.bf16_emul import param_group
 from oracle.fill import fill_module
 from oracle.inputs import eval_inputs
-from tests.helpers import assert_cs, load, pick, rel_err
+from tests.helpers import assert_cs, bf16_tolerances, elem_err, load, pick, rel_err
 
 pytestmark = pytest.mark.gpu
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
@@ -32,29 +32,6 @@ def hip_msml(frb, C=1000, fp16=False):
     m = MSML(frb, "unet", (1, 1, 1, 1), C, fp16=fp16, fm_params=(3, 2, "sigmoid", "mul"),
              header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(PEER_OFF))
     return fill_module(m).cuda()
-
-
-def bf16_tolerances(case):
-    """{loss, gnorm, stat, <group>: tol} = 2 x the emulated bf16 floor of `case` (absolute minima keep a bound
-    meaningful where the emulated error happens to be tiny)."""
-    fl = load("bf16_floor.npz")
-    groups = {}
-    for k in fl.files:
-        if k.startswith(case + "/grad/"):
-            grp = param_group(k.split("/", 2)[2])
-            groups[grp] = max(groups.get(grp, 0.0), float(fl[k]))
-    stat = max([float(fl[k]) for k in fl.files if k.startswith(case + "/stat/")] + [0.0])
-    tol = {g: 2.0 * v for g, v in groups.items()}
-    tol["loss"] = max(2.0 * max(float(fl[case + "/loss_seg"]), float(fl[case + "/loss_cls"])), 2e-3)
-    tol["gnorm"] = max(2.0 * float(fl[case + "/gnorm"]), 5e-3)
-    tol["stat"] = max(2.0 * stat, 5e-3)
-    return tol
-
-
-def elem_err(a, b):
-    """Element-wise companion of rel_err: the worst single element against the largest reference element."""
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
 @pytest.mark.parametrize("frb,bs", [("iresnet50", 8), ("iresnet100", 4)])

@@ -20,26 +20,21 @@ from msml_amd.tricks.consensus_loss import StructureConsensuLossFunction
 from oracle import model as om
 from oracle.fill import fill_module
 from oracle.inputs import eval_inputs, refinit_frb_convs
-from tests.helpers import assert_cs, load, pick, rel_err
+from oracle.bf16_emul import param_group
+from tests.helpers import assert_cs, bf16_tolerances, load, pick, rel_err
 
 pytestmark = pytest.mark.gpu
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
 
-# Stated tolerances of the bf16 training step (bf16 operands, 8-bit mantissa, f32 accumulation) against the
-# f32 reference golden.  What bf16 costs on THIS problem was measured independently of our kernels by
-# running the CPU oracle with bf16-rounded conv / linear operands in the forward only (plain PyTorch,
-# /tmp experiment recorded in DESIGN.md section 4): batch 4 -- gnorm -5.7 %, early FRB gradients 12-19 %,
-# head 2.3 %, OSB 0.4-1.1 %; batch 32 -- gnorm 0.1 %, early FRB 10-14 %, late FRB 3 %, head 1.3 %, OSB
-# 0.5-0.8 %.  (BatchNorm1d over 4 samples in front of a s=64 ArcFace head amplifies operand rounding: the
-# batch-4 goldens are a conditioning stress test, the batch-32 golden is the gauge.)  The HIP path also
-# rounds the backward operands, hence the factor ~2.5 on the FRB numbers.  At batch 4 the head pick is a draw
-# from that noise, not a constant: two equally valid bf16 roundings of the OSB decoder (im2col kernels vs the
-# tile+halo kernels that replaced them) moved classification.weight between 8e-2 and 1.6e-1 while the
-# batch-32 value stayed at 3.5e-2 -- the batch-4 head bound is set at the FRB noise level for that reason.
-TOL = {          # batch: (loss, gnorm, OSB picks, head picks, FRB picks, running stats)
-    4: (2e-2, 1.5e-1, 3e-2, 2.5e-1, 6e-1, 2e-2),
-    32: (5e-3, 2e-2, 3e-2, 1e-1, 3.5e-1, 1e-2),
-}
+# Tolerances of the bf16 training step against the f32 reference golden are DERIVED, not fitted: the CPU
+# oracle is run under a bf16 rounding model of this path (oracle/bf16_emul.py: every activation and activation gradient
+# stored as bf16, bf16 MFMA operands, f32 parameters / statistics / logits -- plain PyTorch, no HIP code), five draws
+# of the rounding noise, and its error against the same golden is the floor (oracle/make_bf16_floor.py ->
+# tests/golden/bf16_floor.npz); a test bound is 2 x the floor of its parameter group.  What the floor shows: the error is
+# set by the FORWARD roundings of the backbone (an emulation with exact backward operands gives the same numbers), it is
+# 15-30 % on early-FRB gradients whatever the batch, and at batch 4 (BatchNorm1d over FOUR samples in front of a s = 64
+# head) single draws differ by 2-3 x -- the batch-4 goldens are a conditioning stress test, batch 32 is the gauge.
+FLOOR_CASE = {("fill", 4): "ires18_b4_fill", ("refinit", 4): "ires18_b4_refinit", ("fill_b32", 32): "ires18_b32"}
 
 
 def hip_msml(frb, C=1000, fp16=False, fm_layers=(1, 1, 1, 1)):
@@ -61,7 +56,7 @@ def test_train_step_g4_bf16_fused_path(variant, bs):
     m = hip_msml("iresnet18", 1000, fp16=True)
     if variant == "refinit":
         refinit_frb_convs(m)
-    tl, tg, t_osb, t_head, t_frb, t_stat = TOL[bs]
+    tol = bf16_tolerances(FLOOR_CASE[(variant, bs)])
     x, msk = eval_inputs(bs)
     label = synthetic.labels(bs, 1000, seed=1)
     m.train()
@@ -84,8 +79,8 @@ def test_train_step_g4_bf16_fused_path(variant, bs):
         ops.WGRAD_STREAM = ops.OSB_STREAM = None
     # the chained blocks really handed their bn3 sums over (ires18: one hand-off per stage, FRB + OSB)
     assert ops.COUNTERS["bn3_partial_hits"] - hits0 >= 6
-    assert abs(seg_loss.item() - g["seg_loss"]) < tl * abs(g["seg_loss"])
-    assert abs(cls_loss.item() - g["cls_loss"]) < tl * abs(g["cls_loss"])
+    assert abs(seg_loss.item() - g["seg_loss"]) < tol["loss"] * abs(g["seg_loss"])
+    assert abs(cls_loss.item() - g["cls_loss"]) < tol["loss"] * abs(g["cls_loss"])
     gnorm = float(opt.grad_norm())
     report, bad = [], []
     for key in g.files:
@@ -97,23 +92,23 @@ def test_train_step_g4_bf16_fused_path(variant, bs):
             # factor, so that this compares the gradients themselves and gnorm is judged on its own
             got = pick(grads[n], 32) * float(5.0 / (g["grad_norm"] + 1e-6))
             e = rel_err(got, g[key])
-            tol = t_osb if n.startswith("osb.") else (t_head if n in ("frb.fc.weight", "classification.weight") else t_frb)
-            report.append((e, n, tol))
-            if e >= tol:
-                bad.append((n, e, tol))
+            t = tol[param_group(n)]
+            report.append((e, n, t))
+            if e >= t:
+                bad.append((n, e, t))
     report.sort(reverse=True)
     print("bf16 fused train step (%s): gnorm %.4f vs %.4f (%.2e); losses seg %.5f / %.5f cls %.5f / %.5f"
           % (variant, gnorm, g["grad_norm"], abs(gnorm / g["grad_norm"] - 1), seg_loss.item(), g["seg_loss"],
              cls_loss.item(), g["cls_loss"]))
-    for e, n, tol in report:
-        print("   %-50s rel err %.3e (tol %.0e)" % (n, e, tol))
-    assert abs(gnorm - g["grad_norm"]) < tg * abs(g["grad_norm"]), (gnorm, g["grad_norm"])
+    for e, n, t in report:
+        print("   %-50s rel err %.3e (tol %.3f = 2 x emulated floor of %s)" % (n, e, t, param_group(n)))
+    assert abs(gnorm - g["grad_norm"]) < tol["gnorm"] * abs(g["grad_norm"]), (gnorm, g["grad_norm"])
     assert not bad, bad
     sd = m.state_dict()
     for key in g.files:
         if key.startswith("stat/"):
             n = key.split("/", 1)[1]
-            assert rel_err(sd[n].cpu().numpy(), g[key]) < t_stat, n
+            assert rel_err(sd[n].cpu().numpy(), g[key]) < tol["stat"], n
         if key.startswith("new_cs/"):
             assert_cs(sd[key.split("/", 1)[1]], g[key], 1e-2, key)
 
@@ -237,6 +232,81 @@ def test_partial_fc_hip_negative_sampling():
     assert rel_err(pick(wgrad, 256), g[pre + "wgrad_pick"]) < 1e-4
     assert rel_err(pick(p.weight, 512), g[pre + "wnew_pick"]) < 1e-5
     assert rel_err(pick(p.weight_mom, 512), g[pre + "mom_pick"]) < 1e-5
+
+
+def test_partial_fc_hip_negative_sampling_flat_sgd():
+    """Negative sampling on the FAST optimizer (partial_fc.py:82-94,101-116): FlatSGD over the
+    fixed-capacity parameter, sample() gathers the sampled rows + their momentum into the arena views, update()
+    scatters them back.  rate 0.3 against the reference golden G6s (index bit-exact, loss, x_grad, dW, updated rows
+    and momentum); rate 0.005 (fewer samples than positives: the data-dependent branch, :89-90) and a second step
+    against this repo's torch.optim.SGD path, which the CPU tests pin to G6s at W = 2."""
+    from msml_amd.headers import ArcMargin, PartialFC
+    from msml_amd.optim import FlatSGD
+    from oracle.inputs import PFC_B, PFC_C, PFC_E, pfc_inputs
+    g = load("g6s_partial_fc_sampled.npz")
+    feat, label, w = pfc_inputs(1, 0)
+    lr = 0.1 / 512 * PFC_B
+
+    def make(rate, flat):
+        p = PartialFC(0, 0, 1, PFC_B, False, ArcMargin(64.0, 0.48, 0.0, 0.0), PFC_C, sample_rate=rate,
+                      embedding_size=PFC_E)
+        with torch.no_grad():
+            p.weight.copy_(w)
+            gm = torch.Generator().manual_seed(9000)
+            p.weight_mom.copy_(torch.randn(p.weight.shape, generator=gm) * 1e-3)
+        gen = torch.Generator().manual_seed(4321)
+        p.perm_fn = lambda n, device: torch.rand(size=[n], generator=gen).to(device)
+        if flat:
+            opt = FlatSGD([{"params": [p.flat_parameter()], "lr": lr}], 0.9, 5e-4, None)
+            p.adopt_flat_optimizer(opt)
+        else:
+            opt = torch.optim.SGD([{"params": p.parameters()}], lr=lr, momentum=0.9, weight_decay=5e-4)
+        return p, opt
+
+    def steps(p, opt, n):
+        out = []
+        for _ in range(n):
+            opt.zero_grad()
+            x_grad, loss_v = p.forward_backward(label.cuda(), feat.cuda(), opt)
+            _, gact = p._active()
+            wgrad = gact.clone()
+            opt.step()
+            p.update()
+            out.append((x_grad.clone(), float(loss_v), wgrad, p.index.clone()))
+        return out
+
+    # rate 0.3, first step against the reference golden (the golden's draw: torch.manual_seed(4321); torch.rand)
+    p, opt = make(0.3, True)
+    torch.manual_seed(4321)
+    p.perm_fn = lambda n, device: torch.rand(size=[n]).to(device)
+    (x_grad, loss_v, wgrad, index), = steps(p, opt, 1)
+    assert p.sub_weight.grad.data_ptr() == opt.flat_g.data_ptr()          # dW went straight into the arena
+    pre = "w1_rate0.3/r0/"
+    assert np.array_equal(index.cpu().numpy(), g[pre + "index"])
+    assert abs(loss_v - g[pre + "loss"]) < 1e-4 * abs(g[pre + "loss"])
+    assert rel_err(x_grad.cpu().numpy(), g[pre + "x_grad"]) < 1e-4
+    assert rel_err(pick(wgrad, 256), g[pre + "wgrad_pick"]) < 1e-4
+    assert rel_err(pick(p.weight, 512), g[pre + "wnew_pick"]) < 1e-5
+    assert rel_err(pick(p.weight_mom, 512), g[pre + "mom_pick"]) < 1e-5
+    # both branches, three steps each: FlatSGD path == torch.optim.SGD path (same draws)
+    for rate in (0.3, 0.005):
+        pa, oa = make(rate, True)
+        pb, ob = make(rate, False)
+        ra, rb = steps(pa, oa, 3), steps(pb, ob, 3)
+        for (xa, la, wa, ia), (xb, lb, wb, ib) in zip(ra, rb):
+            assert torch.equal(ia, ib)
+            assert abs(la - lb) <= 1e-6 * abs(lb)
+            assert rel_err(xa.cpu().numpy(), xb.cpu().numpy()) < 1e-6
+            assert rel_err(wa.cpu().numpy(), wb.cpu().numpy()) < 1e-6
+        assert rel_err(pa.weight.cpu().numpy(), pb.weight.cpu().numpy()) < 1e-6, rate
+        assert rel_err(pa.weight_mom.cpu().numpy(), pb.weight_mom.cpu().numpy()) < 1e-5, rate
+        if rate == 0.005:
+            assert pa._k is not None and pa._k > pa.num_sample              # kept exactly the positives
+    # checkpoint from the sampled flat state
+    pa.save_params()
+    import os as _os
+    for fn in (pa.weight_name, pa.weight_mom_name):
+        _os.remove(fn)
 
 
 def test_ddp_sgd_gradscaler_step_as_train_py():
