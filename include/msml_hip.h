@@ -103,6 +103,9 @@ int msml_mse_fwd(const void* a, const void* b, long n, double count, float* loss
 int msml_mse_bwd(const void* a, const void* b, const float* g, double count, void* da, void* db, long n,
                  int dtype, void* stream);
 int msml_dropout(const void* x, void* y, long n, float p, long seed, int dtype, void* stream);
+/* the same with the seed read from device memory (seed[0]): a dropout captured into a hipGraph draws a new mask on
+ * every replay once the host side advances the seed tensor inside the graph */
+int msml_dropout_dev(const void* x, void* y, long n, float p, const long* seed, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- convolution -------------
  * Implicit-GEMM convolution on MFMA.  Replaces nn.Conv2d / nn.ConvTranspose2d / nn.Linear
@@ -298,6 +301,16 @@ int msml_sgd_momentum(float* w, const float* grad, float* mom, long n, float lr,
                       int first_step, const float* clip_coef, void* stream);
 int msml_grad_norm_clip(const float* grad, long n, float max_norm, float* out2, float* workspace,
                         long ws_floats, void* stream);
+/* msml_sgd_momentum_dev: msml_sgd_momentum with the learning rate read from DEVICE memory (lr[0]) and the momentum
+ *   buffer always combined (mu * buf + g; a zero buffer gives torch's first step): a step captured into a hipGraph
+ *   follows torch.optim.lr_scheduler.LambdaLR (train.py:193-196) without a re-capture.
+ * msml_grad_norm_clip_scaled: the gradient buffer holds the SUM over W data-parallel ranks (scale = 1 / W): out2[0] =
+ *   norm of the averaged gradient, out2[1] = scale * clip factor -- DistributedDataParallel's division by W
+ *   (train.py:136-138) folded into the one coefficient the SGD kernel applies, no separate pass over the gradients. */
+int msml_sgd_momentum_dev(float* w, const float* grad, float* mom, long n, const float* lr, float mu, float wd,
+                          const float* coef, void* stream);
+int msml_grad_norm_clip_scaled(const float* grad, long n, float max_norm, float scale, float* out2, float* workspace,
+                               long ws_floats, void* stream);
 
 /* Skinny GEMM with a huge K, split over K with deterministic slab reduction: out[M][coutp] (f32)
  * = a[M][K] (bf16, K % 32 == 0) . wp[kop][K]^T.  PartialFC dX = dcos . Wn (K = local classes,
@@ -372,6 +385,9 @@ int msml_x3_to_f32(const void* src, float* dst, long M, int C, void* stream);
  * first threshold index with dist < thr[k] is k (k == nthr: none); every tp / fp / tn / fn of every
  * threshold and fold is a prefix sum of it.  thr: ascending f64 grid (np.arange(0, 4, 0.01 | 0.001)). */
 int msml_pair_sqdist(const float* emb, int n_pairs, int E, double* dist, void* stream);
+/* the same on the f64 sum of the orig + flip embedding passes (verification.py:283,299-300 accumulates both passes
+ * in float64 arrays before normalising) */
+int msml_pair_sqdist_f64(const double* emb, int n_pairs, int E, double* dist, void* stream);
 int msml_pair_hist(const double* dist, const unsigned char* same, int n_pairs, const double* thr, int nthr,
                    int nfolds, int* hist, void* stream);
 

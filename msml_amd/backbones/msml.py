@@ -97,8 +97,12 @@ class MSML(nn.Module):
             # split-bf16 maps hold 6 B per element: a 112 x 112 x 64-channel map of more than ~440 images
             # passes the 2 GiB range of a buffer descriptor.  Images are independent in eval mode, so
             # the batch is processed in chunks (bit-identical results, see the batch-composition test).
-            outs = [self.forward(x[i:i + self.x3_chunk], label, ori) for i in range(0, x.shape[0], self.x3_chunk)]
-            return tuple(torch.cat(t) for t in zip(*outs))
+            def part(t, i):                  # label / ori travel with their images
+                return None if t is None else t[i:i + self.x3_chunk]
+            outs = [self.forward(x[i:i + self.x3_chunk], part(label, i), part(ori, i))
+                    for i in range(0, x.shape[0], self.x3_chunk)]
+            # (use_osb=False returns (feature, None): pass a None output through)
+            return tuple(None if t[0] is None else torch.cat(t) for t in zip(*outs))
         ops.PACKS.refresh_if_stale()      # one batched repack after a FlatSGD step
         ops.DEFER_BN_COUNTERS = True      # num_batches_tracked: one foreach add per forward
         try:

@@ -232,7 +232,8 @@ __device__ __forceinline__ unsigned int drop_hash(unsigned long long seed, unsig
 }
 template <typename T>
 __global__ void __launch_bounds__(256) k_dropout(const T* __restrict__ x, T* __restrict__ y, long n8, float p,
-                                                 unsigned long long seed) {
+                                                 unsigned long long seed, const long* __restrict__ seed_ptr) {
+  if (seed_ptr) seed = (unsigned long long)seed_ptr[0];     // device-resident seed: a graph replay draws a new mask
   const unsigned int thr = (unsigned int)((double)p * 4294967296.0);
   const float scale = 1.f / (1.f - p);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -305,7 +306,15 @@ extern "C" int msml_dropout(const void* x, void* y, long n, float p, long seed, 
   EW_CHECK("dropout");
   MSML_CHECK(p >= 0.f && p < 1.f, MSML_ERR_SHAPE, "dropout: p=%f", p);
   MSML_DISPATCH_DTYPE(dtype, "dropout", (k_dropout<DT>)<<<fm_grid(n / 8), 256, 0, (hipStream_t)stream>>>(
-                                            (const DT*)x, (DT*)y, n / 8, p, (unsigned long long)seed);)
+                                            (const DT*)x, (DT*)y, n / 8, p, (unsigned long long)seed, nullptr);)
   MSML_LAUNCH_OK("dropout");
+  return MSML_OK;
+}
+extern "C" int msml_dropout_dev(const void* x, void* y, long n, float p, const long* seed, int dtype, void* stream) {
+  EW_CHECK("dropout_dev");
+  MSML_CHECK(seed && p >= 0.f && p < 1.f, MSML_ERR_SHAPE, "dropout_dev: p=%f", p);
+  MSML_DISPATCH_DTYPE(dtype, "dropout_dev", (k_dropout<DT>)<<<fm_grid(n / 8), 256, 0, (hipStream_t)stream>>>(
+                                                (const DT*)x, (DT*)y, n / 8, p, 0ULL, seed);)
+  MSML_LAUNCH_OK("dropout_dev");
   return MSML_OK;
 }

@@ -417,10 +417,14 @@ extern "C" int msml_pfc_grad(const float* cosm, int ld, int N, int C, const long
 //   g = grad * coef + wd * w;  buf = first ? g : mu * buf + g;  w -= lr * buf
 // coef (device scalar, optional) is the clip_grad_norm_ factor (train.py:270,275) so that
 // clipping costs no extra pass over the gradients and no host synchronisation.
+// lr_ptr != nullptr: the learning rate is read from device memory (a captured step then follows LambdaLR without
+// a re-capture: the host updates the scalar between replays).
 __global__ void __launch_bounds__(256) k_sgd(float* __restrict__ w, const float* __restrict__ grad,
                                              float* __restrict__ mom, long n4, long n, float lr, float mu,
-                                             float wd, int first, const float* __restrict__ coef_ptr) {
+                                             float wd, int first, const float* __restrict__ coef_ptr,
+                                             const float* __restrict__ lr_ptr) {
   const float coef = coef_ptr ? coef_ptr[0] : 1.f;
+  if (lr_ptr) lr = lr_ptr[0];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 ww = reinterpret_cast<f32x4*>(w)[i];
     f32x4 gg = reinterpret_cast<const f32x4*>(grad)[i];
@@ -455,8 +459,21 @@ extern "C" int msml_sgd_momentum(float* w, const float* grad, float* mom, long n
   long b = (n4 + 255) / 256;
   if (b < 1) b = 1;
   k_sgd<<<(int)(b < 4096 ? b : 4096), 256, 0, (hipStream_t)stream>>>(w, grad, mom, n4, n, lr, mu, wd, first_step,
-                                                                    clip_coef);
+                                                                    clip_coef, nullptr);
   MSML_LAUNCH_OK("sgd_momentum");
+  return MSML_OK;
+}
+
+extern "C" int msml_sgd_momentum_dev(float* w, const float* grad, float* mom, long n, const float* lr, float mu,
+                                     float wd, const float* coef, void* stream) {
+  MSML_CHECK(w && grad && mom && lr && n > 0, MSML_ERR_SHAPE, "sgd_momentum_dev: bad args");
+  MSML_CHECK(((uintptr_t)w & 15) == 0 && ((uintptr_t)grad & 15) == 0 && ((uintptr_t)mom & 15) == 0,
+             MSML_ERR_SHAPE, "sgd_momentum_dev: buffers must be 16-byte aligned");
+  long n4 = n / 4;
+  long b = (n4 + 255) / 256;
+  if (b < 1) b = 1;
+  k_sgd<<<(int)(b < 4096 ? b : 4096), 256, 0, (hipStream_t)stream>>>(w, grad, mom, n4, n, 0.f, mu, wd, 0, coef, lr);
+  MSML_LAUNCH_OK("sgd_momentum_dev");
   return MSML_OK;
 }
 
@@ -491,8 +508,10 @@ __global__ void __launch_bounds__(256) k_sumsq(const float* __restrict__ x, long
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 // one workgroup: thread t sums rows t, t + 256, ... in f64, then a fixed-order tree
+// scale: the gradient buffer holds scale^-1 times the gradient (the SUM over W ranks of a data-parallel job, scale =
+// 1 / W): out[0] = norm of the scaled gradient, out[1] = scale * clip factor -- the one coefficient k_sgd applies.
 __global__ void __launch_bounds__(256) k_norm_finalize(const float* __restrict__ partial, int rows, float max_norm,
-                                                       float* __restrict__ out) {
+                                                       float scale, float* __restrict__ out) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < rows; i += 256) s += (double)partial[i];
@@ -503,10 +522,10 @@ __global__ void __launch_bounds__(256) k_norm_finalize(const float* __restrict__
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    float norm = (float)sqrt(red[0]);
+    float norm = (float)sqrt(red[0]) * scale;
     out[0] = norm;
     float c = max_norm / (norm + 1e-6f);
-    out[1] = c < 1.f ? c : 1.f;
+    out[1] = (c < 1.f ? c : 1.f) * scale;
   }
 }
 
@@ -519,7 +538,19 @@ extern "C" int msml_grad_norm_clip(const float* grad, long n, float max_norm, fl
   MSML_CHECK(ws_floats >= rows, MSML_ERR_WORKSPACE, "grad_norm_clip: workspace too small");
   k_sumsq<<<rows, 256, 0, (hipStream_t)stream>>>(grad, n, workspace);
   MSML_LAUNCH_OK("grad_norm_clip");
-  k_norm_finalize<<<1, 256, 0, (hipStream_t)stream>>>(workspace, rows, max_norm, out2);
+  k_norm_finalize<<<1, 256, 0, (hipStream_t)stream>>>(workspace, rows, max_norm, 1.f, out2);
   MSML_LAUNCH_OK("grad_norm_finalize");
+  return MSML_OK;
+}
+
+extern "C" int msml_grad_norm_clip_scaled(const float* grad, long n, float max_norm, float scale, float* out2,
+                                          float* workspace, long ws_floats, void* stream) {
+  MSML_CHECK(scale > 0.f, MSML_ERR_SHAPE, "grad_norm_clip_scaled: scale %f", scale);
+  int rc = msml_grad_norm_clip(grad, n, max_norm, out2, workspace, ws_floats, stream);   // (its finalize is redone below)
+  if (rc != MSML_OK) return rc;
+  long b = (n + 255) / 256;
+  int rows = (int)(b < 1024 ? b : 1024);
+  k_norm_finalize<<<1, 256, 0, (hipStream_t)stream>>>(workspace, rows, max_norm, scale, out2);
+  MSML_LAUNCH_OK("grad_norm_finalize_scaled");
   return MSML_OK;
 }

@@ -9,13 +9,16 @@
 // emb: [2 * n_pairs][E] f32 (rows 2i, 2i+1 form pair i, verification.py:184-185); dist[i] =
 // sum_j (a_j/|a| - b_j/|b|)^2 in f64 (sklearn.preprocessing.normalize + np.subtract/square/sum, :298-301,78-79).
 // One wave per pair.
-__global__ void __launch_bounds__(256) k_pair_sqdist(const float* __restrict__ emb, int n_pairs, int E,
+// T = float: f32 embeddings; T = double: the f64 sum of the orig + flip passes (verification.py:283,299-300 keeps both
+// passes in float64 arrays and sums / normalises them there).
+template <typename T>
+__global__ void __launch_bounds__(256) k_pair_sqdist(const T* __restrict__ emb, int n_pairs, int E,
                                                      double* __restrict__ dist) {
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= n_pairs) return;
-  const float* a = emb + (long)(2 * pair) * E;
-  const float* b = a + E;
+  const T* a = emb + (long)(2 * pair) * E;
+  const T* b = a + E;
   double sa = 0.0, sb = 0.0;
   for (int j = lane; j < E; j += 64) {
     const double x = a[j], y = b[j];
@@ -64,8 +67,15 @@ __global__ void __launch_bounds__(256) k_pair_hist(const double* __restrict__ di
 
 extern "C" int msml_pair_sqdist(const float* emb, int n_pairs, int E, double* dist, void* stream) {
   MSML_CHECK(emb && dist && n_pairs > 0 && E > 0, MSML_ERR_SHAPE, "pair_sqdist: bad shape n_pairs=%d E=%d", n_pairs, E);
-  k_pair_sqdist<<<cdiv(n_pairs, 4), 256, 0, (hipStream_t)stream>>>(emb, n_pairs, E, dist);
+  k_pair_sqdist<float><<<cdiv(n_pairs, 4), 256, 0, (hipStream_t)stream>>>(emb, n_pairs, E, dist);
   MSML_LAUNCH_OK("pair_sqdist");
+  return MSML_OK;
+}
+
+extern "C" int msml_pair_sqdist_f64(const double* emb, int n_pairs, int E, double* dist, void* stream) {
+  MSML_CHECK(emb && dist && n_pairs > 0 && E > 0, MSML_ERR_SHAPE, "pair_sqdist_f64: bad shape n_pairs=%d E=%d", n_pairs, E);
+  k_pair_sqdist<double><<<cdiv(n_pairs, 4), 256, 0, (hipStream_t)stream>>>(emb, n_pairs, E, dist);
+  MSML_LAUNCH_OK("pair_sqdist_f64");
   return MSML_OK;
 }
 

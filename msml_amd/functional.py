@@ -1016,7 +1016,10 @@ class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, seed):
         y = torch.empty_like(x)
-        call("msml_dropout", x, y, x.numel(), float(p), int(seed), DTYPE_OF[x.dtype])
+        if isinstance(seed, torch.Tensor):       # device-resident seed (graph capture)
+            call("msml_dropout_dev", x, y, x.numel(), float(p), seed, DTYPE_OF[x.dtype])
+        else:
+            call("msml_dropout", x, y, x.numel(), float(p), int(seed), DTYPE_OF[x.dtype])
         ctx.cfg = (p, seed)
         return y
 
@@ -1024,19 +1027,35 @@ class _Dropout(torch.autograd.Function):
     def backward(ctx, g):
         p, seed = ctx.cfg
         dx = torch.empty_like(g)
-        call("msml_dropout", g.contiguous(), dx, g.numel(), float(p), int(seed), DTYPE_OF[g.dtype])
+        if isinstance(seed, torch.Tensor):
+            call("msml_dropout_dev", g.contiguous(), dx, g.numel(), float(p), seed, DTYPE_OF[g.dtype])
+        else:
+            call("msml_dropout", g.contiguous(), dx, g.numel(), float(p), int(seed), DTYPE_OF[g.dtype])
         return dx, None, None
 
 
 _DROP_COUNTER = [0]
+_DROP_STATE = {}
 
 
 def dropout(x, p, seed=None):
     """nn.Dropout(p) in training mode on a storage tensor (iresnet.py:231); the mask comes from a
-    counter-based hash, a fresh seed per call unless one is given."""
+    counter-based hash, a fresh seed per call unless one is given.  Under hipGraph capture a host-side seed would be
+    baked into the graph (every replay the same mask): the seed then lives in a device tensor that the captured
+    sequence itself advances -- copy it for this call's forward / backward, add 1 for the next call or replay."""
     if seed is None:
-        _DROP_COUNTER[0] += 1
-        seed = (torch.initial_seed() * 1000003 + _DROP_COUNTER[0]) & 0x7FFFFFFFFFFFFFFF
+        if torch.cuda.is_current_stream_capturing():
+            st = _DROP_STATE.get(x.device)
+            if st is None:       # (a tensor created inside the capture would be re-initialised by every replay)
+                raise RuntimeError("msml_amd dropout under graph capture: run one eager (warm-up) step first")
+            seed = st.clone()
+            st.add_(1)
+        else:
+            if x.device not in _DROP_STATE:      # the seed tensor captured steps will read and advance
+                _DROP_STATE[x.device] = torch.full((1,), (torch.initial_seed() * 1000003) & 0x3FFFFFFFFFFFFFFF,
+                                                   dtype=torch.int64, device=x.device)
+            _DROP_COUNTER[0] += 1
+            seed = (torch.initial_seed() * 1000003 + _DROP_COUNTER[0]) & 0x7FFFFFFFFFFFFFFF
     return _Dropout.apply(x, p, seed)
 
 

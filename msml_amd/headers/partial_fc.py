@@ -331,12 +331,15 @@ class PartialFC(Module):
 
     def prefetch_labels(self, label):
         """Start the label all-gather + local mapping on the side stream (partial_fc.py:107-110); call it
-        before the backbone forward -- prepare() picks the result up."""
+        before the backbone forward -- prepare() picks the result up when it is handed the SAME tensor object,
+        unmodified (identity + version counter; a label buffer refilled in place, or another tensor that happens to
+        live at the same address, gathers again).  The label must not be written to between the two calls."""
+        given = label
         label = label.to(self.device, torch.long)
         if self.stream is None or not self._dist():
             total = self._all_gather(label)
             self.sample(total)
-            self._label_job = (id(label), total, None, label)
+            self._label_job = ((given, given._version), total, None, label)
             return
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
@@ -344,7 +347,7 @@ class PartialFC(Module):
             self.sample(total)
             ev = self.stream.record_event()
         label.record_stream(self.stream)
-        self._label_job = (id(label), total, ev, label)
+        self._label_job = ((given, given._version), total, ev, label)
 
     def prepare(self, label, optimizer):
         if optimizer is not None and self._flat is not optimizer:
@@ -352,7 +355,7 @@ class PartialFC(Module):
             if isinstance(optimizer, FlatSGD):       # before sample(): it gathers into the optimizer's arenas
                 self.adopt_flat_optimizer(optimizer)
         job, self._label_job = self._label_job, None
-        if job is None or job[3].data_ptr() != label.data_ptr():
+        if job is None or job[0][0] is not label or job[0][1] != label._version:
             self.prefetch_labels(label)
             job, self._label_job = self._label_job, None
         _, total_label, ev, _ = job

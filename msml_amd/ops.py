@@ -415,6 +415,8 @@ def grad_ready(*params):
 def wgrad_stream_join():
     """Make the current stream wait for every side stream that may still be writing gradients."""
     wgrad_flush()
+    if OSB_STREAM is None and WGRAD_STREAM is None:
+        return
     cur = torch.cuda.current_stream()
     if OSB_STREAM is not None:
         cur.wait_stream(OSB_STREAM)

@@ -79,6 +79,12 @@ class FlatSGD:
             p._msml_arena = self
         self.norm_coef = torch.ones(2, dtype=torch.float32, device=dev)
         self.ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        # learning rates live on the device: a step captured into a hipGraph follows set_lr_factor() / LambdaLR
+        self.lr_dev = torch.tensor([g["lr"] for g in self.groups], dtype=torch.float32, device=dev)
+        # flat_g holds grad_scale^-1 times the gradient: the SUM over the ranks after all_reduce_grads(), whose
+        # division by the world size is folded into the clip coefficient (no extra pass over the arena)
+        self.grad_scale = 1.0
+        self.comm_dtype = torch.bfloat16 if __import__("os").environ.get("MSML_GRAD_COMM", "") == "bf16" else None
 
     def momentum_view(self, p):
         """The momentum buffer of parameter `p` as a view into the flat momentum arena."""
@@ -88,6 +94,7 @@ class FlatSGD:
     def set_lr_factor(self, factor):
         for g in self.groups:
             g["lr"] = g["base_lr"] * factor
+        self.lr_dev.copy_(torch.tensor([g["lr"] for g in self.groups], dtype=torch.float32), non_blocking=True)
 
     def release(self):
         """Detach the parameters from the arena protocol (in-place gradients, overlap callbacks): they
@@ -100,7 +107,9 @@ class FlatSGD:
         from . import ops
         if ops.WGRAD_STREAM is not None:     # the side stream must see the zeroed arena
             ops.WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
-        self.train_stream = torch.cuda.current_stream()   # the stream backward kernels are issued on
+        if self.flat_g.is_cuda:
+            self.train_stream = torch.cuda.current_stream()   # the stream backward kernels are issued on
+        self.grad_scale = 1.0
         self.flat_g.zero_()
         base = self.flat_g.data_ptr()
         for p in self.params:        # re-attach the views if something replaced .grad
@@ -135,6 +144,7 @@ class FlatSGD:
         self.pending = [b[2] for b in self.buckets]
         self.fired = [False] * len(self.buckets)
         self.works = []
+        self._half = []
         self.train_stream = torch.cuda.current_stream()     # refreshed by zero_grad()
         for p in self.params:
             p._msml_ready = self._grad_ready
@@ -153,7 +163,24 @@ class FlatSGD:
             if st is not None and st != cur:
                 self.comm.wait_stream(st)
         with torch.cuda.stream(self.comm):
-            self.works.append(dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            self._reduce(self.flat_g[s:e], async_op=True)
+
+    def _reduce(self, buf, async_op=False):
+        """SUM all-reduce of one slice of the gradient arena.  comm_dtype = bfloat16 (MSML_GRAD_COMM=bf16 or
+        `opt.comm_dtype`): the message travels as bf16 -- half the xGMI bytes for one conversion pass each way;
+        the averaged gradient then carries bf16 rounding."""
+        if self.comm_dtype is None:
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=async_op)
+            if async_op:
+                self.works.append(w)
+            return
+        half = buf.to(self.comm_dtype)
+        w = dist.all_reduce(half, op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            self.works.append(w)
+            self._half.append((buf, half))
+        else:
+            buf.copy_(half)
 
     def _grad_ready(self, p):
         bi = self.bucket_of.get(id(p))
@@ -173,9 +200,13 @@ class FlatSGD:
                     self._fire(bi)
             for w in self.works:
                 w.wait()
+            with torch.cuda.stream(self.comm):
+                for buf, half in self._half:          # bf16 messages: back into the f32 arena
+                    buf.copy_(half)
+            self._half = []
             torch.cuda.current_stream().wait_stream(self.comm)
             ops.wgrad_stream_join()
-            self.flat_g.mul_(1.0 / self.ov_world)
+            self.grad_scale = 1.0 / self.ov_world     # applied by step() through the clip coefficient
             self.pending = [b[2] for b in self.buckets]
             self.fired = [False] * len(self.buckets)
             self.works = []
@@ -186,8 +217,8 @@ class FlatSGD:
         n = self.flat_g.numel()
         step = bucket_bytes // 4
         for s in range(0, n, step):
-            dist.all_reduce(self.flat_g[s:min(n, s + step)], op=dist.ReduceOp.SUM)
-        self.flat_g.mul_(1.0 / world_size)
+            self._reduce(self.flat_g[s:min(n, s + step)])
+        self.grad_scale = 1.0 / world_size            # applied by step() through the clip coefficient
 
     def step(self):
         from . import ops
@@ -195,17 +226,24 @@ class FlatSGD:
         n = self.flat_g.numel()
         clip = None
         if self.max_norm is not None:
-            call("msml_grad_norm_clip", self.flat_g, n, float(self.max_norm), self.norm_coef, self.ws,
-                 self.ws.numel())
+            call("msml_grad_norm_clip_scaled", self.flat_g, n, float(self.max_norm), float(self.grad_scale),
+                 self.norm_coef, self.ws, self.ws.numel())
             clip = self.norm_coef[1:]
-        for g in self.groups:
+        elif self.grad_scale != 1.0:
+            if getattr(self, "_scale_set", None) != self.grad_scale:       # constant for the job: filled once
+                self.norm_coef[1] = self.grad_scale
+                self._scale_set = self.grad_scale
+            clip = self.norm_coef[1:]
+        # (a zero momentum buffer makes mu * buf + g the first step of torch.optim.SGD: no first-step flag, nothing
+        # about the step count is baked into a captured graph)
+        for i, g in enumerate(self.groups):
             s, e = g["start"], g["end"]
-            call("msml_sgd_momentum", self.flat_w[s:e], self.flat_g[s:e], self.flat_m[s:e], e - s,
-                 float(g["lr"]), float(self.momentum), float(self.weight_decay),
-                 int(self.steps == 0), clip)
+            call("msml_sgd_momentum_dev", self.flat_w[s:e], self.flat_g[s:e], self.flat_m[s:e], e - s,
+                 self.lr_dev[i:i + 1], float(self.momentum), float(self.weight_decay), clip)
         self.steps += 1
         from . import ops
         ops.WEIGHT_EPOCH += 1        # parameters changed behind torch's version counters
 
     def grad_norm(self):
+        """L2 norm of the (rank-averaged) gradient as seen by the last step()."""
         return self.norm_coef[0]

@@ -37,14 +37,15 @@ def slinear_first_order(x, y, xq):
 
 @torch.no_grad()
 def extract_embeddings(model, x, normalize=False):
-    """(B, E) f32: model(x) + model(flip(x)) (verification.py:269-299); normalize=True adds the L2
-    normalisation of :300 (on device, f32) for callers that only need cosines."""
+    """(B, E) f64: model(x) + model(flip(x)) summed in float64 like the reference, which stores both passes in
+    float64 arrays (verification.py:283,299); normalize=True returns the f32 L2-normalised rows instead (:300, on
+    device) for callers that only need cosines."""
     f1 = model(x)[0]
     f2 = model(x.flip(3))[0]
-    out = (f1 + f2).float()
+    out = f1.double() + f2.double()
     if normalize:
         from . import functional as Fh
-        out = Fh.normalize(out)
+        out = Fh.normalize(out.float())
     return out
 
 
@@ -57,13 +58,14 @@ def pair_cosine(emb):
 
 @torch.no_grad()
 def pair_sqdist(emb):
-    """emb: (2 * n_pairs, E) f32 on the GPU, NOT normalised -> (n_pairs,) f64 squared distances of the
-    L2-normalised rows (sklearn.preprocessing.normalize + np.sum(np.square(diff), 1))."""
-    emb = emb.float().contiguous()
+    """emb: (2 * n_pairs, E) f32 or f64 (extract_embeddings) on the GPU, NOT normalised -> (n_pairs,) f64 squared
+    distances of the L2-normalised rows (sklearn.preprocessing.normalize + np.sum(np.square(diff), 1))."""
+    f64 = emb.dtype == torch.float64
+    emb = emb.contiguous() if f64 else emb.float().contiguous()
     n2, e = emb.shape
     assert n2 % 2 == 0 and emb.is_cuda
     dist = torch.empty(n2 // 2, dtype=torch.float64, device=emb.device)
-    call("msml_pair_sqdist", emb, n2 // 2, e, dist)
+    call("msml_pair_sqdist_f64" if f64 else "msml_pair_sqdist", emb, n2 // 2, e, dist)
     return dist
 
 

@@ -85,3 +85,41 @@ def test_second_capture_gets_its_own_accumulators():
     print("eager losses", le, "second-graph losses", lg)
     assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(le, lg)), (le, lg)
     assert float((we - wg).abs().max()) <= 1e-6 * float(we.abs().max())
+
+
+def test_captured_step_follows_lr_changes_and_redraws_dropout():
+    """a captured step must not bake host-side scalars that change between steps -- the learning rate
+    (LambdaLR.step() -> FlatSGD.set_lr_factor, train.py:193-196) lives in device memory, and a captured dropout
+    (iresnet.py:231) reads a device seed that the graph itself advances: replays draw different masks."""
+    from msml_amd import functional as Fh
+    w = torch.nn.Parameter(torch.ones(1024, device="cuda"))
+    opt = FlatSGD([{"params": [w], "lr": 0.5}], 0.0, 0.0, None)
+    x = torch.ones(8, 1, 1, 512, device="cuda", dtype=torch.bfloat16)
+
+    def step():
+        opt.zero_grad()
+        w.grad.add_(1.0)
+        opt.step()
+        return Fh.dropout(x, 0.5)
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()                                           # eager warm-up: w = 0.5
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = step()
+        g.replay()
+        m1 = y.clone()
+        assert abs(float(w[0]) - 0.0) < 1e-6                 # 0.5 - 0.5 * 1
+        opt.set_lr_factor(0.1)                               # LambdaLR.step() between replays
+        g.replay()
+        m2 = y.clone()
+        assert abs(float(w[0]) + 0.05) < 1e-6                # lr 0.05 now: 0 - 0.05
+        assert not torch.equal(m1, m2)                       # a new mask per replay
+        keep = float((m2 != 0).float().mean())
+        assert 0.4 < keep < 0.6 and set(m2.float().unique().tolist()) <= {0.0, 2.0}
+    finally:
+        opt.release()

@@ -42,6 +42,46 @@ def test_oracle_known_answers():
     assert (v, fa) == (1 / 3, 2 / 3)
 
 
+def test_oracle_against_an_independent_vectorised_restatement():
+    """Second, independently written check of the (execution-unpinned) metric oracle: the same protocol computed a
+    different way -- distances sorted once, confusion counts from np.searchsorted on the sorted same / different
+    distances of every fold (no per-threshold loop, no KFold object, no boolean masks), threshold selection by
+    argmax / interpolation on those counts -- must give the same accuracies, TPR / FPR curves, val and far."""
+    emb, issame = _pairs(1503, 32, 4, 1.2)
+    import sklearn.preprocessing
+    en = sklearn.preprocessing.normalize(emb.astype(np.float64))
+    tpr, fpr, acc, val, val_std, far = ov.evaluate(en, issame, 10)
+    d = ((en[0::2] - en[1::2]) ** 2).sum(1)
+    n, k = len(d), 10
+    edges = np.cumsum([0] + [n // k + (1 if i < n % k else 0) for i in range(k)])
+
+    def counts(idx, thr):
+        ds, dd = np.sort(d[idx][issame[idx]]), np.sort(d[idx][~issame[idx]])
+        return np.searchsorted(ds, thr, "left"), np.searchsorted(dd, thr, "left"), len(ds), len(dd)
+    thr = np.arange(0, 4, 0.01)
+    thr_v = np.arange(0, 4, 0.001)
+    acc2, tprs, fprs, vals, fars = [], [], [], [], []
+    for f in range(k):
+        test = np.arange(edges[f], edges[f + 1])
+        train = np.concatenate((np.arange(0, edges[f]), np.arange(edges[f + 1], n)))
+        tp, fp, ns, nd = counts(train, thr)
+        best = np.argmax((tp + (nd - fp)) / float(len(train)))
+        tp, fp, ns, nd = counts(test, thr)
+        tprs.append(tp / ns)
+        fprs.append(fp / nd)
+        acc2.append((tp[best] + nd - fp[best]) / float(len(test)))
+        _, fpv, _, ndv = counts(train, thr_v)
+        far_train = fpv / ndv
+        t = ov.slinear_first_order(far_train, thr_v, 1e-3) if far_train.max() >= 1e-3 else 0.0
+        tpt, fpt, nst, ndt = counts(test, np.array([t]))
+        vals.append(tpt[0] / nst)
+        fars.append(fpt[0] / ndt)
+    assert np.allclose(acc, acc2, rtol=0, atol=1e-15)
+    assert np.allclose(tpr, np.mean(tprs, 0), atol=1e-15) and np.allclose(fpr, np.mean(fprs, 0), atol=1e-15)
+    assert abs(val - np.mean(vals)) < 1e-15 and abs(far - np.mean(fars)) < 1e-15 and abs(val_std - np.std(vals)) < 1e-15
+    assert 0.6 < np.mean(acc) < 1.0          # a non-trivial operating point
+
+
 def test_oracle_fold_sizes_match_device_rule():
     """KFold(shuffle=False) test folds are contiguous with the first n % k folds one longer -- the rule
     k_pair_hist uses to assign a pair to its fold."""
