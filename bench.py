@@ -29,6 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # MI355X_MICROARCH.md (dense)
+ROUND = "r03"                                     # PMC summaries of OTHER rounds are never quoted (kernels change)
+# forward GFLOP per image (hooks on the imported reference); F_train = 3 x F_fwd (section 3)
+F_FWD_GF = {"iresnet18": 8.446, "iresnet34": 12.146, "iresnet50": 15.845, "iresnet100": 27.406}
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
 
 
@@ -184,10 +187,11 @@ class Inferer:
 
 
 def cpu_baseline(args):
-    """The CPU oracle's training step on a bounded sample (rank 0, N == 1)."""
+    """The CPU oracle's training step on a bounded sample (rank 0, N == 1), protocol of SURVEY section 8d: batch 16,
+    2 warm-up + 5 timed steps, median; the thread count is the best of {all cores, 64, 32} (one step each)."""
     from msml_amd import synthetic
     from oracle import model as om
-    bs = 32
+    bs = 16
     torch.manual_seed(0)
     m = om.MSML(args.frb, "unet", (1, 1, 1, 1), 8, fm_params=(3, 2, "sigmoid", "mul"),
                 header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0))
@@ -202,6 +206,7 @@ def cpu_baseline(args):
     margin = lambda lg, lab: om.margin_logits(lg, lab, "arc", 64.0, 0.48, 0.0, 0.0)  # noqa: E731
 
     def step():
+        t0 = time.time()
         opt.zero_grad()
         seg = m.osb(x)
         feat, _ = m.frb(x, [seg[3], seg[2], seg[1], seg[0]], None)
@@ -214,34 +219,56 @@ def cpu_baseline(args):
         g = dw + 5e-4 * w
         mom.mul_(0.9).add_(g)
         w.sub_(0.1 / 512 * bs * mom)
-    step()
-    t0 = time.time()
-    n = 0
-    while n < 1 or (time.time() - t0 < 20 and n < 5):
-        step()
-        n += 1
-    dt = time.time() - t0
-    return {"value": round(n * bs / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+        return time.time() - t0
+    ncpu = torch.get_num_threads()      # torch's default (physical cores); os.cpu_count() counts SMT siblings, and one
+    # step with 256 threads on this pool's boxes took 399 s (8.3 s with 128) -- never go above the default
+    budget = float(os.environ.get("MSML_CPU_BASELINE_S", "60"))       # wall-clock bound of this leg
+    t_begin = time.time()
+
+    def note(what, dt):                               # progress on stderr: a silent minute looks like a hang
+        print("cpu_baseline: %s %.2f s" % (what, dt), file=sys.stderr, flush=True)
+    note("first step (%d threads)" % torch.get_num_threads(), step())   # allocator / oneDNN primitive caches
+    sweep = {}
+    for c in sorted({c for c in (ncpu, 64, 32, 16) if c <= ncpu}, reverse=True):
+        if sweep and time.time() - t_begin > budget / 2:
+            break
+        torch.set_num_threads(c)
+        sweep[c] = step()
+        note("%d threads" % c, sweep[c])
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    note("warm-up at %d threads" % best, step())      # second warm-up step at the chosen thread count
+    times = []
+    while len(times) < 5 and (len(times) < 2 or time.time() - t_begin + sweep[best] < budget):
+        times.append(step())
+        note("timed step %d" % len(times), times[-1])
+    times.sort()
+    med = times[len(times) // 2]
+    torch.set_num_threads(ncpu)
+    return {"value": round(bs / med, 3), "unit": "images/sec", "cores": best, "host_cores": os.cpu_count(),
             "cpu_model": cpu_model(), "kind": "port",
-            "sample": "%d training steps of the CPU oracle (%s-MSML + %d-id head), batch %d, f32"
-                      % (n, args.frb, args.classes, bs)}
+            "thread_sweep_s_per_step": {str(c): round(t, 2) for c, t in sweep.items()},
+            "sample": "CPU oracle training step (%s-MSML + %d-id head), batch %d, f32: 2 warm-up + %d timed steps "
+                      "(5 unless the %.0f s bound of this leg cut them short), median %.2f s (min %.2f, max %.2f), "
+                      "torch.set_num_threads(%d)"
+                      % (args.frb, args.classes, bs, len(times), budget, med, times[0], times[-1], best)}
 
 
 def pmc_traffic(label):
-    """HBM bytes per launch of `label` from the newest committed PMC summary (profiles/r*_pmc_traffic.json);
-    keys may carry a trailing ' [kernel]' that the event labels of weight gradients do not."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
-        try:
-            pm = json.load(open(path))
-        except Exception:
-            continue
-        for k, v in pm.items():
-            if isinstance(v, dict) and (k == label or k.split(" [")[0] == label.split(" [")[0]) and "hbm_bytes" in v:
-                if k == label or best is None:
-                    best = v["hbm_bytes"]
-    return best
+    """(HBM bytes per launch, source file) of `label` from THIS round's committed PMC summary
+    (profiles/<ROUND>_pmc_traffic.json, written from a rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of the kernels as
+    they are now); (None, None) when the round has no counters for the label -- a summary of an earlier round is never
+    quoted for a kernel that has changed since."""
+    path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % ROUND)
+    try:
+        pm = json.load(open(path))
+    except Exception:
+        return None, None
+    base = label.split(" [")[0]
+    for k, v in pm.items():
+        if isinstance(v, dict) and "hbm_bytes" in v and (k == label or k.split(" [")[0] == base):
+            return v["hbm_bytes"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def memory_table(runner, args):
@@ -418,7 +445,9 @@ def main():
             # RCCL collectives are captured too (verified with a 1-rank communicator); the
             # watchdog thread of ProcessGroupNCCL must not trip the capture -> thread_local mode
             mode = "thread_local" if dist.is_initialized() else "global"
-            if os.environ.get("MSML_GRAPH_STREAMS"):      # experiment: keep the three-stream fork / join
+            # the capture keeps the three-stream fork / join (weight gradients and the OSB on side streams; every
+            # side stream is joined by FlatSGD.step before the capture ends); MSML_GRAPH_SERIAL=1 captures one queue
+            if not os.environ.get("MSML_GRAPH_SERIAL"):
                 eager_mode(True)
             with torch.cuda.graph(graph, capture_error_mode=mode):
                 out = runner.step(static)
@@ -541,6 +570,14 @@ def main():
     }
     if args.mode == "train" and out[0] is not None:
         rec["loss"] = round(float(out[0]), 4)
+    if args.frb in F_FWD_GF and args.dtype in PEAK_TFLOPS:
+        # whole-step fraction of the conv-MFMA roofline: img/s per GPU x F per image / peak
+        f_img = F_FWD_GF[args.frb] * (3.0 if args.mode == "train" else 2.0)       # inference: orig + flip passes
+        rec["roofline_step"] = {"bound": "mfma", "achieved": round(value / world * f_img / 1e3, 2),
+                                "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                "frac": round(value / world * f_img / 1e3 / PEAK_TFLOPS[args.dtype], 4),
+                                "gflop_per_image": round(f_img, 3),
+                                "what": "images/sec per GPU x algorithmic GFLOP per image (F_train = 3 x F_fwd) / dense peak"}
     rec["memory"] = memory_table(runner, args)
     if args.mode == "train" and runner.emu > 1:
         rec["config"]["head"] = ("rank 0 of a %d-way class-parallel %d-id head emulated on one GPU: %d local rows x %d "
@@ -575,9 +612,10 @@ def main():
         top = max(cands, key=lambda n: cands[n]["ms"])
         tv = cands[top]
         tach = tv["flops"] / (tv["ms"] * 1e-3) / 1e12
+        traffic, tsrc = pmc_traffic(top)
         rec["roofline"] = {"bound": "mfma", "kernel": top[top.index("[") + 1:-1] if "[" in top else top.split()[0],
                            "launch": top, "achieved": round(tach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(tach / peak, 4), "traffic": pmc_traffic(top),
+                           "frac": round(tach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                            "algorithmic_flop": tv["flops"] / tv["n"], "launches": tv["n"],
                            "avg_us": round(tv["ms"] * 1e3 / tv["n"], 2)}
         # and the heaviest launch of the OTHER family, so that neither hides behind the other
@@ -590,7 +628,7 @@ def main():
             a2 = v2["flops"] / (v2["ms"] * 1e-3) / 1e12
             rec[famname] = {"launch": t2, "achieved": round(a2, 2), "frac": round(a2 / peak, 4), "unit": "TFLOP/s",
                             "launches": v2["n"], "avg_us": round(v2["ms"] * 1e3 / v2["n"], 2),
-                            "ms_per_step": round(v2["ms"] / prof_steps, 3), "traffic": pmc_traffic(t2)}
+                            "ms_per_step": round(v2["ms"] / prof_steps, 3), "traffic": pmc_traffic(t2)[0]}
         if "conv_wgrad" in fam:
             kw = fam["conv_wgrad"]
             aw = kw["flops"] / (kw["ms"] * 1e-3) / 1e12
