@@ -181,6 +181,35 @@ def _dgrad(dy, cp, h, w, bn_x=None, coef=None, alpha=None):
     return dx, None
 
 
+_UNIT = {}
+
+
+def _dgrad_plus(dy, cp, h, w, other):
+    """dX of a stride-1 conv plus another gradient of the same tensor, summed in the conv epilogue
+    (msml_conv2d_fused with unit scale / zero shift and `other` as its residual) instead of a separate add pass."""
+    wparam, (cout, cin, r, s), stride, ph, pw = cp
+    cinp = cpad(cin)
+    if stride != 1 or other.shape[-1] != cinp:
+        dx, _ = _dgrad(dy, cp, h, w)
+        call("msml_add", dx, other, dx, dx.numel(), BF16)
+        return dx
+    wp = ops.PACKS.get(wparam, True, 0, cout, 0, cin, cout, 0, BF16)
+    key = (cinp, dy.device)
+    unit = _UNIT.get(key)
+    if unit is None:
+        unit = _UNIT[key] = (torch.ones(cinp, dtype=torch.float32, device=dy.device),
+                             torch.zeros(cinp, dtype=torch.float32, device=dy.device))
+    n, p, q, c0p = dy.shape
+    out = torch.empty(n, h, w, cinp, dtype=torch.bfloat16, device=dy.device)
+    name = "conv_igemm"
+    if ops.PROFILE.on:
+        name = ops.conv_label("T+add", c0p, 0, cinp, n, p, q, h, w, r, s, stride, ph, pw, 1, BF16, BF16, False)
+    with ops.PROFILE.rec(name, 2.0 * n * p * q * cout * cin * r * s):
+        call("msml_conv2d_fused", dy, c0p, None, 0, wp, wp.shape[0], unit[0], unit[1], None, other, 0, out, cinp,
+             n, p, q, h, w, r, s, stride, ph, pw, 1)
+    return out
+
+
 def _dgrad_1x1_compact(dy, cp):
     """Input gradient of a 1x1 strided conv on the OUTPUT grid: dxc[n, py, px] = W^T dy[n, py, px]
     (the dense gradient is dxc scattered to the pixels (stride py, stride px), zero elsewhere)."""
@@ -456,8 +485,7 @@ class _Bottle(torch.autograd.Function):
         g1 = _ParamGrads((bn1[0], bn1[1], bp["a1"]), c1.shape[-1], dev)
         dc1 = _bn_bwd(do1, c1, k1, bp["a1"], g1, part1)
         dw1 = _wgrad(dc1, x, bp["c1"])
-        dx, _ = _dgrad(dc1, bp["c1"], h, w)
-        call("msml_add", dx, dres, dx, dx.numel(), BF16)
+        dx = _dgrad_plus(dc1, bp["c1"], h, w, dres)       # conv1's input gradient + the identity path, one kernel
         return (dx, None, dw1, dw2, dw3, g1.out(0), g1.out(1), g1.out(2), g2.out(0), g2.out(1), g2.out(2),
                 g3.out(0), g3.out(1), g3.out(2))
 
