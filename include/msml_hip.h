@@ -265,6 +265,12 @@ int msml_dap_bwd(const float* dseg, void* dx, int N, int H, int W, int Cp, int d
 int msml_seg_consensus_loss(const float* logit, const long* msk, int N, int H, int W, float alpha,
                             float beta, float* loss, float* dlogit, float* workspace,
                             long ws_floats, void* stream);
+/* the same with the reference's other reductions (tricks/consensus_loss.py:42-57,127-133,159-162): reduce_pixel_all != 0
+ * divides the blob mean by H * W ('all') instead of the blob's pixel count ('idx'); reduce_pixel_kl_all != 0 averages the
+ * consensus term over N * H * W instead of its non-zero entries. */
+int msml_seg_consensus_loss_r(const float* logit, const long* msk, int N, int H, int W, float alpha, float beta,
+                              int reduce_pixel_all, int reduce_pixel_kl_all, float* loss, float* dlogit,
+                              float* workspace, long ws_floats, void* stream);
 
 /* ---------------------------------------------------------------- classification head -------
  * kind: 0 = AMArcFace (headers/margin_losses.py:356-418), 1 = AMCosFace (:241-305).

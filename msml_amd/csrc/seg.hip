@@ -119,8 +119,11 @@ __global__ void __launch_bounds__(256) k_seg_sums(const float* __restrict__ logi
 
 // One workgroup: scalar loss and per-(n, s) gradient coefficients.
 //   coef[n][s] = {valid, gA0, gA1, gB0, gB1}: dL/dp_c(x) = gA_c - gB_c / p_c(x)  for x in blob s
+// mean_all: the blob mean divides by H * W instead of the blob's pixel count (reduce_pixel = 'all',
+// consensus_loss.py:131-133); kl_all: the consensus term is averaged over N * H * W instead of the non-zero entries
+// (reduce_pixel_kl = 'all', :159-160).
 __global__ void k_seg_loss(const float* __restrict__ sums, int N, float alpha, float beta,
-                           float* __restrict__ loss, float* __restrict__ coef) {
+                           float* __restrict__ loss, float* __restrict__ coef, int HW, int mean_all, int kl_all) {
   __shared__ double sh_sup[2], sh_nll[2], sh_kl[2];
   __shared__ double red[3][2][256];
   const int t = threadIdx.x;
@@ -131,7 +134,8 @@ __global__ void k_seg_loss(const float* __restrict__ sums, int N, float alpha, f
       const float* q = sums + (n * 2 + s) * 5;
       double sup = q[0];
       if (sup > 0.0) {
-        double pb0 = q[1] / sup, pb1 = q[2] / sup;
+        const double D = mean_all ? (double)HW : sup;
+        double pb0 = q[1] / D, pb1 = q[2] / D;
         double pbs = s == 0 ? pb0 : pb1;
         acc[0][s] += sup;
         acc[1][s] += -log(pbs);
@@ -158,7 +162,7 @@ __global__ void k_seg_loss(const float* __restrict__ sums, int N, float alpha, f
     double total = 0.0;
     for (int s = 0; s < 2; s++)
       if (sh_sup[s] > 0.0)
-        total += alpha * sh_nll[s] / N + beta * sh_kl[s] / (2.0 * sh_sup[s]);
+        total += alpha * sh_nll[s] / N + beta * sh_kl[s] / (kl_all ? (double)N * HW : 2.0 * sh_sup[s]);
     loss[0] = (float)(total / (nblobs > 0 ? nblobs : 1));
   }
   for (int i = t; i < N * 2; i += blockDim.x) {
@@ -167,13 +171,14 @@ __global__ void k_seg_loss(const float* __restrict__ sums, int N, float alpha, f
     float* c = coef + i * 5;
     double sup = q[0];
     if (sup > 0.0 && nblobs > 0) {
-      double pb[2] = {q[1] / sup, q[2] / sup};
-      double Z = 2.0 * sh_sup[s];
+      const double D = mean_all ? (double)HW : sup;                // pbar_k = (sum_x p_k) / D
+      double pb[2] = {q[1] / D, q[2] / D};
+      double Z = kl_all ? (double)N * HW : 2.0 * sh_sup[s];
       double inv_nb = 1.0 / nblobs;
       for (int k = 0; k < 2; k++) {
         double A = sup * (log(pb[k]) + 1.0) - q[3 + k];            // d(kl_n)/d(pbar_k)
-        double gA = beta * (A / sup) / Z;
-        if (k == s) gA += -alpha / (N * pb[k] * sup);
+        double gA = beta * (A / D) / Z;
+        if (k == s) gA += -alpha / (N * pb[k] * D);
         c[1 + k] = (float)(gA * inv_nb);
         c[3 + k] = (float)(beta * pb[k] / Z * inv_nb);
       }
@@ -207,9 +212,19 @@ __global__ void __launch_bounds__(256) k_seg_grad(const float* __restrict__ logi
   }
 }
 
+extern "C" int msml_seg_consensus_loss_r(const float* logit, const long* msk, int N, int H, int W, float alpha,
+                                         float beta, int reduce_pixel_all, int reduce_pixel_kl_all, float* loss,
+                                         float* dlogit, float* workspace, long ws_floats, void* stream);
+
 extern "C" int msml_seg_consensus_loss(const float* logit, const long* msk, int N, int H, int W,
                                        float alpha, float beta, float* loss, float* dlogit,
                                        float* workspace, long ws_floats, void* stream) {
+  return msml_seg_consensus_loss_r(logit, msk, N, H, W, alpha, beta, 0, 0, loss, dlogit, workspace, ws_floats, stream);
+}
+
+extern "C" int msml_seg_consensus_loss_r(const float* logit, const long* msk, int N, int H, int W, float alpha,
+                                         float beta, int reduce_pixel_all, int reduce_pixel_kl_all, float* loss,
+                                         float* dlogit, float* workspace, long ws_floats, void* stream) {
   MSML_CHECK(logit && msk && loss && workspace && N > 0 && H > 0 && W > 0, MSML_ERR_SHAPE,
              "seg_consensus_loss: bad args");
   MSML_CHECK(ws_floats >= (long)N * 20, MSML_ERR_WORKSPACE, "seg_consensus_loss: workspace < %ld floats",
@@ -220,7 +235,7 @@ extern "C" int msml_seg_consensus_loss(const float* logit, const long* msk, int 
   const int HW = H * W;
   k_seg_sums<<<N, 256, 0, st>>>(logit, msk, HW, sums);
   MSML_LAUNCH_OK("seg_sums");
-  k_seg_loss<<<1, 256, 0, st>>>(sums, N, alpha, beta, loss, coef);
+  k_seg_loss<<<1, 256, 0, st>>>(sums, N, alpha, beta, loss, coef, HW, reduce_pixel_all, reduce_pixel_kl_all);
   MSML_LAUNCH_OK("seg_loss");
   if (dlogit) {
     long total = (long)N * HW;

@@ -365,7 +365,7 @@ class _SegLoss(torch.autograd.Function):
     """StructureConsensuLossFunction(alpha, beta, 'idx', 'idx')(logit, msk, msk)."""
 
     @staticmethod
-    def forward(ctx, logit, msk, alpha, beta):
+    def forward(ctx, logit, msk, alpha, beta, mean_all=False, kl_all=False):
         n, c, h, w = logit.shape
         assert c == 2
         logit = logit.contiguous().float()
@@ -373,7 +373,7 @@ class _SegLoss(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=logit.device)
         dlogit = torch.empty_like(logit)
         ws = torch.empty(20 * n, dtype=torch.float32, device=logit.device)
-        call("msml_seg_consensus_loss", logit, msk, n, h, w, alpha, beta, loss, dlogit, ws,
+        call("msml_seg_consensus_loss_r", logit, msk, n, h, w, alpha, beta, int(mean_all), int(kl_all), loss, dlogit, ws,
              ws.numel())
         ctx.save_for_backward(dlogit)
         return loss[0]
@@ -381,11 +381,11 @@ class _SegLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlogit,) = ctx.saved_tensors
-        return dlogit * g, None, None, None
+        return dlogit * g, None, None, None, None, None
 
 
-def seg_consensus_loss(logit, msk, alpha=10.0, beta=5.0):
-    return _SegLoss.apply(logit, msk, alpha, beta)
+def seg_consensus_loss(logit, msk, alpha=10.0, beta=5.0, reduce_pixel="idx", reduce_pixel_kl="idx"):
+    return _SegLoss.apply(logit, msk, alpha, beta, reduce_pixel == "all", reduce_pixel_kl == "all")
 
 
 # --------------------------------------------------------------------------- cosine heads

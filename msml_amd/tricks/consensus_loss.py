@@ -1,7 +1,7 @@
 """Segmentation loss on the HIP path (reference: tricks/consensus_loss.py:28-179).
 
-Only the configuration the reference trains with is built: reduce_pixel='idx',
-reduce_pixel_kl='idx', blobs == target (train.py:228-229,258)."""
+blobs == target as the reference trains (train.py:228-229,258); both reductions of each term ('idx': per blob /
+per non-zero entry, the defaults train.py uses; 'all': H * W / N * H * W, consensus_loss.py:127-133,159-162)."""
 import os
 
 import torch.nn as nn
@@ -13,8 +13,7 @@ class StructureConsensuLossFunction(nn.Module):
     def __init__(self, consensus_loss_alpha=10.0, consensus_loss_beta=5.0, reduce_pixel="idx",
                  reduce_pixel_kl="idx"):
         super().__init__()
-        if reduce_pixel != "idx" or reduce_pixel_kl != "idx":
-            raise NotImplementedError("msml_amd: only the 'idx'/'idx' reductions are built")
+        self.reduce_pixel, self.reduce_pixel_kl = reduce_pixel, reduce_pixel_kl
         self.consensus_loss_alpha = consensus_loss_alpha
         self.consensus_loss_beta = consensus_loss_beta
 
@@ -30,4 +29,4 @@ class StructureConsensuLossFunction(nn.Module):
             if not bool((blobs == target).all()):
                 raise NotImplementedError("msml_amd: blobs must equal target (as in train.py:258)")
         return Fh.seg_consensus_loss(logit, target, float(self.consensus_loss_alpha),
-                                     float(self.consensus_loss_beta))
+                                     float(self.consensus_loss_beta), self.reduce_pixel, self.reduce_pixel_kl)

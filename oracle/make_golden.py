@@ -537,6 +537,16 @@ def g7():
     loss.backward()
     rec["loss_clean"] = np.float64(loss.item())
     rec["grad_clean_cs"] = checksum(lg.grad)
+    # the other reductions of the two terms (consensus_loss.py:42-57): 'all' = H * W / N * H * W
+    for rp, rk in (("all", "idx"), ("idx", "all"), ("all", "all")):
+        with contextlib.redirect_stderr(open(os.devnull, "w")):
+            c2 = StructureConsensuLossFunction(10.0, 5.0, rp, rk)
+        lg = logit.clone().requires_grad_(True)
+        loss = c2(lg, msk, msk)
+        loss.backward()
+        rec["loss_%s_%s" % (rp, rk)] = np.float64(loss.item())
+        rec["grad_pick_%s_%s" % (rp, rk)] = pick(lg.grad, 256)
+        rec["grad_cs_%s_%s" % (rp, rk)] = checksum(lg.grad)
     np.savez_compressed(os.path.join(OUT, "g7_seg_loss.npz"), **rec)
 
 

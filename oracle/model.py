@@ -429,8 +429,9 @@ def mask_index(final_seg):
 
 
 # --------------------------------------------------------------------------- seg loss
-def consensus_loss(logit, msk, alpha=10.0, beta=5.0):
-    """tricks/consensus_loss.py:65-167 with blobs == target == msk, 'idx'/'idx' reductions.
+def consensus_loss(logit, msk, alpha=10.0, beta=5.0, reduce_pixel="idx", reduce_pixel_kl="idx"):
+    """tricks/consensus_loss.py:65-167 with blobs == target == msk; reductions 'idx' (defaults, train.py:228) or
+    'all' (:127-133: blob mean over H * W; :159-160: consensus term averaged over N * H * W).
 
     For each value s present in msk: I = (msk == s); p = softmax(logit, 1);
     pbar[n, c] = sum_I p / |I_n|; NLL of pbar[:, s] (0 for images without the blob, still
@@ -445,14 +446,18 @@ def consensus_loss(logit, msk, alpha=10.0, beta=5.0):
         pb = p * ind
         sup = ind.sum((2, 3)).expand(n, c)                        # N,C
         has = sup > 0
-        pbar = torch.where(has, pb.sum((2, 3)) / sup.clamp_min(1.0), torch.zeros(()))
+        if reduce_pixel != "all":
+            pbar = torch.where(has, pb.sum((2, 3)) / sup.clamp_min(1.0), torch.zeros(()))
+        else:
+            pbar = pb.sum((2, 3)) / float(h * w)
         nll = -torch.log(pbar[:, int(s)])
         nll = torch.where(has[:, 0], nll, torch.zeros(()))
         nz = pb != 0
         logp = torch.where(nz, torch.log(torch.where(nz, pb, torch.ones(()))), torch.zeros(()))
         tgt = torch.where(nz, pbar[:, :, None, None].expand_as(pb), torch.ones(()))
         kl = tgt * (torch.log(tgt) - logp)                        # F.kl_div(..., 'none')
-        total = total + alpha * nll.mean() + beta * kl.sum() / nz.to(p.dtype).sum()
+        dev = kl.sum(1).mean() if reduce_pixel_kl == "all" else kl.sum() / nz.to(p.dtype).sum()
+        total = total + alpha * nll.mean() + beta * dev
     return total / float(vals.numel())
 
 

@@ -146,6 +146,20 @@ def test_seg_loss_g7():
     loss.backward()
     assert abs(loss.item() - g["loss_clean"]) < 1e-5 * abs(g["loss_clean"])
     assert_cs(lg.grad, g["grad_clean_cs"], 1e-4)
+    # the reference's other reductions (consensus_loss.py:42-57: 'all' = H * W / N * H * W)
+    for rp, rk in (("all", "idx"), ("idx", "all"), ("all", "all")):
+        lg = logit.cuda().requires_grad_(True)
+        loss = StructureConsensuLossFunction(10.0, 5.0, rp, rk)(lg, msk.cuda(), msk.cuda())
+        loss.backward()
+        assert abs(loss.item() - g["loss_%s_%s" % (rp, rk)]) < 1e-5 * abs(g["loss_%s_%s" % (rp, rk)]), (rp, rk)
+        # with reduce_pixel='all' the reference's OWN gradient is NaN on images that lack a blob (0 * inf in the autograd
+        # of log(0), the loss term itself is masked to 0): the kernel returns the finite limit (0) there
+        ref, got = g["grad_pick_%s_%s" % (rp, rk)], pick(lg.grad, 256)
+        ok = ~np.isnan(ref)
+        assert torch.isfinite(lg.grad).all()
+        assert rel_err(got[ok], ref[ok]) < 1e-4, (rp, rk)
+        if ok.all():
+            assert_cs(lg.grad, g["grad_cs_%s_%s" % (rp, rk)], 1e-4)
 
 
 def test_heads_g5():

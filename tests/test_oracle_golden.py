@@ -242,6 +242,17 @@ def test_g7_seg_loss():
     loss.backward()
     assert abs(loss.item() - g["loss_clean"]) < 1e-5 * abs(g["loss_clean"])
     assert_cs(lg.grad, g["grad_clean_cs"], 1e-4)
+    for rp, rk in (("all", "idx"), ("idx", "all"), ("all", "all")):       # consensus_loss.py:42-57
+        lg = logit.clone().requires_grad_(True)
+        loss = om.consensus_loss(lg, msk, reduce_pixel=rp, reduce_pixel_kl=rk)
+        loss.backward()
+        assert abs(loss.item() - g["loss_%s_%s" % (rp, rk)]) < 1e-5 * abs(g["loss_%s_%s" % (rp, rk)]), (rp, rk)
+        # reduce_pixel='all': the REFERENCE's gradient is NaN on every image that lacks one of the blobs (log of a zero
+        # blob mean, masked in the loss but 0 * inf in autograd) -- the third image of this fixture; same NaN set here
+        ref, got = g["grad_pick_%s_%s" % (rp, rk)], pick(lg.grad, 256)
+        ok = ~np.isnan(ref)
+        assert np.array_equal(np.isnan(got), ~ok) and (ok.all() if rp == "idx" else not ok.all())
+        assert rel_err(got[ok], ref[ok]) < 1e-4, (rp, rk)
 
 
 def test_g8_lr_groups():
