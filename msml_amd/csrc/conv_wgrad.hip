@@ -332,6 +332,11 @@ bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float*
                             int ntw, int splits, int chunk, hipStream_t st, float* dw_direct, int A, int Breal,
                             int Btot, int boff, int accumulate);
 
+bool msml_wgrad_fast_launch_group(const void* const* u, int up, const void* const* v, int vp, float* ws, int N, int H,
+                                  int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int ba, int bb,
+                                  int ntw, int group, int splits, int chunk, hipStream_t st, float* const* dw_direct,
+                                  int A, int Breal, int Btot, int boff, int accumulate);
+
 int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
                            int stride, int pad_h, int pad_w);
 bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
@@ -504,19 +509,41 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
   return MSML_OK;
 }
 
+// Splits per layer of the im2col kernel when `group` layers share a launch: the workgroup budget of ONE layer's launch
+// spread over the group (>= 1; 1 = every layer's tile goes straight into its dW, no slabs, no reduce).
+static int fast_group_splits(long mpix, int out_tiles, int group) {
+  const int one = pick_splits(mpix, out_tiles);
+  int per = one / group;
+  return per < 1 ? 1 : per;
+}
+
 // Largest number of same-shape layers msml_conv_wgrad_group accepts for this shape (1: no grouping).
 extern "C" int msml_conv_wgrad_group_max(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R,
                                          int S, int stride, int pad_h, int pad_w) {
+  if (msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0) {
+    int g = 1;
+    while (g * 2 <= WR_MAXGROUP &&
+           msml_wgrad_halo_group_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w, g * 2) >= 2)
+      g *= 2;
+    return g;
+  }
+  // im2col kernel (small maps, the shapes the strip / halo kernel leaves): grouping pays while a layer still has
+  // split-K slabs to shed, i.e. up to the split count of the one-layer launch
+  static const bool off = getenv("MSML_NO_FAST_WGRAD_GROUP") != nullptr;
+  if (off || R != 3 || S != 3 || stride != 1 || up % 8 || vp % 8) return 1;
+  if (msml_wgrad_n32_splits(up, vp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0) return 1;
+  const int ba = pick_tile(up), bb = pick_tile(vp), taps = R * S, ntw = wgrad_ntw(vp, taps);
+  const int tiles = ntw > 1 ? cdiv(up, ba) * cdiv(taps, ntw) * cdiv(vp, 64) : cdiv(up, ba) * cdiv(vp, bb) * taps;
+  const int one = pick_splits((long)N * P * Q, tiles);
   int g = 1;
-  while (g * 2 <= WR_MAXGROUP &&
-         msml_wgrad_halo_group_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w, g * 2) >= 2)
-    g *= 2;
-  return msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0 ? g : 1;
+  while (g * 2 <= WR_MAXGROUP && g * 2 <= one) g *= 2;
+  return g;
 }
 
-// Weight gradients of `group` layers of ONE shape in one launch pair (strip / halo kernel + fixed-order reduce):
-// every layer gets 1 / group of the workgroups, so the split-K slab bytes written and re-read PER LAYER fall by
-// the same factor (256 -> 256 @ 14x14: 75 MB of slabs for a 2.4 MB gradient at group 1).  u / v / dw: host arrays of
+// Weight gradients of `group` layers of ONE shape in one launch pair (strip / halo kernel, or the im2col kernel for
+// the shapes it serves, + fixed-order reduce): every layer gets 1 / group of the workgroups, so the split-K slab bytes
+// written and re-read PER LAYER fall by the same factor (256 -> 256 @ 14x14: 75 MB of slabs for a 2.4 MB gradient at
+// group 1; 512 -> 512 @ 7x7 at group 4: no slabs at all, the tiles go straight into dW).  u / v / dw: host arrays of
 // `group` device pointers.  Results depend on `group` only through the split partition (fixed for a given group).
 extern "C" int msml_conv_wgrad_group(const void* const* u, const void* const* v, float* const* dw, int group, int up,
                                      int vp, int A, int Breal, int Btot, int boff, int N, int H, int W, int P, int Q,
@@ -527,16 +554,35 @@ extern "C" int msml_conv_wgrad_group(const void* const* u, const void* const* v,
   for (int i = 0; i < group; i++)
     MSML_CHECK(u[i] && v[i] && dw[i], MSML_ERR_SHAPE, "conv_wgrad_group: null pointer in layer %d", i);
   MSML_CHECK(dtype == MSML_BF16, MSML_ERR_UNSUPPORTED, "conv_wgrad_group: bf16 only");
-  MSML_CHECK(boff >= 0 && boff + Breal <= Btot, MSML_ERR_SHAPE, "conv_wgrad_group: bad column range");
-  const int per = msml_wgrad_halo_group_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w, group);
-  MSML_CHECK(per > 0, MSML_ERR_UNSUPPORTED, "conv_wgrad_group: shape not covered by the strip / halo kernel");
-  const long need = (long)group * per * up * 9 * vp * (long)sizeof(float);
-  MSML_CHECK(ws_bytes >= need, MSML_ERR_WORKSPACE, "conv_wgrad_group: workspace %ld < %ld bytes", ws_bytes, need);
+  MSML_CHECK(boff >= 0 && boff + Breal <= Btot && A <= up && Breal <= vp, MSML_ERR_SHAPE, "conv_wgrad_group: bad channel range");
   hipStream_t st = (hipStream_t)stream;
-  msml_wgrad_halo_launch_group(u, up, v, vp, (float*)workspace, N, H, W, group, per, st, nullptr);
-  MSML_LAUNCH_OK("conv_wgrad_group(halo)");
-  wgrad_reduce_launch_group((const float*)workspace, dw, group, per, up, 9, vp, A, Breal, Btot, boff, accumulate, st);
-  MSML_LAUNCH_OK("conv_wgrad_group_reduce");
+  const int per = msml_wgrad_halo_group_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w, group);
+  if (per > 0) {
+    const long need = (long)group * per * up * 9 * vp * (long)sizeof(float);
+    MSML_CHECK(ws_bytes >= need, MSML_ERR_WORKSPACE, "conv_wgrad_group: workspace %ld < %ld bytes", ws_bytes, need);
+    msml_wgrad_halo_launch_group(u, up, v, vp, (float*)workspace, N, H, W, group, per, st, nullptr);
+    MSML_LAUNCH_OK("conv_wgrad_group(halo)");
+    wgrad_reduce_launch_group((const float*)workspace, dw, group, per, up, 9, vp, A, Breal, Btot, boff, accumulate, st);
+    MSML_LAUNCH_OK("conv_wgrad_group_reduce");
+    return MSML_OK;
+  }
+  MSML_CHECK(R == 3 && S == 3 && stride == 1 && (long)N * P * Q < (1L << 24), MSML_ERR_UNSUPPORTED,
+             "conv_wgrad_group: 3x3 / stride-1 layers only");
+  const int ba = pick_tile(up), bb = pick_tile(vp), taps = R * S, ntw = wgrad_ntw(vp, taps);
+  const int tiles = ntw > 1 ? cdiv(up, ba) * cdiv(taps, ntw) * cdiv(vp, 64) : cdiv(up, ba) * cdiv(vp, bb) * taps;
+  const long mpix = (long)N * P * Q;
+  const int splits = fast_group_splits(mpix, tiles, group);
+  const int chunk = (int)(((mpix + splits - 1) / splits + 63) / 64 * 64);
+  const long need = splits == 1 ? 0 : (long)group * splits * up * taps * vp * (long)sizeof(float);
+  MSML_CHECK(ws_bytes >= need, MSML_ERR_WORKSPACE, "conv_wgrad_group: workspace %ld < %ld bytes", ws_bytes, need);
+  MSML_CHECK(msml_wgrad_fast_launch_group(u, up, v, vp, (float*)workspace, N, H, W, P, Q, R, S, stride, pad_h, pad_w, ba,
+                                          bb, ntw, group, splits, chunk, st, dw, A, Breal, Btot, boff, accumulate),
+             MSML_ERR_UNSUPPORTED, "conv_wgrad_group: tensors too large for 32-bit offsets");
+  MSML_LAUNCH_OK("conv_wgrad_group(fast)");
+  if (splits > 1) {
+    wgrad_reduce_launch_group((const float*)workspace, dw, group, splits, up, taps, vp, A, Breal, Btot, boff, accumulate, st);
+    MSML_LAUNCH_OK("conv_wgrad_group_reduce");
+  }
   return MSML_OK;
 }
 

@@ -21,9 +21,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define OOB_OFFSET 0x7ffffff0u
 
+#define WF_MAXGROUP 8
 struct WgradFastArgs {
-  const unsigned short* u; int up; unsigned int u_bytes;
-  const unsigned short* v; int vp; unsigned int v_bytes;
+  const unsigned short* u[WF_MAXGROUP]; int up; unsigned int u_bytes;     // one (dY, X, dW) per grouped layer
+  const unsigned short* v[WF_MAXGROUP]; int vp; unsigned int v_bytes;
+  int zper;                   // splits per layer: grid.z = layers x zper
   int N, H, W, P, Q, R, S, stride, pad_h, pad_w;
   float* ws;
   int arows;
@@ -32,7 +34,8 @@ struct WgradFastArgs {
   float rcp_pq, rcp_q;
   // splits == 1 (many output tiles, short K: the PartialFC / fc weight gradients): no slab, the
   // tile goes straight into dW[a][boff + b][tap] (saves writing and re-reading |dW| floats)
-  float* dw;
+  float* dw[WF_MAXGROUP];
+  int direct;
   int A, Breal, Btot, boff, accumulate;
 };
 
@@ -60,15 +63,16 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
   const int a0 = blockIdx.x * BA;
   const int tap0 = (blockIdx.y / btiles) * NTW, b0 = (blockIdx.y % btiles) * (NTW > 1 ? 64 : BB);
   const int taps = p.R * p.S;
-  const int split = blockIdx.z;
+  const int layer = __builtin_amdgcn_readfirstlane(blockIdx.z / p.zper);    // several same-shape layers per launch
+  const int split = blockIdx.z - layer * p.zper;
   const long k_begin = (long)split * p.chunk;
   long k_end = k_begin + p.chunk;
   if (k_end > p.Mpix) k_end = p.Mpix;
   const int nstages = k_begin < k_end ? (int)((k_end - k_begin + 63) / 64) : 0;
   const int PQ = p.P * p.Q;
 
-  __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, (int)p.u_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)p.v, 0, (int)p.v_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)p.u[layer], 0, (int)p.u_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)p.v[layer], 0, (int)p.v_bytes, 0x00020000);
 
   // DMA slot of this lane: pixel (16 * wave + lane / 4) of the stage, 16-B chunk lane % 4 of
   // every 32-channel group
@@ -196,13 +200,14 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int a = a0 + arow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (p.dw) {
+        if (p.direct) {
           if (a < p.A && b < p.Breal && tap < taps) {
+            float* dwl = p.dw[layer];
             const long o = ((long)a * p.Btot + p.boff + b) * taps + tap;
-            p.dw[o] = p.accumulate ? p.dw[o] + acc[i][j][e] : acc[i][j][e];
+            dwl[o] = p.accumulate ? dwl[o] + acc[i][j][e] : acc[i][j][e];
           }
         } else if (a < p.arows && b < p.vp && tap < taps) {
-          p.ws[(((long)split * p.arows + a) * taps + tap) * p.vp + b] = acc[i][j][e];
+          p.ws[(((long)blockIdx.z * p.arows + a) * taps + tap) * p.vp + b] = acc[i][j][e];
         }
       }
     }
@@ -211,17 +216,24 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
 
 
 
-// Called from msml_conv_wgrad (conv_wgrad.hip) for bf16; chunk is a multiple of 64.
-// Returns false when the tensors are too large for 32-bit buffer offsets.
-bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
-                            int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int ba, int bb,
-                            int ntw, int splits, int chunk, hipStream_t st, float* dw_direct, int A, int Breal,
-                            int Btot, int boff, int accumulate) {
+// Called from msml_conv_wgrad[_group] (conv_wgrad.hip) for bf16; chunk is a multiple of 64.  group layers of one shape
+// share the launch (grid.z = group x splits; slabs at ws[layer * splits + split], or, with splits == 1, every layer's
+// tile straight into its dW).  Returns false when the tensors are too large for 32-bit buffer offsets.
+bool msml_wgrad_fast_launch_group(const void* const* u, int up, const void* const* v, int vp, float* ws, int N, int H,
+                                  int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int ba, int bb,
+                                  int ntw, int group, int splits, int chunk, hipStream_t st, float* const* dw_direct,
+                                  int A, int Breal, int Btot, int boff, int accumulate) {
   const long ub = (long)N * P * Q * up * 2, vb = (long)N * H * W * vp * 2;
-  if (ub >= 0x7fffff00L || vb >= 0x7fffff00L) return false;
+  if (ub >= 0x7fffff00L || vb >= 0x7fffff00L || group < 1 || group > WF_MAXGROUP) return false;
   WgradFastArgs a;
-  a.u = (const unsigned short*)u; a.up = up; a.u_bytes = (unsigned int)ub;
-  a.v = (const unsigned short*)v; a.vp = vp; a.v_bytes = (unsigned int)vb;
+  for (int i = 0; i < WF_MAXGROUP; i++) {
+    a.u[i] = (const unsigned short*)u[i < group ? i : 0];
+    a.v[i] = (const unsigned short*)v[i < group ? i : 0];
+    a.dw[i] = dw_direct ? dw_direct[i < group ? i : 0] : nullptr;
+  }
+  a.up = up; a.u_bytes = (unsigned int)ub;
+  a.vp = vp; a.v_bytes = (unsigned int)vb;
+  a.zper = splits;
   a.N = N; a.H = H; a.W = W; a.P = P; a.Q = Q; a.R = R; a.S = S;
   a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
   a.ws = ws; a.arows = up;
@@ -229,20 +241,30 @@ bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float*
   a.chunk = chunk;
   a.rcp_pq = 1.0f / (float)(P * Q);
   a.rcp_q = 1.0f / (float)Q;
-  a.dw = splits == 1 ? dw_direct : nullptr;
+  a.direct = (splits == 1 && dw_direct) ? 1 : 0;
   a.A = A; a.Breal = Breal; a.Btot = Btot; a.boff = boff; a.accumulate = accumulate;
+  const int gz = group * splits;
 #define WF(BA_, BB_, NTW_) k_wgrad_fast<BA_, BB_, NTW_><<<grid, dim3(256), 2 * 64 * (BA_ + BB_) * 2, st>>>(a)
   if (ntw == 3) {                                       // narrow V: 3 taps per workgroup
-    dim3 grid(cdiv(up, ba), cdiv(R * S, 3) * cdiv(vp, 64), splits);
+    dim3 grid(cdiv(up, ba), cdiv(R * S, 3) * cdiv(vp, 64), gz);
     if (ba == 128) WF(128, 192, 3);
     else WF(64, 192, 3);
     return true;
   }
-  dim3 grid(cdiv(up, ba), cdiv(vp, bb) * R * S, splits);
+  dim3 grid(cdiv(up, ba), cdiv(vp, bb) * R * S, gz);
   if (ba == 128 && bb == 128) WF(128, 128, 1);
   else if (ba == 128) WF(128, 64, 1);
   else if (bb == 128) WF(64, 128, 1);
   else WF(64, 64, 1);
 #undef WF
   return true;
+}
+
+bool msml_wgrad_fast_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
+                            int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int ba, int bb,
+                            int ntw, int splits, int chunk, hipStream_t st, float* dw_direct, int A, int Breal,
+                            int Btot, int boff, int accumulate) {
+  return msml_wgrad_fast_launch_group(&u, up, &v, vp, ws, N, H, W, P, Q, R, S, stride, pad_h, pad_w, ba, bb, ntw, 1,
+                                      splits, chunk, st, dw_direct ? &dw_direct : nullptr, A, Breal, Btot, boff,
+                                      accumulate);
 }

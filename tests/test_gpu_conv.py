@@ -409,11 +409,13 @@ def test_conv_wgrad_halo(shape, accumulate):
 
 
 @pytest.mark.parametrize("group", [2, 3, 4, 8])
-@pytest.mark.parametrize("shape", [(16, 256, 256, 14, 14), (12, 128, 128, 28, 28), (6, 64, 64, 56, 56), (9, 128, 64, 21, 28)])
+@pytest.mark.parametrize("shape", [(16, 256, 256, 14, 14), (12, 128, 128, 28, 28), (6, 64, 64, 56, 56), (9, 128, 64, 21, 28),
+                                   (256, 512, 512, 7, 7), (200, 256, 256, 7, 7), (256, 128, 128, 7, 7), (256, 512, 512, 4, 4)])
 def test_conv_wgrad_group(shape, group):
     """msml_conv_wgrad_group: `group` same-shape layers in one launch pair (each layer gets 1 / group of the
-    workgroups, XCD-aware order for the many-tile shapes) -- every layer's gradient against f64 torch, accumulated
-    onto existing values, through the raw entry point and through the host-side queue."""
+    workgroups, XCD-aware order for the many-tile shapes; the small maps run on the im2col kernel, down to one split =
+    tiles written straight into dW) -- every layer's gradient against f64 torch, accumulated onto existing values,
+    through the raw entry point and through the host-side queue."""
     import ctypes
     n, cin, cout, h, w_ = shape
     gmax = _lib.value("msml_conv_wgrad_group_max", cout, cin, cout, cin, n, h, w_, h, w_, 3, 3, 1, 1, 1)
