@@ -474,6 +474,12 @@ class _WgradQueue:
 _WQ = _WgradQueue()
 
 
+def wgrad_drop():
+    """Forget queued weight gradients without issuing them: a backward pass that raised half-way leaves its queue
+    behind, and those launches must not write into the NEXT step's gradient arena (FlatSGD.zero_grad calls this)."""
+    _WQ.items, _WQ.key, _WQ.stream = [], None, None
+
+
 def wgrad_flush():
     """Issue the pending grouped weight gradients (on the stream they were queued for)."""
     q = _WQ

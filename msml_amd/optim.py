@@ -105,6 +105,7 @@ class FlatSGD:
 
     def zero_grad(self):
         from . import ops
+        ops.wgrad_drop()                     # leftovers of a backward pass that raised must not reach this step
         if ops.WGRAD_STREAM is not None:     # the side stream must see the zeroed arena
             ops.WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
         if self.flat_g.is_cuda:
