@@ -529,28 +529,27 @@ __global__ void __launch_bounds__(256) k_norm_finalize(const float* __restrict__
   }
 }
 
-extern "C" int msml_grad_norm_clip(const float* grad, long n, float max_norm, float* out2,
-                                   float* workspace, long ws_floats, void* stream) {
+static int grad_norm_clip_impl(const float* grad, long n, float max_norm, float scale, float* out2, float* workspace,
+                               long ws_floats, void* stream) {
   MSML_CHECK(grad && out2 && workspace && n > 0 && ((uintptr_t)grad & 15) == 0, MSML_ERR_SHAPE,
              "grad_norm_clip: bad args (grad must be 16-byte aligned)");
+  MSML_CHECK(scale > 0.f, MSML_ERR_SHAPE, "grad_norm_clip: scale %f", scale);
   long b = (n + 255) / 256;
   int rows = (int)(b < 1024 ? b : 1024);
   MSML_CHECK(ws_floats >= rows, MSML_ERR_WORKSPACE, "grad_norm_clip: workspace too small");
   k_sumsq<<<rows, 256, 0, (hipStream_t)stream>>>(grad, n, workspace);
   MSML_LAUNCH_OK("grad_norm_clip");
-  k_norm_finalize<<<1, 256, 0, (hipStream_t)stream>>>(workspace, rows, max_norm, 1.f, out2);
+  k_norm_finalize<<<1, 256, 0, (hipStream_t)stream>>>(workspace, rows, max_norm, scale, out2);
   MSML_LAUNCH_OK("grad_norm_finalize");
   return MSML_OK;
 }
 
+extern "C" int msml_grad_norm_clip(const float* grad, long n, float max_norm, float* out2,
+                                   float* workspace, long ws_floats, void* stream) {
+  return grad_norm_clip_impl(grad, n, max_norm, 1.f, out2, workspace, ws_floats, stream);
+}
+
 extern "C" int msml_grad_norm_clip_scaled(const float* grad, long n, float max_norm, float scale, float* out2,
                                           float* workspace, long ws_floats, void* stream) {
-  MSML_CHECK(scale > 0.f, MSML_ERR_SHAPE, "grad_norm_clip_scaled: scale %f", scale);
-  int rc = msml_grad_norm_clip(grad, n, max_norm, out2, workspace, ws_floats, stream);   // (its finalize is redone below)
-  if (rc != MSML_OK) return rc;
-  long b = (n + 255) / 256;
-  int rows = (int)(b < 1024 ? b : 1024);
-  k_norm_finalize<<<1, 256, 0, (hipStream_t)stream>>>(workspace, rows, max_norm, scale, out2);
-  MSML_LAUNCH_OK("grad_norm_finalize_scaled");
-  return MSML_OK;
+  return grad_norm_clip_impl(grad, n, max_norm, scale, out2, workspace, ws_floats, stream);
 }

@@ -498,8 +498,7 @@ def wgrad_flush():
         arr(*[it[2].data_ptr() for it in items])
     if g == 1:
         u, v, dw = items[0][:3]
-        call("msml_conv_wgrad", u, up, v, vp, dw, a, breal, btot, boff, n, h, w, h, w, 3, 3, 1, 1, 1, 1, ws, ws.numel(),
-             BF16, raw)
+        conv_wgrad(u, v, dw, a, breal, btot, boff, 3, 3, 1, 1, 1, accumulate=True, stream=stream)
     elif PROFILE.on and stream is None:
         with PROFILE.rec("wgrad u%d v%d %dx%d k3x3 s1 n%d x%d" % (up, vp, h, w, n, g), 2.0 * n * h * w * a * breal * 9 * g):
             call("msml_conv_wgrad_group", us, vs, dws, g, up, vp, a, breal, btot, boff, n, h, w, h, w, 3, 3, 1, 1, 1, 1,
