@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
     __syncthreads();
     // one (sum, sumsq) row pair per SROWS pixel rows: 128 when BN >= 128 (so the row count does
     // not depend on BM = 128 / 256), the whole tile otherwise
-    constexpr int SROWS = BN >= 128 ? 128 : BM;
+    constexpr int SROWS = (BN >= 128 && BM >= 128) ? 128 : BM;   // (BM = 64: accumulator-mode launches only)
     constexpr int NH = BM / SROWS, WPH = WGM / NH;     // halves per tile, wave rows per half
     for (int i = t; i < NH * 2 * BN; i += NT) {
       int hf = i / (2 * BN), which = (i / BN) & 1, c = i % BN;
@@ -637,6 +637,29 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   // big tile only when it still fills the 256 CUs
   static const int use_big = getenv("MSML_CONV_BIG_TILE") ? atoi(getenv("MSML_CONV_BIG_TILE")) : 0;
   const bool big = use_big && bn == 128 && (long)cdiv(a.M, 256) * cdiv(coutp, 128) >= 256;
+  // Small maps (7x7 / 4x4 stages, the OSB's deepest levels): the default 128- / 256-row tile leaves the chip half
+  // empty (512 -> 512 @ 4x4: 128 workgroups, 512 -> 8 @ 4x4: 16), a 64-row tile doubles / quadruples the workgroup
+  // count.  Statistics / fused BatchNorm sums only in accumulator mode (the partial-row formats are sized by the
+  // default tile), no split-K, bf16 output.
+  static const bool small_ok = getenv("MSML_CONV_NO_SMALL_M") == nullptr;
+  const long def_wgs = (long)cdiv(a.parity ? (long)N * ((P + 1) / 2) * ((Q + 1) / 2) : a.M, bn == 128 ? 128 : 256) *
+                       cdiv(coutp, bn) * (a.parity ? 4 : 1);
+  const bool small_m = small_ok && !x3 && out_dtype == MSML_BF16 && def_wgs <= 200 && a.M >= 2048 &&
+                       (!stats || a.stats_acc) && (!bnb || bnb->acc);
+  if (small_m) {
+    if (bnb) {
+      if (bias || residual || scale || alpha) return false;
+      if (bn == 128) launch_fast<unsigned short, 64, 128, 2, 2, 2, true>(a, st);
+      else if (bn == 64) launch_fast<unsigned short, 64, 64, 2, 2, 2, true>(a, st);
+      else launch_fast<unsigned short, 64, 32, 2, 1, 2, true>(a, st);
+    } else {
+      if (bn == 128) launch_fast<unsigned short, 64, 128, 2, 2, 2>(a, st);
+      else if (bn == 64) launch_fast<unsigned short, 64, 64, 2, 2, 2>(a, st);
+      else launch_fast<unsigned short, 64, 32, 2, 1, 2>(a, st);
+    }
+    if (bnb_rows) *bnb_rows = a.tiles_m * (a.parity ? 4 : 1);
+    return true;
+  }
 #define FAST_CASE(TO)                                                   \
   if (big && use_big == 3) launch_fast<TO, 256, 128, 4, 2, 3>(a, st);   \
   else if (big) launch_fast<TO, 256, 128, 4, 2, 2>(a, st);              \

@@ -714,3 +714,63 @@ def test_bn_backward_row_and_accumulator_protocols_agree(n, k, c, h, stride, fol
     else:
         assert ((a[2] - b[2]).abs() <= 1e-4 * b[2].abs() + 1e-6).all()
         assert int((a[1] != b[1]).sum()) < 1e-5 * a[1].numel()
+
+
+# (N, Cin, Cout, H, R, S, stride, pad_h, pad_w, bias): small maps whose default 128- / 256-row tile would leave the
+# chip half empty -- at these batch sizes (N * P * Q >= 2048) msml_conv_fast_dispatch takes the 64-row tiles
+SMALL_MAPS = [
+    (160, 512, 512, 4, 3, 3, 1, 1, 1, False),      # OSB layer4 (512 @ 4x4)
+    (64, 256, 256, 7, 3, 3, 1, 1, 1, False),       # OSB layer3
+    (64, 128, 128, 7, 3, 3, 1, 1, 1, False),       # FM stage-3 bottleneck 3x3
+    (160, 512, 8, 4, 7, 1, 1, 3, 0, True),         # GCM1 7x1 (64 x 32 tile)
+    (64, 256, 18, 7, 1, 7, 1, 0, 3, True),         # GCM2 1x7
+    (64, 512, 128, 7, 1, 1, 1, 0, 0, False),       # bottleneck 1x1 (64 x 128 tile, one K stage per 64 channels)
+    (64, 256, 256, 14, 3, 3, 2, 1, 1, False),      # stride 2: 14x14 -> 7x7
+]
+
+
+@pytest.mark.parametrize("shape", SMALL_MAPS)
+def test_conv_small_map_tiles(shape):
+    """The 64-row tiles of k_conv_fast: forward (+ accumulator-mode statistics), backward-data, and backward-data with
+    the fused BatchNorm backward sums (accumulator mode), against f64 torch on the same bf16-rounded operands."""
+    n, cin, cout, h, r, s, stride, ph, pw, has_bias = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, h, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, r, s, generator=g) * (2.0 / (cin * r * s)) ** 0.5).bfloat16().float()
+    bias = torch.randn(cout, generator=g) if has_bias else None
+    xd = x.double().requires_grad_(True)
+    ref = F.conv2d(xd, w.double(), None if bias is None else bias.double(), stride, (ph, pw))
+    out, stats = run_conv(x, None, w, bias, stride, ph, pw, _lib.BF16)
+    got = ops.to_nchw(out, cout).cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref.float()).abs().max().item() <= 1.5e-2 * scale
+    if stats is not None and stats.dtype == torch.float64:
+        ssum = stats.sum(0).float().cpu()
+        assert torch.allclose(ssum[0, :cout], ref.float().sum((0, 2, 3)), rtol=0, atol=1.5e-2 * scale * ref[:, 0].numel() ** 0.5)
+    # backward-data
+    dy = torch.randn(ref.shape, generator=g).bfloat16().float()
+    ref.backward(dy.double())
+    p_, q_ = ref.shape[2], ref.shape[3]
+    wpt = ops.pack_weight(w.cuda(), True, cout, 0, _lib.BF16)
+    dyd = ops.to_nhwc(dy.cuda(), _lib.BF16)
+    dx, _ = ops.conv2d(dyd, None, wpt, None, ops.cpad(cin), r, s, stride, ph, pw, True, p=h, q=h)
+    gx = ops.to_nchw(dx, cin).cpu().double()
+    gscale = xd.grad.abs().max().item()
+    assert (gx - xd.grad).abs().max().item() <= 1.5e-2 * gscale
+    if r == 3 and stride == 1 and ops.acc_applies(ops.cpad(cin), _lib.BF16):
+        # fused BatchNorm backward sums of the conv input's BatchNorm (+PReLU): sum g, sum g * xhat, sum dy * min(z, 0)
+        bnx = torch.randn(n, h, h, ops.cpad(cin), generator=g).bfloat16().cuda()
+        coef = (torch.rand(4, ops.cpad(cin), generator=g) + 0.5).cuda()
+        alpha = torch.full((ops.cpad(cin),), 0.25, device="cuda")
+        res = ops.conv_dgrad_bnbwd(dyd, wpt, ops.cpad(cin), r, s, stride, ph, pw, h, h, bnx, coef, alpha)
+        assert res is not None
+        dx2, acc = res
+        assert torch.equal(dx2, dx)
+        gq = dx2.float().reshape(-1, dx2.shape[-1])
+        xf = bnx.float().reshape(-1, bnx.shape[-1])
+        z = xf * coef[0] + coef[1]
+        gg = torch.where(z > 0, gq, gq * alpha)
+        xh = (xf - coef[2]) * coef[3]
+        want = torch.stack((gg.sum(0), (gg * xh).sum(0), (gq * torch.clamp(z, max=0)).sum(0))).double()
+        have = acc.sum(0)
+        assert torch.allclose(have, want, rtol=2e-3, atol=2e-3 * want.abs().max().item())
