@@ -706,8 +706,10 @@ def test_block_chain_statistics_hand_off():
     # by one bf16 ulp
     assert rel_err(y2.cpu().numpy(), y1.cpu().numpy()) < 3e-3
     assert (y1 - y2).abs().max().item() <= 2e-2 * y1.abs().max().item()
+    # (running statistics: 0.1 x batch statistics of tensors in which a few elements differ by one bf16 ulp -> some
+    # 1e-5 absolute on values of 1e-2 .. 3e-1)
     for k in b1:
-        assert torch.allclose(b1[k].float(), b2[k].float(), rtol=1e-4, atol=1e-5), k
+        assert torch.allclose(b1[k].float(), b2[k].float(), rtol=3e-4, atol=3e-5), k
     assert rel_err(dx2.cpu().numpy(), dx1.cpu().numpy()) < 1.5e-2     # three bf16 blocks deep
     for k in g1:
         assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-2, k
