@@ -306,3 +306,32 @@ def test_texture_resize_kernel_is_pil_resize():
         for i, (w, h) in enumerate(sizes):
             ref = np.array(Image.fromarray(sets[si][1][desc[i, 14]], mode="RGBA").resize((w, h)))
             assert np.array_equal(got[i, :h * w * 4].reshape(h, w, 4), ref), (si, w, h)
+
+
+@pytest.mark.gpu
+def test_device_loader_with_texture_atlas():
+    """DeviceLoaderX on the reference's full ms1m mix (load_dataset.py:155-157) with an occluder atlas: every batch is
+    reproducible from (seed, batch index) and equals the oracle's -- masks bit-exact, images to exp() rounding."""
+    from msml_amd import data
+    sets = synthetic_sets(9)
+    atlas = data.OccluderAtlas(sets, 112, "cuda")
+    osets = oracle_sets(sets)
+    src = data.SynthFaceSource(24, 500, steps=3, pool=2, seed=4)
+    seen = []
+    for img, msk, ori, lab in data.DeviceLoaderX(src, 0, seed=55, mode="ms1m", atlas=atlas):
+        seen.append((img.clone(), msk.clone(), ori.clone(), lab.clone()))
+        torch.cuda.synchronize()
+    assert len(seen) == 3
+    kinds = set()
+    for k, (img, msk, ori, lab) in enumerate(seen):
+        faces, labels = src.pool[k % 2]
+        assert torch.equal(lab.cpu(), labels)
+        ref_desc = oo.draw(55, k * 24, 24, 112, 112, 5, sets=osets)
+        kinds |= set(ref_desc[:, 0].tolist())
+        rimg, rmsk, rori = oo.apply(faces.numpy(), ref_desc, True, True, sets=osets)
+        assert np.array_equal(msk.cpu().numpy(), rmsk)
+        assert np.array_equal(ori.cpu().numpy(), rori)
+        assert np.abs(img.cpu().numpy() - rimg).max() < 2e-3
+    assert kinds & {5, 6, 7}                       # texture occluders were drawn
+    with pytest.raises(ValueError):
+        data.draw(4, 1, 0, "ms1m")                 # the texture mixes need an atlas
