@@ -1,0 +1,44 @@
+"""The bench line's contract (driver + tier framing): checked on the line of the round that is committed under
+profiles/ (written by `python bench.py --steps 20 --warmup 5` on an MI355X) -- no GPU needed here."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    import bench
+    path = os.path.join(ROOT, "profiles", "%s_bench_default_run.json" % bench.ROUND)
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "images/sec" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None                      # BASELINE.md publishes no number for this metric
+    assert d["n_gpus"] == 1 and d["dtype"] == "bf16" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 256 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic_source"].startswith("profiles/%s_" % bench.ROUND)   # current round only
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1
+    s = d["roofline_step"]                               # img/s x F_train / peak
+    assert abs(s["achieved"] - d["value"] * 47.535 / 1e3) < 0.5 and abs(s["frac"] - s["achieved"] / 2500.0) < 1e-3
+
+
+def test_pmc_summary_of_the_round_is_keyed_by_bench_labels():
+    import bench
+    pm = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % bench.ROUND)))
+    labels = [k for k, v in pm.items() if isinstance(v, dict)]
+    assert any(k.startswith("conv T+bnb c256+0->256 14x14") for k in labels)
+    assert any(k.startswith("wgrad u256 v256 14x14") and k.endswith("x4") for k in labels)
+    for k in labels:
+        v = pm[k]
+        assert v["hbm_bytes"] > 0 and v["algorithmic_bytes"] > 0
+        b, src = bench.pmc_traffic(k)
+        assert b == v["hbm_bytes"] and src.endswith("%s_pmc_traffic.json" % bench.ROUND)
+    assert bench.pmc_traffic("conv N c3+0->64 1x1 no such launch") == (None, None)
