@@ -392,6 +392,10 @@ def main():
         # one-rank communicator only, and a capture that fails mid-collective cannot be retried
         args.launch = "eager"
     side_stream = torch.cuda.Stream()
+    if os.environ.get("MSML_BENCH_MAIN_PRIORITY"):
+        # experiment: the step's critical chain (forward, backward-data, BatchNorm) on a HIGH-priority stream, the side
+        # streams (weight gradients, OSB) at the default priority
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):      # the heads announce themselves like the reference's do: stdout
         runner = (Trainer if args.mode == "train" else Inferer)(args, rank, local_rank, world)   # carries the JSON line only

@@ -460,6 +460,9 @@ def conv_wgrad(u, v, dw, a, breal, btot, boff, r, s, stride, pad_h, pad_w, accum
 # gradients (FlatSGD arena views) can wait; a shape change, a full group, wgrad_flush() or wgrad_stream_join() issue
 # what is pending.  The group size is a function of the layer sequence only, so results are reproducible.
 WGRAD_GROUP = int(os.environ.get("MSML_WGRAD_GROUP", "4"))
+# maps larger than this are not queued: the 56x56 / 112x112 layers are the LAST of the backward pass, a queued launch
+# of theirs would only be issued by the end-of-backward flush, after the main stream has nothing left to overlap it with
+WGRAD_GROUP_MAX_HW = int(os.environ.get("MSML_WGRAD_GROUP_MAX_HW", "1000"))
 _GROUP_MAX = {}
 
 
@@ -521,7 +524,7 @@ def conv_wgrad_queued(u, v, dw, a, breal, btot, boff, stream, param):
     if gmax is None:
         gmax = _GROUP_MAX[skey] = min(WGRAD_GROUP, _lib.value("msml_conv_wgrad_group_max", up, vp, a, breal, n, p, q, p, q,
                                                               3, 3, 1, 1, 1)) if WGRAD_GROUP > 1 else 1
-    if gmax <= 1 or u.dtype != torch.bfloat16:
+    if gmax <= 1 or u.dtype != torch.bfloat16 or p > WGRAD_GROUP_MAX_HW:
         conv_wgrad(u, v, dw, a, breal, btot, boff, 3, 3, 1, 1, 1, accumulate=True, stream=stream)
         grad_ready(param)
         return
