@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256) k_occ_apply(const unsigned char* __restri
     // (:495, :591); the mask marks alpha != 0 for all three (:400-401, :504-505, :600-601).
     const unsigned char* tp = nullptr;
     bool paste = false;
-    if (d[0] >= OCC_GLASSES) {
+    if (d[0] >= OCC_GLASSES && patch != nullptr) {       // (no patch buffer: msml_occ_apply on texture descriptors = clean)
       const int px = sx - d[1], py = y - d[2];
       if (px >= 0 && px < d[3] && py >= 0 && py < d[4]) {
         tp = patch + (long)n * pstride + ((long)py * d[3] + px) * 4;

@@ -471,7 +471,6 @@ class _WgradQueue:
         self.key = None
         self.items = []          # (u, v, dw, param)
         self.stream = None
-        self.limit = 1
 
 
 _WQ = _WgradQueue()
