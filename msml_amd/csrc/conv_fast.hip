@@ -644,7 +644,8 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   static const bool small_ok = getenv("MSML_CONV_NO_SMALL_M") == nullptr;
   const long def_wgs = (long)cdiv(a.parity ? (long)N * ((P + 1) / 2) * ((Q + 1) / 2) : a.M, bn == 128 ? 128 : 256) *
                        cdiv(coutp, bn) * (a.parity ? 4 : 1);
-  const bool small_m = small_ok && !x3 && out_dtype == MSML_BF16 && def_wgs <= 200 && a.M >= 2048 &&
+  static const long small_wgs = getenv("MSML_CONV_SMALL_M_WGS") ? atol(getenv("MSML_CONV_SMALL_M_WGS")) : 200;
+  const bool small_m = small_ok && !x3 && out_dtype == MSML_BF16 && def_wgs <= small_wgs && a.M >= 2048 &&
                        (!stats || a.stats_acc) && (!bnb || bnb->acc);
   if (small_m) {
     if (bnb) {
