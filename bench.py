@@ -112,6 +112,7 @@ class Trainer:
             lab = synthetic.labels(args.batch, args.classes, seed=seed)
             self.batches.append((x.to(dev), msk.to(dev), lab.to(dev)))
         self.it = 0
+        self.phases = None
         self.loader = None
         if getattr(args, "data", "resident") == "device-synth":
             from msml_amd import data
@@ -126,15 +127,24 @@ class Trainer:
         self.it += 1
         return b
 
+    def mark(self, name):
+        """MSML_BENCH_PHASES=1: an event on the main stream at every phase boundary of the step (diagnostic)."""
+        if self.phases is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.phases.append((name, ev))
+
     def step(self, batch=None):
         Fh = self.Fh
         x, msk, label = batch if batch is not None else self.next_batch()
+        self.mark("start")
         self.opt.zero_grad()
         if self.world > 1:
             self.pfc.prefetch_labels(label)          # label all-gather on the head's side stream
         feature, final_seg, kd = self.model(x)                   # head-less training return
         seg_loss = self.seg_crit(final_seg, msk, msk)
         fn = Fh.normalize(feature)
+        self.mark("forward")
         if self.world > 1:
             # the OSB backward depends on final_seg only: issue it first so that it runs (on the OSB
             # stream) underneath the head's collectives; the FRB backward follows once dX is back
@@ -151,10 +161,13 @@ class Trainer:
             # one engine call: the OSB nodes, created first, run last (as its own call the OSB backward
             # measured 1 % slower at world size 1 -- 4 ms of host time before the FRB backward starts)
             x_grad, loss_v = self.pfc.forward_backward(label, fn, self.opt_pfc)
+            self.mark("head")
             torch.autograd.backward([fn, seg_loss], [x_grad, None])
+        self.mark("backward")
         self.opt.all_reduce_grads(self.world)
         self.opt.step()
         self.opt_pfc.step()                          # dW was written straight into its gradient arena
+        self.mark("optimizer")
         return loss_v, seg_loss
 
 
@@ -534,6 +547,20 @@ def main():
     if os.environ.get("MSML_BENCH_STEP_TIMES"):
         print("step ms:", " ".join("%.0f" % v for v in step_ms),
               "| reserved GB %.1f" % (torch.cuda.memory_reserved() / 2 ** 30), file=sys.stderr)
+    if os.environ.get("MSML_BENCH_PHASES") and args.mode == "train":
+        # diagnostic: where the main stream spends the eager multi-stream step (events at the phase boundaries; the
+        # side streams' work shows up in the phase during which the main stream waits for it -- the optimizer's join)
+        eager_mode(True)
+        acc = {}
+        for _ in range(6):
+            runner.phases = []
+            runner.step()
+            torch.cuda.synchronize()
+            ph = runner.phases
+            for (n0, e0), (n1, e1) in zip(ph, ph[1:]):
+                acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1) / 6
+        runner.phases = None
+        print("phases (ms on the main stream): " + "  ".join("%s %.2f" % kv for kv in acc.items()), file=sys.stderr)
     # roofline pass: the same step, eagerly, with a HIP-event pair around every instrumented
     # launch (events cannot be recorded inside a graph replay); kernel durations are unaffected
     prof = {}
