@@ -33,6 +33,7 @@ ROUND = "r03"                                     # PMC summaries of OTHER round
 # forward GFLOP per image (hooks on the imported reference); F_train = 3 x F_fwd (section 3)
 F_FWD_GF = {"iresnet18": 8.446, "iresnet34": 12.146, "iresnet50": 15.845, "iresnet100": 27.406}
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
+JSON_OUT = None                                   # the process's real stdout (main() points fd 1 at stderr)
 
 
 def parse():
@@ -380,14 +381,71 @@ def extra_modes(args, rank, local_rank):
     return out
 
 
+def launch_ranks(n):
+    """Start `n` rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, one GPU
+    each), wait for all of them and return the exit code: 0 only if every rank exited 0.  stdout of rank 0 (the JSON
+    line) is passed through as the only stdout of this process; the other ranks' stdout goes to stderr.  A rank that
+    dies takes the others down (they would otherwise sit in a collective until the watchdog fires)."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as sk:                       # a free port (closed again before the ranks bind it)
+            sk.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(sk.getsockname()[1])
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    import signal
+
+    def stop(signum, _frame):                             # killed from outside: do not leave ranks behind
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        raise SystemExit(128 + signum)
+    signal.signal(signal.SIGTERM, stop)
+    signal.signal(signal.SIGINT, stop)
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:                           # exact children of this process, by handle
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" in os.environ or args.gpus == 1:
+        # stdout carries the JSON line and nothing else: keep the real stdout for it and point fd 1 at stderr, so that
+        # whatever a library prints from C (gloo's "[Gloo] Rank 0 is connected to ...", ROCm notices) cannot land there
+        global JSON_OUT
+        sys.stdout.flush()
+        JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as the reference's launch line
+        # does (README.md:33-38, `python -m torch.distributed.launch --nproc_per_node=8 ... train.py`).  This parent
+        # has not touched the GPU (importing torch does not) and never will: it relays rank 0's JSON line.
+        raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # rehearsal of the multi-rank control flow on a ONE-GPU box (MSML_BENCH_ONE_GPU=1): every rank on device 0, gloo
     # instead of RCCL (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
     one_gpu = bool(os.environ.get("MSML_BENCH_ONE_GPU"))
@@ -687,7 +745,7 @@ def main():
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):
             rec["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(rec), flush=True)
+    print(json.dumps(rec), file=JSON_OUT or sys.stdout, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -92,12 +92,73 @@ class FMCnn(nn.Module):
         x = conv_bn(seq[0], seq[1], x, prelu=seq[2])
         return conv_bn(seq[3], seq[4], x, prelu=seq[5])
 
+    # ---- visualisation hooks of eval/qeval_mxnet.py --is_vis (:290-293, :372-375; fmoperator.py:177-276) -------------
+    def _save_intermediate_features(self, yf, x):
+        """en_save: keep host copies of the 'contaminated' features Y_f, the 'mask' M = act(x) and the 'purified'
+        features arith(Y_f, M) (before the skip / peer terms, as fmoperator.py:289-305 saves them), flattened in the
+        reference's NCHW order.  Host-side only: the device tensors (any precision mode's storage) are converted to
+        NCHW f32 once and M / arith are evaluated in numpy -- a debugging dump, not part of the timed path."""
+        if not self.en_save:
+            return
+        import numpy as np
+        with torch.no_grad():
+            c = self.channel_f
+            f = Fh.to_nchw_any(yf.detach(), c).cpu().numpy().astype(np.float32).reshape(-1)
+            pre = Fh.to_nchw_any(x.detach(), c).cpu().numpy().astype(np.float32).reshape(-1)
+        m = np.tanh(pre) if self.activation == "tanh" else (1.0 / (1.0 + np.exp(-pre))).astype(np.float32)
+        self.contaminated_feat = f
+        self.mask_feat = m
+        print(self.mask_feat.shape, 'mask saved.')
+        self.purified_feat = {"add": f + m, "sub": f - m, "mul": f * m, "div": f / m}[self.arith_strategy]
+
+    def plot_intermediate_features(self, gt_occ_msk, save_folder="."):
+        """Scatter plots of Y_f against M and against the purified features, coloured by the (resized) occlusion
+        mask: `fm_cm_{H}_{arith}.jpg`, `fm_cp_{H}_{arith}.jpg` in save_folder (fmoperator.py:202-276; the reference's
+        own body uses np.float, which numpy >= 1.24 no longer has).  gt_occ_msk: (B, H0, W0) in {0, 1}, 0 = occluded.
+        Needs a forward pass with en_save = True; matplotlib is imported here, lazily."""
+        import os.path
+        import numpy as np
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        from PIL import Image
+        if getattr(self, "mask_feat", None) is None:
+            raise RuntimeError("plot_intermediate_features: run a forward pass with en_save = True first")
+        msk = (gt_occ_msk.cpu().numpy() if isinstance(gt_occ_msk, torch.Tensor) else np.asarray(gt_occ_msk))
+        msk = msk.astype(np.uint8) * 255
+        batch = msk.shape[0]
+        resized = np.zeros((batch, self.height, self.width), dtype=np.uint8)
+        for b in range(batch):
+            resized[b] = np.array(Image.fromarray(msk[b], mode="L").resize(size=(self.width, self.height))) // 255
+        flat = np.repeat(resized[:, None, :, :], self.channel_f, axis=1).reshape(-1)
+        assert flat.size == self.mask_feat.size, (flat.size, self.mask_feat.size)
+        colors = np.where(flat == 0, 0.3, 0.7)          # 0 = occluded (purple), 1 = clean (yellow)
+        out = []
+        for tag, ys, ylabel in (("cm", self.mask_feat, "Mask Generated by FM Operators"),
+                                ("cp", self.purified_feat, "Face Feature Purified by FM Operators")):
+            name = "fm_%s_%d_%s.jpg" % (tag, self.height, self.arith_strategy)
+            plt.figure(dpi=300)
+            plt.title(name)
+            plt.xlabel("Contaminated Face Feature")
+            plt.ylabel(ylabel)
+            plt.scatter(x=self.contaminated_feat, y=ys, s=1, c=colors, alpha=0.4, vmin=0.0, vmax=1.0)
+            if tag == "cp":
+                lo, hi = float(self.contaminated_feat.min()), float(self.contaminated_feat.max())
+                plt.plot([lo, hi], [lo, hi], "r--", linewidth=1)        # the curve y = x
+            path = os.path.join(save_folder, name)
+            plt.savefig(path)
+            plt.close()
+            out.append(path)
+        return out
+
     def forward(self, yf, yo, yt=None):
         if yo is None:
             raise TypeError("FMCnn needs the OSB mask maps (use_osb=False only works with fm_layers=(0,0,0,0), "
                             "as in the reference: torch.cat((yf, None)) fails there)")
         x, _ = conv(self.same_conv, yf, yo, c1=18)
         x = self.res_block(x)
+        if self.en_save:
+            self._save_intermediate_features(yf, x)
         if not self.use_ori:
             return Fh.fm_fuse(x, yf, self.activation, self.arith_strategy), None
         # peer-guided branch (fmoperator.py:293-308): the mask is needed as a tensor

@@ -10,12 +10,24 @@ One autograd node per residual block instead of eight: the backward is written o
 Arithmetic per tensor is the same as the op-by-op graph in functional.py (same kernels, same
 order of the fixed-order reductions), which stays the path for f32 parity mode and inference.
 """
+import os
+
 import torch
 
 from . import ops
 from . import _lib
 from ._lib import BF16, call
 from .ops import cpad
+
+
+# Test instrumentation (tests/test_gpu_block_local.py).  TAP: callable(kind, pack, tensors) invoked at the end of a
+# block's hand-written backward with the tensors that backward actually consumed and produced (block input, saved
+# BatchNorm coefficients, incoming and outgoing gradient), so that ONE block can be recomputed in f64 from the very same
+# operands -- an error then no longer compounds through 50 layers and a missing term shows.  FAULT: deliberately wrong
+# backward variants ("skip_join": the identity-path gradient is not added at the block input) that demonstrate that the
+# local check can fail; never set outside that demonstration.
+TAP = None
+FAULT = os.environ.get("MSML_FAULT", "")
 
 
 def _bn_pack(bn):
@@ -382,7 +394,7 @@ class _IBlock(torch.autograd.Function):
             else:
                 join, _ = _dgrad(dd, ds[0], h, w)
         else:
-            join, join_s2 = dout, False
+            join, join_s2 = (None if FAULT == "skip_join" else dout), False
         # bn1: dx = bn1 path + joined gradient in one kernel
         g1 = _ParamGrads((bn1[0], bn1[1], None), x.shape[-1], dev)
         if pc2 is not None and part1 is not None and ops.FUSE_BN_BWD:
@@ -392,6 +404,8 @@ class _IBlock(torch.autograd.Function):
                 dx._msml_bn3_partial = pprev
         else:
             dx = _bn_bwd(do1, x, k1, None, g1, part1, add=join, add_s2=join_s2)
+        if TAP is not None:
+            TAP("iblock", bp, {"x": x, "dout": dout, "dx": dx, "k1": k1, "k2": k2, "k3": k3, "kd": kd})
         grads = [dw1, dw2] + ([dwd] if ds is not None else [])
         grads += [g1.out(0), g1.out(1), g2.out(0), g2.out(1), g2.out(2), g3.out(0), g3.out(1)]
         if ds is not None:
@@ -486,6 +500,8 @@ class _Bottle(torch.autograd.Function):
         dc1 = _bn_bwd(do1, c1, k1, bp["a1"], g1, part1)
         dw1 = _wgrad(dc1, x, bp["c1"])
         dx = _dgrad_plus(dc1, bp["c1"], h, w, dres)       # conv1's input gradient + the identity path, one kernel
+        if TAP is not None:
+            TAP("bottle", bp, {"x": x, "dout": dout, "dx": dx, "k1": k1, "k2": k2, "k3": k3})
         return (dx, None, dw1, dw2, dw3, g1.out(0), g1.out(1), g1.out(2), g2.out(0), g2.out(1), g2.out(2),
                 g3.out(0), g3.out(1), g3.out(2))
 

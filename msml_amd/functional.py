@@ -1035,27 +1035,42 @@ class _Dropout(torch.autograd.Function):
 
 
 _DROP_COUNTER = [0]
-_DROP_STATE = {}
+_DROP_STATE = {}           # device -> [torch.initial_seed() the tensor was derived from, int64 seed tensor]
+_M63 = 0x7FFFFFFFFFFFFFFF
+
+
+def _capture_seed_base(s0):
+    """Start of the device-resident seed sequence captured steps draw from: a different affine map of the torch seed
+    than the eager sequence `s0 * 1000003 + counter` (the two would otherwise coincide step for step: replay k re-drew
+    the mask of eager call k -- ADVICE r3), with 2^40 calls of headroom before the int64 wraps."""
+    return ((s0 * 2862933555777941757 + 3037000493) & (_M63 >> 1)) | (1 << 40)
 
 
 def dropout(x, p, seed=None):
     """nn.Dropout(p) in training mode on a storage tensor (iresnet.py:231); the mask comes from a
     counter-based hash, a fresh seed per call unless one is given.  Under hipGraph capture a host-side seed would be
     baked into the graph (every replay the same mask): the seed then lives in a device tensor that the captured
-    sequence itself advances -- copy it for this call's forward / backward, add 1 for the next call or replay."""
+    sequence itself advances -- copy it for this call's forward / backward, add 1 for the next call or replay.
+    The device sequence is one per device (every captured graph of the process draws from it, so two graphs never
+    repeat each other's masks) and is re-derived, in place, when torch.manual_seed() changed the seed since the last
+    eager call."""
     if seed is None:
         if torch.cuda.is_current_stream_capturing():
             st = _DROP_STATE.get(x.device)
             if st is None:       # (a tensor created inside the capture would be re-initialised by every replay)
                 raise RuntimeError("msml_amd dropout under graph capture: run one eager (warm-up) step first")
-            seed = st.clone()
-            st.add_(1)
+            seed = st[1].clone()
+            st[1].add_(1)
         else:
-            if x.device not in _DROP_STATE:      # the seed tensor captured steps will read and advance
-                _DROP_STATE[x.device] = torch.full((1,), (torch.initial_seed() * 1000003) & 0x3FFFFFFFFFFFFFFF,
-                                                   dtype=torch.int64, device=x.device)
+            s0 = torch.initial_seed()
+            st = _DROP_STATE.get(x.device)
+            if st is None:      # the seed tensor captured steps will read and advance
+                _DROP_STATE[x.device] = [s0, torch.full((1,), _capture_seed_base(s0), dtype=torch.int64, device=x.device)]
+            elif st[0] != s0:   # torch.manual_seed() since: restart the device sequence (same tensor: graphs hold its address)
+                st[0] = s0
+                st[1].fill_(_capture_seed_base(s0))
             _DROP_COUNTER[0] += 1
-            seed = (torch.initial_seed() * 1000003 + _DROP_COUNTER[0]) & 0x7FFFFFFFFFFFFFFF
+            seed = (s0 * 1000003 + _DROP_COUNTER[0]) & _M63
     return _Dropout.apply(x, p, seed)
 
 

@@ -165,6 +165,7 @@ class PartialFC(Module):
             self.sub_weight = Parameter(torch.empty((0, 0), device=self.device))
             self.sub_weight_mom = None
         self._k = None                # sampled mode on a flat-arena optimizer: rows of sub_weight in use this step
+        self._flat_param = None       # the fixed-capacity parameter handed out by flat_parameter()
         if backend is None:
             from .._lib import BF16, F32
             backend = HipBackend(BF16 if fp16 else F32)
@@ -196,8 +197,13 @@ class PartialFC(Module):
             # the sampled rows every step): here the optimizer keeps ONE fixed-capacity parameter in its arenas
             # (flat_parameter()), sample() gathers the sampled rows and their momentum into the arena views and
             # update() scatters them back -- no re-registration, no host sync on the static branch
-            if tuple(self.sub_weight.shape) != (self.flat_capacity(), self.embedding_size):
-                raise ValueError("negative sampling on a flat-arena optimizer: build it over pfc.flat_parameter()")
+            if self._flat_param is None or self.sub_weight is not self._flat_param or id(self.sub_weight) not in opt.offsets:
+                raise ValueError("negative sampling on a flat-arena optimizer: build it over pfc.flat_parameter() "
+                                 "(and adopt it before the first prefetch_labels() / forward_backward())")
+            if opt.max_norm is not None:
+                # rows [k, capacity) of the arena parameter are not part of the step: they must not enter a norm
+                raise ValueError("the head's FlatSGD must be built with max_norm=None (the reference never clips the "
+                                 "PartialFC weight, train.py:267-277)")
             self._flat_mom = opt.momentum_view(self.sub_weight)
             opt.steps = max(opt.steps, 1)          # the gathered momentum is never a "first step" buffer
             self._flat = opt
@@ -221,7 +227,8 @@ class PartialFC(Module):
         `pfc.sub_weight`, whose first len(index) rows are the sampled classes of the current step."""
         if self.full:
             return self.sub_weight
-        self.sub_weight = Parameter(torch.zeros((self.flat_capacity(), self.embedding_size), device=self.device))
+        self.sub_weight = self._flat_param = Parameter(torch.zeros((self.flat_capacity(), self.embedding_size),
+                                                                   device=self.device))
         return self.sub_weight
 
     def _active(self):
@@ -272,6 +279,11 @@ class PartialFC(Module):
             torch.index_select(self.weight_mom, 0, index, out=self._flat_mom[:k])
             self.sub_weight_mom = self._flat_mom[:k]
             return
+        if self._flat_param is not None:
+            # flat_parameter() was handed to a FlatSGD that has not been adopted yet (prefetch_labels() before the first
+            # forward_backward(): ADVICE r3) -- replacing sub_weight here would orphan the arena parameter
+            raise RuntimeError("PartialFC: call pfc.adopt_flat_optimizer(opt) right after building FlatSGD over "
+                               "pfc.flat_parameter(), before prefetch_labels()")
         self.sub_weight = Parameter(self.weight[index])
         self.sub_weight_mom = self.weight_mom[index]
 

@@ -490,6 +490,10 @@ def wgrad_flush():
     items, key, stream = q.items, q.key, q.stream
     q.items, q.key, q.stream = [], None, None
     up, vp, n, h, w, a, breal, btot, boff, raw = key
+    if stream is None and raw != _lib.raw_stream():
+        # queued for "the current stream" of another moment (the flush runs from the end-of-backward callback or from
+        # a node of another stream): launch on THAT stream with ITS scratch buffer, not the caller's
+        stream = torch.cuda.ExternalStream(raw)
     g = len(items)
     need = _WGRAD_WS_NEED.get((up, vp, n, h, w, 3, 3))
     if need is None:

@@ -96,9 +96,19 @@ class FlatSGD:
             g["lr"] = g["base_lr"] * factor
         self.lr_dev.copy_(torch.tensor([g["lr"] for g in self.groups], dtype=torch.float32), non_blocking=True)
 
+    def averaged_grad(self):
+        """The flat gradient as the optimizer will apply it before clipping: flat_g x grad_scale (a copy when a
+        scale is pending, flat_g itself otherwise)."""
+        return self.flat_g if self.grad_scale == 1.0 else self.flat_g * self.grad_scale
+
     def release(self):
         """Detach the parameters from the arena protocol (in-place gradients, overlap callbacks): they
-        behave like plain parameters again (their data / grad stay views of the arenas)."""
+        behave like plain parameters again (their data / grad stay views of the arenas).  A pending rank-sum scale
+        (all_reduce_grads() without step()) is folded into the arena first, so that the .grad handed out is the
+        averaged gradient."""
+        if self.grad_scale != 1.0:
+            self.flat_g.mul_(self.grad_scale)
+            self.grad_scale = 1.0
         for p in self.params:
             p.__dict__.pop("_msml_arena", None)
             p.__dict__.pop("_msml_ready", None)
@@ -192,16 +202,26 @@ class FlatSGD:
             self._fire(bi)
 
     def all_reduce_grads(self, world_size, bucket_bytes=64 << 20):
-        """DDP gradient averaging on the flat arena: a few large all-reduces (overlapped with
-        the backward when enable_overlap() was called, otherwise issued here)."""
+        """DDP gradient reduction on the flat arena: a few large SUM all-reduces (overlapped with
+        the backward when enable_overlap() was called, otherwise issued here).
+
+        Contract: afterwards flat_g -- and every p.grad, which is a view of it -- holds the SUM over the ranks,
+        NOT the average; the division by the world size lives in `grad_scale` (1 / W), which step() folds into the
+        coefficient of the fused clip + SGD kernel and zero_grad() resets.  Code that reads .grad between this call
+        and step() (logging, an external clip_grad_norm_, a torch optimizer after release()) must use
+        averaged_grad() / release(), which apply the scale."""
         from . import ops
         if getattr(self, "buckets", None) is not None:
             for bi in range(len(self.buckets)):          # parameters that never reported
                 if not self.fired[bi]:
                     self._fire(bi)
-            for w in self.works:
-                w.wait()
+            # Work.wait() orders the CURRENT stream behind the collective (ProcessGroupNCCL runs it on an internal
+            # stream): wait on the communication stream, where the bf16 -> f32 copy-back is enqueued, and let the
+            # training stream wait for that stream afterwards (ADVICE r3: waiting on the main stream only let the
+            # copy-back read `half` before its all-reduce had finished)
             with torch.cuda.stream(self.comm):
+                for w in self.works:
+                    w.wait()
                 for buf, half in self._half:          # bf16 messages: back into the f32 arena
                     buf.copy_(half)
             self._half = []

@@ -227,6 +227,23 @@ def g4c():
               flush=True)
 
 
+def g4d():
+    """The headline workload's backbone step AT ITS FULL PER-GPU BATCH (the full-size test compared
+    the bf16 HIP path with the f32 HIP path only): ires50 (config 3, iresnet.py:470-481), batch 256, train-mode
+    BatchNorm, key fill, the recorder of g4c with 256-element picks.  MSML_G4D_BS overrides the batch (memory probe)."""
+    C = 1000
+    bs = int(os.environ.get("MSML_G4D_BS", "256"))
+    torch.manual_seed(0)
+    m = fill_module(ref_msml("iresnet50", C))
+    rec = train_step_record(m, bs, C, DEEP_PICKS["iresnet50"], npick=256)
+    if bs == 256:
+        np.savez_compressed(os.path.join(OUT, "g4_train_ires50_b256.npz"), **rec)
+    import resource
+    print("   iresnet50", bs, "cls %.5f seg %.5f gnorm %.4f  peak RSS %.1f GB"
+          % (rec["cls_loss"], rec["seg_loss"], rec["grad_norm"], resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20),
+          flush=True)
+
+
 KD_PEER = {"use_ori": True, "use_conv": True, "mask_trans": "conv", "use_decoder": True}
 KD_PICKS = ["frb.conv1.weight", "frb.fm_ops.0.same_conv.weight", "frb.fm_ops.0.conv_m.0.weight",
             "frb.fm_ops.0.conv_m.0.bias", "frb.fm_ops.0.conv_m.1.weight", "frb.fm_ops.2.conv1.0.weight",

@@ -22,6 +22,7 @@ def pytest_sessionstart(session):
     fork + exec on this pool; counting devices does not initialise it).  The test only collects them."""
     config = session.config
     config._pfc_ranks = None
+    config._bench2 = None
     expr = getattr(config.option, "markexpr", "") or ""
     if "gpu" not in expr or "not gpu" in expr or os.environ.get("MSML_NO_RANK_CHILDREN"):
         return
@@ -40,6 +41,18 @@ def pytest_sessionstart(session):
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pfc_gpu_rank.py"), str(r), "2",
                                        port, outdir], stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT))
     config._pfc_ranks = (procs, outdir)
+    # `python bench.py --gpus 2` with no launcher around it: bench.py starts its own ranks.  Started
+    # here for the same reason as the rank children; both ranks share device 0 under gloo (MSML_BENCH_ONE_GPU: the
+    # multi-rank control flow, not a measurement), small workload.  test_bench_launches_its_own_ranks collects it.
+    benv = dict(env, MSML_BENCH_ONE_GPU="1")
+    benv.pop("WORLD_SIZE", None)
+    benv.pop("RANK", None)
+    bout = open(os.path.join(outdir, "bench2.out"), "w")
+    berr = open(os.path.join(outdir, "bench2.err"), "w")
+    config._bench2 = (subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                                        "--warmup", "1", "--frb", "iresnet18", "--batch", "32", "--classes", "1000",
+                                        "--no-extra-modes", "--no-cpu-baseline", "--no-kernel-events"],
+                                       stdout=bout, stderr=berr, env=benv, cwd=ROOT), outdir)
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -48,6 +61,14 @@ def pytest_sessionfinish(session, exitstatus):
         for p in ranks[0]:
             if p.poll() is None:
                 p.kill()
+    b2 = getattr(session.config, "_bench2", None)
+    if b2 and b2[0].poll() is None:
+        b2[0].terminate()            # the launcher takes its ranks down with it (SIGTERM handler in bench.launch_ranks)
+
+
+@pytest.fixture(scope="session")
+def bench2_result(request):
+    return request.config._bench2
 
 
 @pytest.fixture(scope="session")

@@ -46,20 +46,37 @@ def elem_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def bf16_tolerances(case):
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+
+
+BF16_CAP = 0.35          # no norm-wise gradient bound of a bf16 training-step test is looser than this
+
+
+def bf16_tolerances(case, cap=BF16_CAP):
     """Tolerances of a bf16 training-step test, DERIVED from the bf16 error floor of the CPU oracle under the rounding
-    model of oracle/bf16_emul.py (tests/golden/bf16_floor.npz, recorded by oracle/make_bf16_floor.py: maximum over
-    five draws of the rounding noise): {loss, gnorm, stat, osb, head, frb_early, frb_late} = 2 x floor, per parameter
-    group (oracle.bf16_emul.param_group); absolute minima keep a bound meaningful where the emulated error is tiny."""
+    model of oracle/bf16_emul.py (tests/golden/bf16_floor.npz, recorded by oracle/make_bf16_floor.py for five draws of
+    the rounding noise).  Per parameter group (oracle.bf16_emul.param_group: osb / head / frb_early / frb_late):
+    floor = MEDIAN over the draws of the group's worst gradient error in that draw, bound = min(3 x floor, cap).
+    (Round 3 used 2 x the MAXIMUM over the draws, uncapped: one outlier draw at batch 4 -- BatchNorm1d over four
+    samples in front of an s = 64 head -- put the head bound of ires100 b4 at 1.29, which an all-zero gradient passes;
+    VERDICT r3 weak #1.)  losses / gnorm / running statistics: 2 x their recorded floor (maximum over the draws) with absolute minima."""
     from oracle.bf16_emul import param_group
     fl = load("bf16_floor.npz")
-    groups = {}
-    for k in fl.files:
-        if k.startswith(case + "/grad/"):
-            grp = param_group(k.split("/", 2)[2])
-            groups[grp] = max(groups.get(grp, 0.0), float(fl[k]))
+    draws = sorted({k.split("/")[1] for k in fl.files if k.startswith(case + "/draw")})
+    assert draws, case
+    tol = {}
+    for grp in ("osb", "head", "frb_early", "frb_late"):
+        per = []
+        for d in draws:
+            v = [float(fl[k]) for k in fl.files
+                 if k.startswith("%s/%s/" % (case, d)) and param_group(k.split("/", 2)[2]) == grp]
+            if v:
+                per.append(max(v))
+        if per:
+            tol[grp] = min(3.0 * float(np.median(per)), cap)
     stat = max([float(fl[k]) for k in fl.files if k.startswith(case + "/stat/")] + [0.0])
-    tol = {g: 2.0 * v for g, v in groups.items()}
     tol["loss"] = max(2.0 * max(float(fl[case + "/loss_seg"]), float(fl[case + "/loss_cls"])), 2e-3)
     tol["gnorm"] = max(2.0 * float(fl[case + "/gnorm"]), 5e-3)
     tol["stat"] = max(2.0 * stat, 5e-3)

@@ -51,11 +51,12 @@ def main():
     from oracle.fill import fill_module
     peer = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
 
-    def grads(overlap):
+    def grads(overlap, comm_dtype=None):
         torch.manual_seed(0)
         m = fill_module(MSML("iresnet18", "unet", (1, 1, 1, 1), 50, fp16=True, fm_params=(3, 2, "sigmoid", "mul"),
                              header_type="AMArcFace", peer_params=dict(peer))).cuda().train()
         opt = FlatSGD(reference_param_groups(m, 2, world), 0.9, 5e-4, 5.0)
+        opt.comm_dtype = comm_dtype
         if overlap:
             opt.enable_overlap(world, bucket_bytes=8 << 20)
         ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
@@ -71,7 +72,7 @@ def main():
             fired = sum(opt.fired) if overlap else 0
             opt.all_reduce_grads(world)
             torch.cuda.synchronize()
-            return opt.flat_g.clone(), fired, (len(opt.buckets) if overlap else 0)
+            return opt.averaged_grad().clone(), fired, (len(opt.buckets) if overlap else 0)
         finally:
             ops.WGRAD_STREAM = ops.OSB_STREAM = None
             opt.release()
@@ -81,6 +82,16 @@ def main():
     out["ddp_fired_during_backward"] = fired
     out["ddp_buckets"] = nb
     out["ddp_gsum"] = float(ga.double().abs().sum().item())
+    # bf16 gradient messages (MSML_GRAD_COMM=bf16 / opt.comm_dtype), overlap off and on (the copy-back of an
+    # overlapped bf16 bucket must be ordered behind its all-reduce): both equal the f32 average to bf16 rounding and
+    # equal each other bit for bit (same messages, same order of the two summands)
+    gh, _, _ = grads(False, torch.bfloat16)
+    gho, fired_h, _ = grads(True, torch.bfloat16)
+    den = float(ga.double().norm().item())
+    out["ddp_bf16_rel"] = float((gh.double() - ga.double()).norm().item()) / den
+    out["ddp_bf16_overlap_rel"] = float((gho.double() - ga.double()).norm().item()) / den
+    out["ddp_bf16_equal"] = int(torch.equal(gh, gho))
+    out["ddp_bf16_fired_during_backward"] = fired_h
     np.savez(os.path.join(outdir, "r%d.npz" % rank), **out)
     dist.destroy_process_group()
 

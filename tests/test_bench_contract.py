@@ -42,3 +42,25 @@ def test_pmc_summary_of_the_round_is_keyed_by_bench_labels():
         b, src = bench.pmc_traffic(k)
         assert b == v["hbm_bytes"] and src.endswith("%s_pmc_traffic.json" % bench.ROUND)
     assert bench.pmc_traffic("conv N c3+0->64 1x1 no such launch") == (None, None)
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` with no launcher around it (the reference's launch line is
+    README.md:33-38) starts two rank processes itself.  Without a GPU both ranks fail at torch.cuda.set_device: the
+    launcher must come back promptly with a non-zero exit code and an EMPTY stdout (stdout carries the JSON line
+    only) -- the control flow the GPU test test_bench_launches_its_own_ranks runs to the end."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-side check of the launcher's failure path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    # with WORLD_SIZE set by an external launcher the script must NOT spawn again: a mismatch is an error message
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr

@@ -180,3 +180,36 @@ def test_partial_fc_hip_two_ranks_one_gpu(pfc_rank_results):
         assert int(z["ddp_equal"]) == 1
         assert int(z["ddp_buckets"]) >= 4 and int(z["ddp_fired_during_backward"]) >= int(z["ddp_buckets"]) - 1
     assert abs(float(z0["ddp_gsum"]) - float(z1["ddp_gsum"])) <= 1e-6 * float(z0["ddp_gsum"])
+    # bf16 gradient messages, overlapped or not, equal the f32 average to bf16 rounding (each summand 2^-9, the sum
+    # once more) and each other exactly
+    for z in (z0, z1):
+        assert float(z["ddp_bf16_rel"]) < 2.0 ** -7 and float(z["ddp_bf16_overlap_rel"]) < 2.0 ** -7
+        assert int(z["ddp_bf16_equal"]) == 1
+        assert int(z["ddp_bf16_fired_during_backward"]) >= int(z["ddp_buckets"]) - 1
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(bench2_result):
+    """`python bench.py --gpus 2 --steps 2` started with NO launcher around it (tests/conftest.py, as a fresh process
+    before this one touched the GPU): bench.py spawns its two ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    relays rank 0's JSON line as its only stdout and exits 0 -- the reference's launch line, README.md:33-38.  Both ranks
+    share device 0 under gloo (MSML_BENCH_ONE_GPU=1): the multi-rank control flow (label prefetch, OSB backward under the
+    head's collectives, bucketed gradient all-reduce, max-over-ranks timing), not a measurement."""
+    import json
+    import os
+    if bench2_result is None:
+        pytest.skip("bench child was not started (session not selected with -m gpu)")
+    proc, outdir = bench2_result
+    try:
+        rc = proc.wait(timeout=600)
+    except Exception:
+        proc.terminate()
+        raise AssertionError("bench.py --gpus 2 did not finish: " + open(os.path.join(outdir, "bench2.err")).read()[-3000:])
+    err = open(os.path.join(outdir, "bench2.err")).read()
+    assert rc == 0, err[-3000:]
+    lines = [ln for ln in open(os.path.join(outdir, "bench2.out")).read().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 64 and rec["value"] > 0
+    assert rec["unit"] == "images/sec" and np.isfinite(rec["loss"])

@@ -56,7 +56,9 @@ def test_train_step_g4_bf16_fused_path(variant, bs):
     m = hip_msml("iresnet18", 1000, fp16=True)
     if variant == "refinit":
         refinit_frb_convs(m)
-    tol = bf16_tolerances(FLOOR_CASE[(variant, bs)])
+    # (batch 4: BatchNorm over four images -- the EMULATED bf16 floor of the early-FRB gradients already has a median
+    # of 0.31-0.38 over the rounding draws, above the 0.35 cap the batch >= 8 tests use; cap 0.5 here)
+    tol = bf16_tolerances(FLOOR_CASE[(variant, bs)], cap=0.5 if bs == 4 else 0.35)
     x, msk = eval_inputs(bs)
     label = synthetic.labels(bs, 1000, seed=1)
     m.train()
@@ -164,6 +166,48 @@ def test_fm_none_layers():
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in mb.parameters() if p.grad is not None)
     assert mb.frb.fm_ops[1].__class__.__name__ == "FMNone"
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_fm_visualisation_hooks_as_qeval_is_vis(tmp_path, fp16):
+    """The call sequence of eval/qeval_mxnet.py --is_vis (:290-293 en_save on every fm_op, :332-334 forward, :366-375
+    mask from final_seg, plot_intermediate_features per stage): the saved 'contaminated' / 'mask' / 'purified' vectors
+    (fmoperator.py:289-305, NCHW order) equal the oracle's hooked tensors, and both scatter plots of every stage are
+    written.  f32 and the fp16=True default (split-bf16 storage)."""
+    torch.manual_seed(0)
+    o = fill_module(om.MSML("iresnet18", "unet", (1, 1, 1, 1), 100, fm_params=(3, 2, "sigmoid", "mul"),
+                            header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0))).eval()
+    m = hip_msml("iresnet18", 100, fp16=fp16).eval()
+    x, _ = eval_inputs(2)
+    got = {}
+    hooks = []
+    for k in range(4):
+        op = o.frb.fm_ops[k]
+        hooks.append(op.register_forward_pre_hook(lambda mod, inp, k=k: got.__setitem__(("yf", k), inp[0].detach())))
+        hooks.append(op.res_block.register_forward_hook(lambda mod, inp, out, k=k: got.__setitem__(("x", k), out.detach())))
+    for k in range(4):
+        m.frb.fm_ops[k].en_save = True
+    with torch.no_grad():
+        o(x)
+        _, seg = m(x.cuda())
+    for h in hooks:
+        h.remove()
+    mask = Fh.mask_index(seg).cpu()
+    tol = 1e-4 if fp16 else 1e-5
+    for k in range(4):
+        op = m.frb.fm_ops[k]
+        yf, pre = got[("yf", k)].numpy().reshape(-1), got[("x", k)]
+        mk = torch.sigmoid(pre).numpy().reshape(-1)
+        assert rel_err(op.contaminated_feat, yf) < tol
+        assert rel_err(op.mask_feat, mk) < tol
+        assert rel_err(op.purified_feat, yf * mk) < tol
+        paths = op.plot_intermediate_features(gt_occ_msk=mask, save_folder=str(tmp_path))
+        assert [os.path.basename(q) for q in paths] == ["fm_cm_%d_mul.jpg" % op.height, "fm_cp_%d_mul.jpg" % op.height]
+        assert all(os.path.getsize(q) > 1000 for q in paths)
+    # a stage that never saw a forward pass with en_save says so
+    fresh = hip_msml("iresnet18", 100).frb.fm_ops[0]
+    with pytest.raises(RuntimeError, match="en_save"):
+        fresh.plot_intermediate_features(mask, str(tmp_path))
 
 
 def test_partial_fc_hip_checkpoint_roundtrip(tmp_path):
@@ -303,6 +347,17 @@ def test_partial_fc_hip_negative_sampling_flat_sgd():
         assert rel_err(pa.weight_mom.cpu().numpy(), pb.weight_mom.cpu().numpy()) < 1e-5, rate
         if rate == 0.005:
             assert pa._k is not None and pa._k > pa.num_sample              # kept exactly the positives
+    # prefetch_labels() before the optimizer was adopted: a clear error, not an orphaned arena parameter;
+    # a clipping head optimizer is refused (rows beyond k would enter the norm)
+    pc = PartialFC(0, 0, 1, PFC_B, False, ArcMargin(64.0, 0.48, 0.0, 0.0), PFC_C, sample_rate=0.3, embedding_size=PFC_E)
+    oc = FlatSGD([{"params": [pc.flat_parameter()], "lr": lr}], 0.9, 5e-4, None)
+    with pytest.raises(RuntimeError, match="adopt_flat_optimizer"):
+        pc.prefetch_labels(label.cuda())
+    pc.adopt_flat_optimizer(oc)
+    pc.prefetch_labels(label.cuda())
+    pd = PartialFC(0, 0, 1, PFC_B, False, ArcMargin(64.0, 0.48, 0.0, 0.0), PFC_C, sample_rate=0.3, embedding_size=PFC_E)
+    with pytest.raises(ValueError, match="max_norm"):
+        pd.adopt_flat_optimizer(FlatSGD([{"params": [pd.flat_parameter()], "lr": lr}], 0.9, 5e-4, 5.0))
     # checkpoint from the sampled flat state
     pa.save_params()
     import os as _os
