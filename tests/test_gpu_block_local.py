@@ -9,7 +9,7 @@ actual bf16 input, the BatchNorm coefficients it saved, the gradient it received
 parameter gradients are read from the flat arena (every parameter is used once, the arena was zeroed).  ONE block is
 then recomputed in f64 torch on the CPU (the oracle's block class, filled with the HIP model's parameters) from those
 same tensors, and dX, dW, dgamma, dbeta, dalpha and the saved statistics must agree to what bf16 storage costs THAT
-block on THOSE operands: the bound of every quantity is 3 x the error of the same block recomputed on the CPU under
+block on THOSE operands: the bound of every quantity is 2 x the error of the same block recomputed on the CPU under
 the bf16 rounding model of oracle/bf16_emul.py (three draws) -- a few per cent for an IBasicBlock, 5-7 % for the FM
 bottlenecks' weight gradients (three BatchNorm backward projections in a row), instead of the 20-35 % of the global
 comparison.  The error no longer compounds, so a missing or mis-scaled term shows: test_local_check_catches_an_injected_fault runs the same check with the identity-path gradient
@@ -35,7 +35,7 @@ from tests.helpers import rel_err
 pytestmark = pytest.mark.gpu
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
 # bound = FLOOR_X x (the block's own emulated bf16 error, worst of three draws) + an absolute term
-FLOOR_X, NORM_ABS, FRAC_ABS, CHAN_ABS, ELEM_TOL, STAT_TOL = 3.0, 5e-3, 5e-4, 1e-2, 5e-2, 1e-2
+FLOOR_X, NORM_ABS, FRAC_ABS, CHAN_ABS, ELEM_TOL, STAT_TOL = 2.0, 5e-3, 5e-4, 1e-2, 5e-2, 1e-2
 
 
 def _step_with_taps(frb, bs, fault=""):
@@ -115,7 +115,7 @@ def _check_block(kind, name, mod, t, grads):
     """Recompute ONE block from the tensors its HIP backward consumed: in f64 (the truth) and, for the bound, in f32
     under the bf16 rounding model of oracle/bf16_emul.py (every stored activation / activation gradient rounded, bf16
     conv operands -- plain PyTorch hooks, no HIP code) for three draws of the rounding noise.  The emulation's own
-    error against f64 is what bf16 storage costs THIS block on THESE operands; the HIP block must stay within 3 x the
+    error against f64 is what bf16 storage costs THIS block on THESE operands; the HIP block must stay within 2 x the
     worst draw (+ a small absolute term).  Returns rows (what, hip error, bound) for tensors (norm-wise), element
     fractions, per-channel gradients, and the saved statistics.
     A per-channel parameter gradient is a sum over N*H*W terms that largely cancel (the shift of a BatchNorm in front
@@ -227,7 +227,7 @@ def test_deep_bf16_backward_block_by_block_f64(frb, bs, n_iblocks):
     assert n_i == n_iblocks and n_b == 8, (n_i, n_b)
     assert not _bad(rows), _bad(rows)[:10]
     # the bounds themselves stay small: a local bound has power (the global ones sit at 0.2-0.35)
-    assert max(b for _, _, b in rows["norm-wise"]) < 0.25
+    assert max(b for _, _, b in rows["norm-wise"]) < 0.15
 
 
 def test_local_check_catches_an_injected_fault():
@@ -239,7 +239,7 @@ def test_local_check_catches_an_injected_fault():
     dx = {n[:-3]: (e, b) for n, e, b in rows["norm-wise"] if n.endswith(".dx")}
     faulty = [n for n, mod in m.named_modules() if n in dx and hasattr(mod, "downsample") and mod.downsample is None]
     assert len(faulty) == 4 + 4 and len(dx) == n_i + n_b                 # FRB + OSB: the second block of each stage
-    assert all(dx[n][0] > 3 * dx[n][1] and dx[n][0] > 0.3 for n in faulty), {n: dx[n] for n in faulty}
+    assert all(dx[n][0] > 5 * dx[n][1] and dx[n][0] > 0.3 for n in faulty), {n: dx[n] for n in faulty}
     bad = _bad(rows)
     assert {r[1] for r in bad if r[0] == "norm-wise"} == {n + ".dx" for n in faulty}, bad[:12]
     assert all(r[1].endswith(".dx") and r[1][:-3] in faulty for r in bad), bad[:12]
