@@ -42,7 +42,9 @@ struct ConvWsArgs {
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // XF: forward launch whose input is PReLU(in * xin.scale + xin.shift), applied to each image in LDS.
-template <bool FUSE, bool XF = false>
+// M16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (see conv_halo.hip): 8 accumulator tiles of 16 channels x 16
+// pixels per wave, the 18 32-deep windows of a tile as one software pipeline; chunk key p & 7.
+template <bool FUSE, bool XF = false, bool M16 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_ws(const ConvWsArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int C = 64, PL2 = 4, PITCH = 16, TW = 14, TH = 14, BM = 224, NT = 512;
@@ -60,6 +62,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int kg = wave & 1, mg = wave >> 1;             // channel group (32), pixel-row group
   const int i0 = 2 * mg, nmt = mg < 3 ? 2 : 1;         // this wave's 32-pixel tiles [i0, i0 + nmt)
   const int r32 = lane & 31, h = lane >> 5;
+  const int l16 = lane & 15, q16 = lane >> 4;          // M16: row inside a 16-group, 8-deep k block
+  static_assert(!M16 || !XF, "the 16x16x32 variant serves the plain and FUSE launches");
+  auto skey = [](int p_) { return M16 ? (p_ & 7) : ((p_ >> 1) & 7); };      // chunk swizzle of LDS row p (conv_halo.hip)
   const int tpi = p.tpy * p.tpx;
 
   __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
@@ -69,7 +74,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
   for (int i = 0; i < 9; i++) {
     const int j = wave + i * 8, tap = j >> 3, row = (j & 7) * 8 + (lane >> 3);
-    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    const int logical = (lane & 7) ^ skey(row);
     const unsigned int off = (unsigned int)(row * 576 + tap * 64) * 2u + logical * 16u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(Ws + j * 1024), 16, off, 0, 0, 0);
   }
@@ -82,7 +87,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int i = 0; i < 4; i++) {
       const int j = wave + i * 8;
       const int hp = j * 8 + (lane >> 3);
-      const int logical = (lane & 7) ^ ((hp >> 1) & 7);
+      const int logical = (lane & 7) ^ skey(hp);
       const int iy = y0 + (hp >> PL2) - 1, ix = x0 + (hp & (PITCH - 1)) - 1;
       const bool v = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
       const unsigned int off = v ? (unsigned int)((n * p.H + iy) * p.W + ix) * (unsigned int)(C * 2) + logical * 16u : WS_OOB;
@@ -114,7 +119,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) bfr[kk] = row * 128 + (((kk * 2 + h) ^ ((row >> 1) & 7)) << 4);
   }
-  const int kb = kg * 32 + 4 * h;                      // this lane's output channels: kb + 8 g + j
+  int bfr16[2][2];                                     // M16: weights row kg * 32 + 16 g + l16, chunk 4 w + q16
+#pragma unroll
+  for (int g = 0; g < 2; g++)
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const int row = kg * 32 + 16 * g + l16;
+      bfr16[g][w] = row * 128 + (((4 * w + q16) ^ skey(row)) << 4);
+    }
+  // this lane's output channels: kb + 8 g + j, g < 4 (M16: kb + 16 g + j, g < 2)
+  const int kb = M16 ? kg * 32 + 4 * q16 : kg * 32 + 4 * h;
   const int c8 = t % C8;
 
   // epilogue coefficients and the accumulators that live across all tiles of this workgroup
@@ -122,7 +136,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   f32x4 bv[4], sv[4], av[4], s1[4], s2[4];
 #pragma unroll
   for (int g = 0; g < 4; g++) {
-    const int col = kb + 8 * g;
+    const int col = kb + (M16 ? 16 * (g & 1) : 8 * g);
     bv[g] = (!FUSE && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     sv[g] = (!FUSE && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + col) : f32x4{1.f, 1.f, 1.f, 1.f};
     av[g] = act_here ? *reinterpret_cast<const f32x4*>(p.alpha + col) : f32x4{1.f, 1.f, 1.f, 1.f};
@@ -167,10 +181,51 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __builtin_amdgcn_sched_barrier(0);
 
     f32x16 acc[2];
+    f32x4 acc4[4][2];                                  // M16: [16-pixel group][channel half]
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int g = 0; g < 2; g++) acc4[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (M16) {
+      // 9 taps x two 32-deep windows = 18 pipeline steps; the fragments of step k + 1 (4 pixel groups + 2 weight
+      // halves) are requested before the 8 MFMAs of step k -- weights and image are resident, nothing to wait for
+      const int ng = 2 * nmt;
+      const char* Abase = As + cur * ABYTES + i0 * 32 * 128;
+      u32x4 a16[2][4], b16[2][2];
+      auto frags = [&](int step, u32x4 (&a)[4], u32x4 (&b)[2]) {
+        const int tap = step >> 1, w = step & 1;
+        const int tr = tap / 3, ts = tap - tr * 3;
+        const int r = p.flip ? 2 - tr : tr, sft = p.flip ? 2 - ts : ts;
+        const int arow = l16 + sft;
+        const char* Arow = Abase + ((r << PL2) + arow) * 128 + (((4 * w + q16) ^ skey(arow)) << 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < ng) a[j] = *reinterpret_cast<const u32x4*>(Arow + j * 2048);
+#pragma unroll
+        for (int g = 0; g < 2; g++) b[g] = *reinterpret_cast<const u32x4*>(Ws + tap * 8192 + bfr16[g][w]);
+      };
+      frags(0, a16[0], b16[0]);
+#pragma unroll
+      for (int step = 0; step < 18; step++) {
+        const int cb = step & 1, nb = cb ^ 1;
+        if (step + 1 < 18) frags(step + 1, a16[nb], b16[nb]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (j < ng) {
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+              acc4[j][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b16[cb][g]),
+                                                                   __builtin_bit_cast(bf16x8, a16[cb][j]), acc4[j][g],
+                                                                   0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     const char* Abase = As + cur * ABYTES + i0 * 32 * 128;
     u32x4 a[2][2], b[2];
     for (int tap = 0; tap < 9; tap++) {
@@ -206,10 +261,40 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    }
     __syncthreads();     // every wave is done with image `cur`; the next image has landed (vmcnt drained)
 
     // ---- epilogue: affine / PReLU / statistics in registers, transpose through the consumed image
     unsigned short* otile = reinterpret_cast<unsigned short*>(As + cur * ABYTES);
+    if constexpr (M16) {
+#pragma unroll
+      for (int jg = 0; jg < 4; jg++) {
+        if (jg >= 2 * nmt) break;
+        const int m = i0 * 32 + jg * 16 + l16;
+        const bool valid = pix_ok(m);
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            float z = acc4[jg][g][j];
+            if (!FUSE) {
+              z = z * sv[g][j] + bv[g][j];
+              if (act_here) z = z > 0.f ? z : z * av[g][j];
+            }
+            v[j] = z;
+            if (!FUSE && valid) {
+              s1[g][j] += z;
+              s2[g][j] += z * z;
+            }
+          }
+          u32x2 pk;
+          pk[0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
+          pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
+          *reinterpret_cast<u32x2*>(otile + m * OP + kb + 16 * g) = pk;
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       if (i >= nmt) break;
@@ -236,6 +321,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
         *reinterpret_cast<u32x2*>(otile + m * OP + kb + 8 * g) = pk;
       }
+    }
     }
     __syncthreads();
 #pragma unroll
@@ -283,7 +369,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   if (!FUSE && p.stats) {
     float* red = reinterpret_cast<float*>(smem) + wave * 64 * 33;
 #pragma unroll
-    for (int g = 0; g < 4; g++)
+    for (int g = 0; g < (M16 ? 2 : 4); g++)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         red[lane * 33 + g * 4 + j] = s1[g][j];
@@ -291,13 +377,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
     __syncthreads();
     if (mg == 0) {                                     // waves 0 / 1 add the four pixel-row groups
-      const int which = lane >> 5, kl = lane & 31;     // channel kl = 8 g + 4 hh + j
-      const int k = which * 16 + (kl >> 3) * 4 + (kl & 3), hh = (kl >> 2) & 1;
+      const int which = lane >> 5, kl = lane & 31;
       float sum = 0.f;
+      if constexpr (M16) {                             // channel kl = 16 g + 4 q + j lives in the 16 lanes 16 q + rr
+        const int k = which * 16 + (kl >> 4) * 4 + (kl & 3), qq = (kl >> 2) & 3;
 #pragma unroll
-      for (int gm = 0; gm < 4; gm++)
+        for (int gm = 0; gm < 4; gm++)
 #pragma unroll 8
-        for (int rr = 0; rr < 32; rr++) sum += red[gm * 2 * 64 * 33 + (hh * 32 + rr) * 33 + k];
+          for (int rr = 0; rr < 16; rr++) sum += red[gm * 2 * 64 * 33 + (qq * 16 + rr) * 33 + k];
+      } else {                                         // channel kl = 8 g + 4 hh + j
+        const int k = which * 16 + (kl >> 3) * 4 + (kl & 3), hh = (kl >> 2) & 1;
+#pragma unroll
+        for (int gm = 0; gm < 4; gm++)
+#pragma unroll 8
+          for (int rr = 0; rr < 32; rr++) sum += red[gm * 2 * 64 * 33 + (hh * 32 + rr) * 33 + k];
+      }
       stats_emit(p.stats, p.stats_acc, blockIdx.x, which, C, kg * 32 + kl, sum);
     }
     for (int row = gridDim.x + blockIdx.x; !p.stats_acc && row < p.stats_rows; row += gridDim.x)
@@ -329,17 +423,17 @@ bool msml_conv_ws_applies(int c0p, int kop, int coutp, int N, int H, int W, int 
   return (long)N * H * W * c0p * 2 < 0x70000000L && tiles < (1L << 30);
 }
 
-template <bool FUSE, bool XF = false>
+template <bool FUSE, bool XF = false, bool M16 = false>
 static void launch_ws(ConvWsArgs& a, hipStream_t st) {
   // (+ the 2 pixels the padding rows read past an image, + the input-transform coefficient table)
   const size_t lds = 9 * 64 * 128 + 2 * 256 * 128 + 512 + (XF ? 3 * 64 * sizeof(float) : 0);
   static std::once_flag attr_once;                     // (per template instantiation; launches come from
   std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_ws<FUSE, XF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_ws<FUSE, XF, M16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   const int wgs = a.ntiles < ws_num_cus() ? a.ntiles : ws_num_cus();
-  k_conv_ws<FUSE, XF><<<dim3(wgs), dim3(512), lds, st>>>(a);
+  k_conv_ws<FUSE, XF, M16><<<dim3(wgs), dim3(512), lds, st>>>(a);
 }
 
 // Tried by msml_conv_fast_dispatch before the im2col kernel; false = shape not covered here.
@@ -368,8 +462,11 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
   a.xin = BnIn{nullptr, nullptr, nullptr};
   if (xin) a.xin = *xin;
   if (bnb_rows) *bnb_rows = a.ntiles < ws_num_cus() ? a.ntiles : ws_num_cus();
+  // 16x16x32 variant: measured neutral here (64 -> 64 @ 112x112 forward 426 -> 408 us, backward-data and the 56x56 maps
+  // +-1 %: this kernel waits on its image loads and transposes, not on the MFMA clock) -- opt-in, MSML_WS_M16=1
+  static const bool m16 = getenv("MSML_WS_M16") && atoi(getenv("MSML_WS_M16")) != 0;
   if (xin) launch_ws<false, true>(a, st);
-  else if (bnb) launch_ws<true>(a, st);
-  else launch_ws<false>(a, st);
+  else if (bnb) { if (m16) launch_ws<true, false, true>(a, st); else launch_ws<true>(a, st); }
+  else { if (m16) launch_ws<false, false, true>(a, st); else launch_ws<false>(a, st); }
   return true;
 }

@@ -488,8 +488,10 @@ def test_conv_bn_in_lds_matches_unfused(shape, with_alpha):
     ref, rstats = ops.conv2d(act, None, wp, None, cout, 3, 3, 1, 1, 1, False, want_stats=True)
     got, gstats = ops.conv2d_bnin(x, coef, alpha, wp, cout)
     assert torch.equal(got, ref)
-    # (partial rows from the bnin kernel, f64 accumulator from the plain conv under ops.ACC_STATS: same totals)
-    assert torch.allclose(gstats.double().sum(0), rstats.double().sum(0), rtol=1e-12, atol=0)
+    # (partial rows from the bnin kernel, f64 accumulator from the plain conv under ops.ACC_STATS: the same totals up
+    # to the order of the per-workgroup f32 sums -- the plain conv runs the 16x16x32 MFMA tiling since round 4, the
+    # bnin instantiation the 32x32x16 one: identical outputs, another lane-to-pixel map in the statistics epilogue)
+    assert torch.allclose(gstats.double().sum(0), rstats.double().sum(0), rtol=1e-5, atol=1e-4)
     # weight gradient
     dy = ops.to_nhwc(torch.randn(n, cout, h, w_, generator=g).cuda(), _lib.BF16)
     assert _lib.value("msml_conv_wgrad_bnin_applies", cout, cin, cout, cin, n, h, w_, h, w_, 3, 3, 1, 1, 1) == 1
