@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # MI355X_MICROARCH.md (dense)
-ROUND = "r03"                                     # PMC summaries of OTHER rounds are never quoted (kernels change)
+ROUND = "r04"                                     # PMC summaries of OTHER rounds are never quoted (kernels change)
 # forward GFLOP per image (hooks on the imported reference); F_train = 3 x F_fwd (section 3)
 F_FWD_GF = {"iresnet18": 8.446, "iresnet34": 12.146, "iresnet50": 15.845, "iresnet100": 27.406}
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
@@ -283,6 +283,18 @@ def pmc_traffic(label):
         if isinstance(v, dict) and "hbm_bytes" in v and (k == label or k.split(" [")[0] == base):
             return v["hbm_bytes"], os.path.relpath(path, ROOT)
     return None, None
+
+
+def pmc_family(family):
+    """(average HBM bytes per launch, launches per step, source file) of a kernel family ('conv', 'wgrad') from THIS
+    round's whole-step PMC summary (profiles/<ROUND>_pmc_step.json, tools/pmc_step.py: FETCH_SIZE / WRITE_SIZE passes over
+    `bench.py --steps 2`, summed over every kernel of the family); (None, None, None) without current counters."""
+    path = os.path.join(ROOT, "profiles", "%s_pmc_step.json" % ROUND)
+    try:
+        f = json.load(open(path))["families"][family]
+        return f["hbm_bytes_per_launch"], f["launches_per_step"], os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None, None
 
 
 def memory_table(runner, args):
@@ -690,9 +702,10 @@ def main():
                                      {"ms": 1e-9, "n": 1, "flops": 0.0, "bytes": 0.0})
         k = fam["conv_igemm"]
         ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        ftraffic, _, fsrc = pmc_family("conv") if args.mode == "train" and args.dtype == "bf16" else (None, None, None)
         rec["roofline_family"] = {"bound": "mfma", "kernel": "k_conv_halo / k_conv_fast / k_conv_igemm (conv fwd + dgrad, every shape of the step)",
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": None,
+                           "frac": round(ach / peak, 4), "traffic": ftraffic, "traffic_source": fsrc,
                            "launches": k["n"], "avg_us": round(k["ms"] * 1e3 / k["n"], 2)}
         # the dominant launch of the step over conv forward / backward-data AND weight-gradient labels
         # (one shape, one kernel): achieved from its own events, HBM traffic from the committed rocprofv3
@@ -721,9 +734,11 @@ def main():
         if "conv_wgrad" in fam:
             kw = fam["conv_wgrad"]
             aw = kw["flops"] / (kw["ms"] * 1e-3) / 1e12
+            wtraffic, _, wsrc = pmc_family("wgrad") if args.mode == "train" and args.dtype == "bf16" else (None, None, None)
             rec["roofline_family_wgrad"] = {"bound": "mfma", "kernel": "k_wgrad_halo / k_wgrad_fast (+ slab reduce)",
                                             "achieved": round(aw, 2), "peak": peak, "unit": "TFLOP/s",
-                                            "frac": round(aw / peak, 4), "launches": kw["n"],
+                                            "frac": round(aw / peak, 4), "traffic": wtraffic, "traffic_source": wsrc,
+                                            "launches": kw["n"],
                                             "avg_us": round(kw["ms"] * 1e3 / kw["n"], 2)}
         rec["kernels"] = {name: {"ms_per_step": round(v["ms"] / prof_steps, 3), "launches_per_step": v["n"] // prof_steps,
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,

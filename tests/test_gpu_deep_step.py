@@ -25,6 +25,7 @@ from tests.helpers import assert_cs, bf16_tolerances, cosine, elem_err, load, pi
 
 pytestmark = pytest.mark.gpu
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
+COS_MIN = 0.94       # cosine similarity of a picked bf16 gradient with the reference's (see test_deep_train_step_bf16_fused)
 
 
 def hip_msml(frb, C=1000, fp16=False):
@@ -80,8 +81,8 @@ def test_deep_train_step_f32(frb, bs):
 def test_deep_train_step_bf16_fused(frb, bs):
     """The path bench.py times (bf16, one-node blocks, BatchNorm backward sums from the backward-data epilogues,
     side streams, FlatSGD) on the deep FRBs against the reference golden: every picked gradient norm-wise within
-    min(3 x median emulated bf16 floor of its group, 0.35), cosine similarity >= 0.95, element-wise within 2 x the
-    norm-wise bound.  (The ires100 batch-4 golden stays an exact-f32 case only: BatchNorm1d over four samples in front
+    min(3 x median emulated bf16 floor of its group, 0.35), cosine similarity >= 0.94 (what a norm-wise error of 0.35
+    orthogonal to the gradient leaves: 1 / sqrt(1 + 0.35^2) = 0.944), element-wise within 2 x the norm-wise bound.  (The ires100 batch-4 golden stays an exact-f32 case only: BatchNorm1d over four samples in front
     of an s = 64 head makes single bf16 rounding draws differ by 2-3 x, no bf16 bound on it means anything.  The
     block-by-block f64 check of the same step is tests/test_gpu_block_local.py.)"""
     short = frb.replace("iresnet", "ires")
@@ -126,7 +127,7 @@ def test_deep_train_step_bf16_fused(frb, bs):
             e, ee, cs = rel_err(got, g[key]), elem_err(got, g[key]), cosine(got, g[key])
             t = tol[param_group(n)]
             report.append((e / t, e, t, n, ee, cs))
-            if e >= t or cs < 0.95 or ee >= 2 * t:
+            if e >= t or cs < COS_MIN or ee >= 2 * t:
                 bad.append((n, e, t, ee, cs))
     report.sort(reverse=True)
     print("bf16 fused deep step %s b%d: gnorm %.4f vs %.4f (%.2e, tol %.1e); seg %.5f / %.5f cls %.5f / %.5f (tol %.1e)"

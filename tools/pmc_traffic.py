@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""profiles/<round>_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/pmc_shapes.py:
+HBM bytes per LAUNCH of the dominant launches of the step, keyed by the labels bench.py gives them.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_shapes/fetch -- python3 tools/pmc_shapes.py
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_shapes/write -- python3 tools/pmc_shapes.py
+    python3 tools/pmc_traffic.py gpurun_out/pmc_shapes profiles/r04_pmc_traffic.json
+
+pmc_shapes.py issues, per repetition: forward conv, backward-data conv + BatchNorm sums, weight gradient of ONE layer
+(k_wgrad_halo + k_wgrad_reduce_rows), weight gradient of FOUR layers in one launch pair -- the two weight-gradient
+launches share kernel names and are told apart by dispatch order.  hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950
+counts wide reads at half their bytes, MI355X_MICROARCH.md, HBM)."""
+import csv
+import glob
+import json
+import re
+import sys
+
+N, C, H = 256, 256, 14
+ACT = N * H * H * C * 2                 # one bf16 activation tensor
+WB = C * C * 9 * 2                      # packed bf16 weights
+DW = C * C * 9 * 4                      # f32 gradient
+
+
+def rows(d):
+    out = []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            out.append((int(r["Dispatch_Id"]), r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])))
+    return sorted(out)
+
+
+def per_kind(d, counter):
+    """{kind: [value per dispatch]} in dispatch order."""
+    seq = {}
+    for _, name, cn, val in rows(d):
+        if cn != counter:
+            continue
+        kind = None
+        m = re.search(r"k_conv_halo<\d+, \d+, (true|false)", name)       # third template argument = FUSE
+        if m:
+            kind = "dgrad" if m.group(1) == "true" else "fwd"
+        elif "k_wgrad_halo" in name:
+            kind = "wgrad"
+        elif "k_wgrad_reduce" in name:
+            kind = "reduce"
+        if kind:
+            seq.setdefault(kind, []).append(val)
+    return seq
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    f, w = per_kind(src + "/fetch", "FETCH_SIZE"), per_kind(src + "/write", "WRITE_SIZE")
+    mean = lambda v: sum(v) / max(len(v), 1)      # noqa: E731
+    out = {"_comment": __doc__.split("\n\n")[0].replace("\n", " ") + "  Collected by the two commands in tools/pmc_traffic.py; "
+           "distinct 51 MB operand sets per repetition so that the counters see HBM, not L2 hits."}
+
+    def entry(label, kernel, fk, wk, alg, note):
+        out[label] = {"kernel": kernel, "fetch_size_kb": round(fk), "write_size_kb": round(wk),
+                      "hbm_bytes": int((2 * fk + wk) * 1024), "algorithmic_bytes": alg, "note": note}
+    halo = "[k_conv_halo<14x14 px x 256 ch, 8 waves>]"
+    entry("conv T+bnb c256+0->256 14x14 k3x3 s1 n256 " + halo, "k_conv_halo<256, 1, FUSE, 16x16x32 MFMA>",
+          mean(f["dgrad"]), mean(w["dgrad"]), 3 * ACT + WB,
+          "backward-data conv with the fused BatchNorm backward sums: dY + saved BatchNorm input read, dX written")
+    entry("conv N c256+0->256 14x14 k3x3 s1 n256 " + halo, "k_conv_halo<256, 1, forward, 16x16x32 MFMA>",
+          mean(f["fwd"]), mean(w["fwd"]), 2 * ACT + WB, "forward conv + statistics: input once, output once")
+    # weight gradients: dispatches alternate one layer / four layers
+    for which, label, layers in ((0, "wgrad u256 v256 14x14 k3x3 s1 n256", 1), (1, "wgrad u256 v256 14x14 k3x3 s1 n256 x4", 4)):
+        fk = mean(f["wgrad"][which::2]) + mean(f["reduce"][which::2])
+        wk = mean(w["wgrad"][which::2]) + mean(w["reduce"][which::2])
+        entry(label, "k_wgrad_halo<128> + k_wgrad_reduce_rows (%d layer%s per launch pair)" % (layers, "s" * (layers > 1)),
+              fk, wk, layers * (2 * ACT + DW), "operands + split-K slabs written and re-read + the f32 gradient")
+    json.dump(out, open(dst, "w"), indent=1)
+    for k, v in out.items():
+        if isinstance(v, dict):
+            print("%-100s %6.1f MB = %.2f x algorithmic" % (k[:100], v["hbm_bytes"] / 1e6, v["hbm_bytes"] / v["algorithmic_bytes"]))
+
+
+if __name__ == "__main__":
+    main()
