@@ -13,7 +13,8 @@ import bench  # noqa: E402
 
 
 def main():
-    args = argparse.Namespace(frb="iresnet50", batch=256, classes=85742, dtype="bf16", mode="train")
+    args = argparse.Namespace(frb="iresnet50", batch=256, classes=85742, dtype="bf16", mode="train", emulate_world=1,
+                              data="resident")
     tr = bench.Trainer(args, 0, 0, 1)
     for _ in range(3):
         tr.step()
