@@ -141,7 +141,7 @@ k_conv_halo(const ConvHaloArgs p) {
     for (int i = 0; i < NAI; i++) {
       const int j = wave + i * NW;
       const int hp = j * 8 + (lane >> 3);
-      const int logical = (lane & 7) ^ ((hp >> 1) & 7);
+      const int logical = (lane & 7) ^ skey(hp);
       if (j < NAJ && aoff[i] != HALO_OOB)
         bn_in_chunk(a + j * 1024 + lane * 16, xtab, p.C, cs * 64 + logical * 8, has_alpha);
     }
@@ -156,7 +156,7 @@ k_conv_halo(const ConvHaloArgs p) {
 
   // D = W_frag x X_frag: accumulator rows = output channels, columns (lanes) = pixels, so a lane
   // ends up with 4 consecutive channels of one pixel per register quad (8-B LDS stores below)
-  static_assert(!M16 || (!XF && !X3), "the 16x16x32 variant serves the plain forward and FUSE launches");
+  static_assert(!M16 || !X3, "the 16x16x32 variant serves the plain forward, FUSE and XF launches");
   constexpr int NG = 2 * MTW, NGH = NG / 2;            // M16: 16-pixel groups of one wave (at most), per pipeline phase
   f32x16 acc[M16 ? 1 : MTW];
   f32x4 acc4[M16 ? NG : 1][2];                         // M16: [pixel group][channel half]: channels 16 g + 4 q + j
@@ -643,8 +643,11 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   // A/B on one box, LDS conflicts 0.7 %).  MSML_HALO_M16=0 restores the 32x32x16 kernels, 1 limits
   // the variant to the 256-channel tile.
   static const int m16 = getenv("MSML_HALO_M16") ? atoi(getenv("MSML_HALO_M16")) : 2;
-  if (m16 && !x3 && !xin && (wide || m16 >= 2)) {
-    if (bnb) {
+  if (m16 && !x3 && (wide || m16 >= 2)) {
+    if (xin) {                           // (same tiling as the plain launch: the two stay bit-identical)
+      if (wide) launch_halo<256, 1, false, true, false, true>(a, st);
+      else launch_halo<128, 2, false, true, false, true>(a, st);
+    } else if (bnb) {
       if (wide) launch_halo<256, 1, true, false, false, true>(a, st);
       else launch_halo<128, 2, true, false, false, true>(a, st);
     } else {
