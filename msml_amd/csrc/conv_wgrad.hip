@@ -597,6 +597,7 @@ bool msml_conv_fast_splitk(const void* in0, int c0p, const void* wp, int kop, fl
 // (msml_conv_wgrad_bnin_applies); MSML_ERR_UNSUPPORTED otherwise.
 extern "C" int msml_conv_wgrad_bnin_applies(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q,
                                             int R, int S, int stride, int pad_h, int pad_w) {
+  if (H == 7 && W == 7) return 0;      // (the image-pair strips of the 7 x 7 maps have no in-LDS BatchNorm variant)
   return msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w) > 0 ? 1 : 0;
 }
 
@@ -612,7 +613,7 @@ extern "C" int msml_conv_wgrad_bnin(const void* u, int up, const void* v, int vp
              vp, A, Breal, Btot, boff);
   MSML_CHECK(N > 0 && H > 0 && W > 0 && P > 0 && Q > 0, MSML_ERR_SHAPE, "conv_wgrad_bnin: bad dims");
   const int hs = msml_wgrad_halo_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w);
-  MSML_CHECK(hs > 0, MSML_ERR_UNSUPPORTED, "conv_wgrad_bnin: shape not covered by the strip kernel");
+  MSML_CHECK(hs > 0 && !(H == 7 && W == 7), MSML_ERR_UNSUPPORTED, "conv_wgrad_bnin: shape not covered by the strip kernel");
   long need = msml_conv_wgrad_workspace(up, vp, N, P, Q, R, S);
   MSML_CHECK(ws_bytes >= need, MSML_ERR_WORKSPACE, "conv_wgrad_bnin: workspace %ld < %ld bytes", ws_bytes, need);
   hipStream_t st = (hipStream_t)stream;

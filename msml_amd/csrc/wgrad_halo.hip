@@ -38,13 +38,16 @@ struct WgradHaloArgs {
   int nstrips, chunk;         // total strips, strips per split
   int zper;                   // splits per layer: grid.z = layers x zper, z = layer * zper + split
   int remap;                  // 1: XCD-aware workgroup order (all dW tiles of one z on one XCD's L2)
+  int pair7;                  // 7 x 7 maps: a strip = TWO images side by side (columns 0-6 | gap | 8-14): the P7 instantiation
   float* ws;                  // [z][up][9][vp]
   BnIn xin;                   // xin.scale != nullptr: X is PReLU(v * scale + shift), applied in LDS (common.h)
 };
 
 // CO = Cout rows per workgroup: 128 (a wave carries a pair of 32-row tiles) or 64 (one tile)
 // XF: the conv input X is a BatchNorm(+PReLU) of the stored tensor v; the strips are normalised in LDS
-template <int CO, bool XF = false>
+// P7: 7 x 7 maps, a strip = two images side by side (issue()); compile-time, the 128-row instantiation has no register
+// to spare (a run-time switch spilled three dwords: 940 -> 595 TFLOP/s on the 14 x 14 layers)
+template <int CO, bool XF = false, bool P7 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wgrad_halo(const WgradHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int GU = CO / 32, NI = CO / 64, UBLK = 7 * GU, NBLK = UBLK + 20, NISS = (NBLK + 7) / 8;
@@ -79,11 +82,41 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   // DMA slot of a lane inside a 1-KB block [16 px][64 B]: pixel lane / 4, 16-B chunk lane % 4
   const int lp = lane >> 2, lc = lane & 3;
+  // 7 x 7 maps (pair7): a strip is the PAIR of images 2 strip, 2 strip + 1 laid side by side on the 16-pixel pitch:
+  // dY columns 0-6 = image A, 7 = zero, 8-14 = image B, 15 = zero; X halo columns 0 = zero, 1-7 = A, 8 = zero (A's right
+  // and B's left padding at once), 9-15 = B, and "column 16" of a row is column 0 of the next one = zero.  Every tap
+  // offset of the k loop below then reads exactly the pixels a 7 x 7 conv with zero padding reads: 14 real k-values
+  // of 16 per strip row, as on the 14-wide maps, with no change to the MFMA loop.
   auto issue = [&](int strip, int buf) {
-    const int n = strip / spi, rem = strip - n * spi, sy = rem / p.spx;
-    const int y0 = sy * 7, x0 = (rem - sy * p.spx) * 14;
     char* ub = smem + buf * STAGE;
     char* vb = ub + UB;
+    if constexpr (P7) {
+      const int n = 2 * strip + (lp >> 3), x = lp & 7;  // image of the pair, column inside it (7 = the zero gap)
+      const bool img = n < p.N;
+#pragma unroll
+      for (int i = 0; i < NISS; i++) {
+        const int blk = wave + 8 * i;
+        if (blk >= NBLK) break;
+        if (blk < UBLK) {
+          const int j = blk / GU, g = blk % GU;
+          const unsigned int off = (img & (x < 7)) ? (unsigned int)((n * 7 + j) * 7 + x) * (unsigned int)(p.up * 2) +
+                                                         (unsigned int)(a0 + g * 32 + lc * 8) * 2u
+                                                   : WH_OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lptr_t)(ub + blk * 1024), 16, off, 0, 0, 0);
+        } else {
+          const int bb = blk - UBLK, hr = bb >> 1, g = bb & 1;
+          const int y = hr - 1;                          // halo columns 0 and 8 (x == 0) are the zero padding
+          const bool ok = img & ((unsigned)y < 7u) & (x > 0);
+          const unsigned int off = ok ? (unsigned int)((n * 7 + y) * 7 + x - 1) * (unsigned int)(p.vp * 2) +
+                                            (unsigned int)(b0 + g * 32 + lc * 8) * 2u
+                                      : WH_OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lptr_t)(vb + bb * 1024), 16, off, 0, 0, 0);
+        }
+      }
+      return;
+    }
+    const int n = strip / spi, rem = strip - n * spi, sy = rem / p.spx;
+    const int y0 = sy * 7, x0 = (rem - sy * p.spx) * 14;
 #pragma unroll
     for (int i = 0; i < NISS; i++) {
       const int blk = wave + 8 * i;                    // 7 GU dY blocks, then 20 X blocks
@@ -273,10 +306,12 @@ int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W
   if (off) return 0;
   if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return 0;
   if (up % 64 != 0 || vp % 64 != 0 || A != up || Breal != vp) return 0;
-  const long strips = (long)N * cdiv(H, 7) * cdiv(W, 14);
+  const bool pair7 = H == 7 && W == 7 && getenv("MSML_WGRAD_HALO_NO_PAIR7") == nullptr;   // two 7 x 7 images per strip
+  const long strips = pair7 ? (N + 1) / 2 : (long)N * cdiv(H, 7) * cdiv(W, 14);
   if ((long)N * H * W * 10 < strips * 112 * 7) return 0;           // < 70 % real k-values
   if ((long)N * H * W * up * 2 >= 0x70000000L || (long)N * H * W * vp * 2 >= 0x70000000L) return 0;
-  const int tiles = (wh_wide(up) ? up / 128 : up / 64) * (vp / 64);
+  // (image-pair strips: 64-row tiles only -- the 128-row instantiation of that variant spills)
+  const int tiles = ((wh_wide(up) && !pair7) ? up / 128 : up / 64) * (vp / 64);
   long splits = wh_cus() / tiles;                      // one resident workgroup per CU
   if (splits < 1) splits = 1;
   if (splits > strips) splits = strips;
@@ -284,16 +319,16 @@ int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W
   return (int)splits;
 }
 
-template <int CO, bool XF>
+template <int CO, bool XF, bool P7 = false>
 static void wh_launch(const WgradHaloArgs& a, dim3 grid, hipStream_t st) {
   // two stages of (7 dY row blocks per 32 Cout + 10 X rows x 2 channel groups) KB (+ coefficient table)
   const size_t lds = 2 * (7 * (CO / 32) + 10 * 2) * 1024 + (XF ? 3 * 64 * sizeof(float) : 0);
   static std::once_flag attr_once;                     // (per template instantiation; launches come from
   std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<CO, XF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<CO, XF, P7>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  k_wgrad_halo<CO, XF><<<grid, dim3(512), lds, st>>>(a);
+  k_wgrad_halo<CO, XF, P7><<<grid, dim3(512), lds, st>>>(a);
 }
 
 // splits per layer when `group` layers of this shape share one launch (0: not covered)
@@ -318,15 +353,21 @@ bool msml_wgrad_halo_launch_group(const void* const* u, int up, const void* cons
   a.up = up; a.u_bytes = (unsigned int)((long)N * H * W * up * 2);
   a.vp = vp; a.v_bytes = (unsigned int)((long)N * H * W * vp * 2);
   a.N = N; a.H = H; a.W = W; a.spy = cdiv(H, 7); a.spx = cdiv(W, 14);
-  a.nstrips = N * a.spy * a.spx;
+  a.pair7 = (H == 7 && W == 7) ? 1 : 0;
+  a.nstrips = a.pair7 ? (N + 1) / 2 : N * a.spy * a.spx;
   a.chunk = cdiv(a.nstrips, splits);
   a.zper = splits;
   a.ws = ws;
   a.xin = BnIn{nullptr, nullptr, nullptr};
   if (xin) a.xin = *xin;
   const int gz = group * splits;
-  const int tiles = (wh_wide(up) ? up / 128 : up / 64) * (vp / 64);
+  const int tiles = ((wh_wide(up) && !a.pair7) ? up / 128 : up / 64) * (vp / 64);
   a.remap = (!no_remap && tiles >= 4 && gz % 8 == 0) ? 1 : 0;
+  if (a.pair7) {
+    if (xin) return false;                             // (no in-LDS BatchNorm variant of the image-pair strips)
+    wh_launch<64, false, true>(a, dim3(up / 64, vp / 64, gz), st);
+    return true;
+  }
   if (wh_wide(up)) {
     if (xin) wh_launch<128, true>(a, dim3(up / 128, vp / 64, gz), st);
     else wh_launch<128, false>(a, dim3(up / 128, vp / 64, gz), st);

@@ -388,7 +388,9 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, with_alpha, acc_mode, monkey
 
 # (N, Cin, Cout, H, W): weight gradients routed to the strip / halo kernel (wgrad_halo.hip):
 # Cout % 128 == 0, Cin % 64 == 0, 3x3 s1 p1
-WGRAD_HALO = [(6, 64, 64, 14, 14), (9, 128, 64, 28, 28), (6, 64, 128, 14, 14), (5, 128, 128, 21, 28), (4, 128, 256, 13, 27), (40, 64, 128, 28, 28)]
+# (7 x 7 maps: two images per strip, side by side on the 16-pixel pitch -- odd batches leave the last strip half empty)
+WGRAD_HALO = [(6, 64, 64, 14, 14), (9, 128, 64, 28, 28), (6, 64, 128, 14, 14), (5, 128, 128, 21, 28), (4, 128, 256, 13, 27), (40, 64, 128, 28, 28),
+              (7, 128, 128, 7, 7), (10, 64, 128, 7, 7), (33, 256, 64, 7, 7), (1, 64, 64, 7, 7)]
 
 
 @pytest.mark.parametrize("accumulate", [False, True])
