@@ -501,6 +501,10 @@ def main():
     osb_stream = torch.cuda.Stream()
 
     def eager_mode(on):
+        # (MSML_BENCH_NO_SIDE_STREAMS=1: diagnostic -- everything on one stream; against a single-queue graph replay of
+        # the same sequence, MSML_GRAPH_SERIAL=1, the difference is the GPU idle time the host's issue rate causes)
+        if os.environ.get("MSML_BENCH_NO_SIDE_STREAMS"):
+            on = False
         ops.WGRAD_STREAM = side_stream if on else None
         ops.OSB_STREAM = osb_stream if on else None
 
