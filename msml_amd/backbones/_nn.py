@@ -7,8 +7,10 @@ import torch.nn as nn
 from .. import functional as Fh
 
 
-def conv(m, x0, x1=None, want_stats=False, c0=None, c1=0):
-    """Run nn.Conv2d / nn.ConvTranspose2d `m` on NHWC input(s).  x1: second concat segment."""
+def conv(m, x0, x1=None, want_stats=False, c0=None, c1=0, tee=False):
+    """Run nn.Conv2d / nn.ConvTranspose2d `m` on NHWC input(s).  x1: second concat segment.
+    tee: x0 has a second consumer -- also return an alias of x0 for it (Fh.conv_tee: the two gradients of x0 are summed
+    in the backward-data epilogue)."""
     deconv = isinstance(m, nn.ConvTranspose2d)
     cin = m.in_channels
     if c0 is None:
@@ -20,6 +22,8 @@ def conv(m, x0, x1=None, want_stats=False, c0=None, c1=0):
     cfg = {"deconv": deconv, "c0": c0, "c1": c1, "cout": m.out_channels, "stride": m.stride[0],
            "pad_h": m.padding[0], "pad_w": m.padding[1], "want_stats": want_stats}
     # packed operands are cached / refreshed by ops.PACKS (keyed on parameter version)
+    if tee:
+        return Fh.conv_tee(x0, x1, m.weight, m.bias, cfg)
     return Fh.conv(x0, x1, m.weight, m.bias, cfg)
 
 

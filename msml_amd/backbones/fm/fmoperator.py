@@ -155,7 +155,14 @@ class FMCnn(nn.Module):
         if yo is None:
             raise TypeError("FMCnn needs the OSB mask maps (use_osb=False only works with fm_layers=(0,0,0,0), "
                             "as in the reference: torch.cat((yf, None)) fails there)")
-        x, _ = conv(self.same_conv, yf, yo, c1=18)
+        tee = (torch.is_grad_enabled() and isinstance(yf, torch.Tensor) and yf.requires_grad
+               and yf.dtype == torch.bfloat16 and not self.use_ori and ops.FM_TEE)
+        if tee:
+            # yf feeds same_conv and the fused act / arith / skip kernel: its two gradients meet in same_conv's
+            # backward-data epilogue (no separate add pass over the feature map)
+            x, _, yf = conv(self.same_conv, yf, yo, c1=18, tee=True)
+        else:
+            x, _ = conv(self.same_conv, yf, yo, c1=18)
         x = self.res_block(x)
         if self.en_save:
             self._save_intermediate_features(yf, x)

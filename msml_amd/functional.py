@@ -67,6 +67,11 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        return _Conv._bwd(ctx, dy, ctx.needs_input_grad)
+
+    @staticmethod
+    def _bwd(ctx, dy, need):
+        """need: needs_input_grad as the caller wants it honoured (_ConvTee computes the first input's gradient itself)."""
         x0, x1, weight = ctx.saved_tensors
         cfg = ctx.cfg
         if dy is None:
@@ -81,7 +86,7 @@ class _Conv(torch.autograd.Function):
         w = weight.detach()
         n, h, wd, _ = x0.shape
         grads = [None, None]
-        if (deconv and x1 is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dtype == BF16
+        if (deconv and x1 is not None and need[0] and need[1] and dtype == BF16
                 and r == 4 and s == 4 and stride == 2 and ph == 1 and pw == 1 and x0.shape[3] == 32 and x1.shape[3] == 32
                 and dy.shape[3] == 32 and h == wd and h in (14, 28, 56)):
             # OSB decoder: both segments' input gradients from ONE pass over dY (msml_deconv4_bwd_data)
@@ -98,7 +103,7 @@ class _Conv(torch.autograd.Function):
         for i, (x, off, ci) in enumerate(((x0, 0, c0), (x1, c0, c1))):
             if grads[i] is not None:
                 continue
-            if x is None or not ctx.needs_input_grad[i]:
+            if x is None or not need[i]:
                 continue
             if deconv:      # backward-data of a transposed conv = strided conv of dy
                 wp = ops.PACKS.get(w, False, off, ci, 0, cout, cout, 0, dtype, owner=ctx.wobj)
@@ -109,7 +114,7 @@ class _Conv(torch.autograd.Function):
                 grads[i], _ = ops.conv2d(dy, None, wp, None, cpad(ci), r, s, stride, ph, pw, True,
                                          p=h, q=wd, real=(cout, ci))
         dw = None
-        if ctx.needs_input_grad[2]:
+        if need[2]:
             inplace = ops.inplace(ctx.wparam)
             dw = ctx.wparam.grad.view(w.shape) if inplace else torch.empty_like(w)
             side = ops.WGRAD_STREAM if inplace else None
@@ -132,7 +137,7 @@ class _Conv(torch.autograd.Function):
                 dw = None
                 ops.grad_ready(ctx.wparam)
         db = None
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+        if ctx.has_bias and need[3]:
             m = dy.numel() // dy.shape[-1]
             cp = dy.shape[-1]
             rows = ops.bn_stats_rows(m, cp)
@@ -149,6 +154,72 @@ class _Conv(torch.autograd.Function):
 def conv(x0, x1, weight, bias, cfg, wp=None):
     y, stats = _Conv.apply(x0, x1, weight, bias, cfg, wp)
     return y, (stats if stats.numel() else None)
+
+
+class _ConvTee(torch.autograd.Function):
+    """_Conv whose first input has a SECOND consumer: returns (y, statistics, alias of x0).  The caller hands the alias
+    to the other consumer; its gradient then arrives HERE and is summed with the conv's input gradient inside the
+    backward-data kernel's epilogue (msml_conv2d_fused with the other gradient as residual) instead of by a separate
+    element-wise add that autograd would issue for the fan-out (FMCnn: yf feeds same_conv AND the act / arith / skip
+    kernel, backbones/fm/fmoperator.py:284-306 of the reference)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, cfg, wp):
+        y, stats = _Conv.forward(ctx, x0, x1, weight, bias, cfg, wp)
+        ctx.mark_non_differentiable(stats)
+        return y, stats, x0.view_as(x0)
+
+    @staticmethod
+    def backward(ctx, dy, _dstats, dtee):
+        cfg = ctx.cfg
+        x0, x1, weight = ctx.saved_tensors
+        fused = None
+        if (dy is not None and dtee is not None and ctx.needs_input_grad[0] and not cfg["deconv"] and cfg["stride"] == 1
+                and dy.dtype == torch.bfloat16 and dtee.dtype == torch.bfloat16 and dtee.shape == x0.shape):
+            c0, cout = cfg["c0"], cfg["cout"]
+            r, s = weight.shape[2], weight.shape[3]
+            dyc = dy.contiguous()
+            wp = ops.PACKS.get(weight.detach(), True, 0, cout, 0, c0, cout, 0, BF16, owner=ctx.wobj)
+            n, h, wd, c0p = x0.shape
+            unit = _unit_coef(c0p, dy.device)
+            fused = torch.empty_like(x0)
+            name = "conv_igemm"
+            if ops.PROFILE.on:
+                name = ops.conv_label("T+add", dyc.shape[3], 0, c0p, n, dyc.shape[1], dyc.shape[2], h, wd, r, s, 1,
+                                      cfg["pad_h"], cfg["pad_w"], 1, BF16, BF16, False)
+            with ops.PROFILE.rec(name, 2.0 * n * h * wd * cout * c0 * r * s):
+                call("msml_conv2d_fused", dyc, dyc.shape[3], None, 0, wp, wp.shape[0], unit[0], unit[1], None,
+                     dtee.contiguous(), 0, fused, c0p, n, dyc.shape[1], dyc.shape[2], h, wd, r, s, 1, cfg["pad_h"],
+                     cfg["pad_w"], 1)
+        if fused is not None:
+            # the remaining gradients (second segment, dW, bias) as _Conv computes them, without the first input's
+            g = _Conv._bwd(ctx, dy, (False,) + tuple(ctx.needs_input_grad[1:]))
+            return (fused,) + tuple(g[1:])
+        g = _Conv._bwd(ctx, dy, ctx.needs_input_grad)
+        if dtee is not None and g[0] is not None:
+            g0 = torch.empty_like(g[0])
+            call("msml_add", g[0], dtee.contiguous(), g0, g0.numel(), DTYPE_OF[g0.dtype])
+            return (g0,) + tuple(g[1:])
+        return ((dtee if g[0] is None else g[0]),) + tuple(g[1:])
+
+
+_UNIT_COEF = {}
+
+
+def _unit_coef(cp, device):
+    """(ones, zeros) f32 [cp]: unit scale / zero shift of a fused conv epilogue that only adds its residual."""
+    key = (cp, device)
+    u = _UNIT_COEF.get(key)
+    if u is None:
+        u = _UNIT_COEF[key] = (torch.ones(cp, dtype=torch.float32, device=device),
+                               torch.zeros(cp, dtype=torch.float32, device=device))
+    return u
+
+
+def conv_tee(x0, x1, weight, bias, cfg, wp=None):
+    """conv() that also returns an alias of x0 for x0's other consumer (see _ConvTee)."""
+    y, stats, x0b = _ConvTee.apply(x0, x1, weight, bias, cfg, wp)
+    return y, (stats if stats.numel() else None), x0b
 
 
 class _BnAct(torch.autograd.Function):

@@ -373,6 +373,9 @@ OSB_STREAM = None
 BLOCK_FUNCTION = os.environ.get("MSML_NO_BLOCK_FUNCTION") is None
 BOTTLE_FUNCTION = os.environ.get("MSML_NO_BOTTLE_FUNCTION") is None       # FM resblock_bottle as one node
 FUSE_BN_BWD = os.environ.get("MSML_NO_FUSE_BN_BWD") is None
+# FMCnn: the two gradients of the stage input (same_conv path + act / arith / skip path) summed in same_conv's backward-data
+# epilogue instead of by autograd's fan-out add
+FM_TEE = os.environ.get("MSML_NO_FM_TEE") is None
 # 1x1 / stride-2 downsample backward kept compact and scatter-added by bn1's apply kernel
 SPARSE_DOWNSAMPLE_GRAD = os.environ.get("MSML_NO_SPARSE_DOWNSAMPLE_GRAD") is None
 

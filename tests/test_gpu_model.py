@@ -713,3 +713,41 @@ def test_block_chain_statistics_hand_off():
     assert rel_err(dx2.cpu().numpy(), dx1.cpu().numpy()) < 1.5e-2     # three bf16 blocks deep
     for k in g1:
         assert rel_err(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-2, k
+
+
+@pytest.mark.parametrize("cfg", [(6, 64, 56), (5, 128, 28), (4, 256, 14), (6, 512, 7)])
+def test_fm_stage_gradient_fan_out_summed_in_the_conv_epilogue(cfg):
+    """FMCnn (reference fmoperator.py:277-311): the stage input yf feeds same_conv AND the act / arith / skip kernel.
+    Fh.conv_tee sums its two gradients in same_conv's backward-data epilogue; against the plain graph, where autograd adds
+    them with an element-wise kernel: same forward bit for bit, d yf equal to one bf16 rounding (the fused sum rounds once,
+    the separate add twice), every parameter gradient identical."""
+    import copy
+    from msml_amd import ops
+    from msml_amd.backbones.fm.fmoperator import FMCnn
+    n, c, h = cfg
+    torch.manual_seed(sum(cfg))
+    fm = FMCnn(h, h, c, 3, 2, "sigmoid", "mul", {"use_ori": False}).cuda().train()
+    yf0 = ops.to_nhwc(torch.randn(n, c, h, h).cuda(), 1)
+    yo = ops.to_nhwc(torch.randn(n, 18, h, h).cuda(), 1)
+    dz, res = None, []
+    for tee in (False, True):
+        m = copy.deepcopy(fm)
+        yf = yf0.clone().requires_grad_(True)
+        old = ops.FM_TEE
+        ops.FM_TEE = tee
+        try:
+            # a producer node in front, as in the network (a leaf input would take the same path)
+            z, _ = m(Fh.add(yf, torch.zeros_like(yf)), yo)
+            if dz is None:
+                dz = torch.randn_like(z)
+            z.backward(dz)
+        finally:
+            ops.FM_TEE = old
+        torch.cuda.synchronize()
+        res.append((z.detach().clone(), yf.grad.clone(), {k: v.grad.clone() for k, v in m.named_parameters()}))
+    (z1, g1, p1), (z2, g2, p2) = res
+    assert torch.equal(z1, z2)
+    assert rel_err(g2.float().cpu().numpy(), g1.float().cpu().numpy()) < 4e-3
+    assert elem_err(g2.float().cpu().numpy(), g1.float().cpu().numpy()) < 1e-2
+    for k in p1:
+        assert torch.equal(p1[k], p2[k]), k
