@@ -536,6 +536,16 @@ int msml_bn_act_bwd_apply_next(const void* dy, const void* x, const float* scale
                                int C, float* coef_ws, const void* next_x, const float* next_mean,
                                const float* next_invstd, float* next_partial, int dtype, void* stream);
 
+/* Block-level entry point: every launch of one IBasicBlock forward (backbones/frb/iresnet.py:56-67; the OSB encoder's
+ * copy backbones/osb/unet.py:80-91) in the bf16 training path with accumulator-mode statistics, enqueued by ONE call:
+ * bn1 -> conv1 -> bn2 + PReLU -> conv2 (stride) [-> downsample conv 1x1 -> its BatchNorm] -> bn3 + identity, i.e. the
+ * sequence msml_bn_fin_act_fwd / msml_conv2d_acc the host otherwise issues launch by launch (same kernels, same order,
+ * bit-identical results).  ptrs / ints / flts: tables indexed by the enums at the top of csrc/block.hip
+ * (msml_iblock_fwd_tables returns their lengths); every pointer is a device pointer borrowed for the enqueue,
+ * coefficient blocks are float[4][C] (scale, shift, mean, invstd), accumulators zero-initialised double[8][2][C]. */
+int msml_iblock_fwd_tables(int* nptr, int* nint, int* nflt);
+int msml_iblock_fwd(const void* const* ptrs, const int* ints, const float* flts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

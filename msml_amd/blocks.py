@@ -324,9 +324,125 @@ def _block_pack(blk):
     }
 
 
+# ---- one C call per block forward (csrc/block.hip) -------------------------------------------------------------------
+# The table layout of msml_iblock_fwd (enums at the top of csrc/block.hip).
+(_IB_X, _IB_XACC, _IB_BN1_G, _IB_BN1_B, _IB_BN1_RM, _IB_BN1_RV, _IB_COEF1, _IB_O1, _IB_WP1, _IB_C1, _IB_ACC1,
+ _IB_BN2_G, _IB_BN2_B, _IB_BN2_RM, _IB_BN2_RV, _IB_COEF2, _IB_ALPHA, _IB_O2, _IB_WP2, _IB_C2, _IB_ACC2,
+ _IB_WPD, _IB_D, _IB_ACCD, _IB_BND_G, _IB_BND_B, _IB_BND_RM, _IB_BND_RV, _IB_COEFD, _IB_IDN,
+ _IB_BN3_G, _IB_BN3_B, _IB_BN3_RM, _IB_BN3_RV, _IB_COEF3, _IB_OUT, _IB_ACC_OUT, _IB_NPTR) = range(38)
+(_II_N, _II_H, _II_W, _II_CINP, _II_COUTP, _II_KOP1, _II_KOP2, _II_KOPD, _II_STRIDE, _II_P, _II_Q, _II_HAS_DS,
+ _II_DS_STRIDE, _II_NINT) = range(14)
+_IF_NFLT = 8
+_TABLES_OK = []
+
+
+def _tables_checked():
+    if not _TABLES_OK:
+        import ctypes
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        call("msml_iblock_fwd_tables", ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        if (a.value, b.value, c.value) != (_IB_NPTR, _II_NINT, _IF_NFLT):
+            raise RuntimeError("msml_iblock_fwd: table layout of the library (%d, %d, %d) differs from blocks.py"
+                               % (a.value, b.value, c.value))
+        _TABLES_OK.append(True)
+    return True
+
+
+def _iblock_fwd_applies(x, bp):
+    """The one-call forward serves the default bf16 training configuration only: accumulator-mode statistics on every
+    BatchNorm of the block, no profiling events, no BatchNorm-in-LDS experiment."""
+    if not (ops.BLOCK_C_ENTRY and ops.ACC_STATS and not ops.PROFILE.on and not ops.FUSE_BN_IN and x.dtype == torch.bfloat16):
+        return False
+    cout = cpad(bp["c1"][1][0])
+    return ops.acc_applies(x.shape[-1], BF16) and ops.acc_applies(cout, BF16) and x.shape[-1] == bp["c1"][1][1]
+
+
+def _iblock_fwd_fast(x, bp, xstats):
+    """_IBlock.forward's launches through msml_iblock_fwd; returns what the launch-by-launch path returns."""
+    import ctypes
+    _tables_checked()
+    tab = bp.get("_fwd_tab")
+    if tab is None:
+        tab = bp["_fwd_tab"] = ((ctypes.c_void_p * _IB_NPTR)(), (ctypes.c_int * _II_NINT)(), (ctypes.c_float * _IF_NFLT)())
+    pt, it, ft = tab
+    dev = x.device
+    n, h, w, cinp = x.shape
+    bn1, bn2, bn3, ds = bp["bn1"], bp["bn2"], bp["bn3"], bp["ds"]
+    w1, (cout, cin, _, _), _, _, _ = bp["c1"]
+    w2, _, stride, _, _ = bp["c2"]
+    coutp = cpad(cout)
+    p_, q_ = ops.conv_out_size(h, 3, stride, 1, False), ops.conv_out_size(w, 3, stride, 1, False)
+    if xstats is None:
+        xstats = _own_stats(x, None)
+    bf = torch.bfloat16
+    o1 = torch.empty_like(x)
+    c1 = torch.empty(n, h, w, coutp, dtype=bf, device=dev)
+    o2 = torch.empty_like(c1)
+    c2 = torch.empty(n, p_, q_, coutp, dtype=bf, device=dev)
+    out = torch.empty_like(c2)
+    k1 = torch.empty(4, cinp, dtype=torch.float32, device=dev)
+    k2 = torch.empty(4, coutp, dtype=torch.float32, device=dev)
+    k3 = torch.empty(4, coutp, dtype=torch.float32, device=dev)
+    acc1, acc2 = ops.stats_acc(coutp, dev), ops.stats_acc(coutp, dev)
+    wp1 = ops.PACKS.get(w1, False, 0, cout, 0, cin, cin, 0, BF16)
+    wp2 = ops.PACKS.get(w2, False, 0, cout, 0, cout, cout, 0, BF16)
+    emit = bp["emit_stats"] and 256 % (coutp // 8) == 0
+    ostats = ops.stats_acc(coutp, dev) if emit else None
+    pt[_IB_X], pt[_IB_XACC] = x.data_ptr(), xstats.data_ptr()
+    pt[_IB_BN1_G], pt[_IB_BN1_B], pt[_IB_BN1_RM], pt[_IB_BN1_RV] = (bn1[0].data_ptr(), bn1[1].data_ptr(),
+                                                                    bn1[2].data_ptr(), bn1[3].data_ptr())
+    pt[_IB_COEF1], pt[_IB_O1], pt[_IB_WP1], pt[_IB_C1], pt[_IB_ACC1] = (k1.data_ptr(), o1.data_ptr(), wp1.data_ptr(),
+                                                                       c1.data_ptr(), acc1.data_ptr())
+    pt[_IB_BN2_G], pt[_IB_BN2_B], pt[_IB_BN2_RM], pt[_IB_BN2_RV] = (bn2[0].data_ptr(), bn2[1].data_ptr(),
+                                                                    bn2[2].data_ptr(), bn2[3].data_ptr())
+    pt[_IB_COEF2], pt[_IB_ALPHA], pt[_IB_O2], pt[_IB_WP2], pt[_IB_C2], pt[_IB_ACC2] = (
+        k2.data_ptr(), bp["alpha"].data_ptr(), o2.data_ptr(), wp2.data_ptr(), c2.data_ptr(), acc2.data_ptr())
+    d = kd = None
+    it[_II_HAS_DS] = 0
+    if ds is not None:
+        wd, (_, _, dr, dsz), dstride, dph, dpw = ds[0]
+        if dr != 1 or dsz != 1 or dph != 0 or dpw != 0:
+            return None                                # (not the reference's 1x1 downsample: launch by launch)
+        dbn = ds[1]
+        d = torch.empty_like(c2)
+        idn = torch.empty_like(c2)
+        kd = torch.empty(4, coutp, dtype=torch.float32, device=dev)
+        accd = ops.stats_acc(coutp, dev)
+        wpd = ops.PACKS.get(wd, False, 0, cout, 0, cin, cin, 0, BF16)
+        pt[_IB_WPD], pt[_IB_D], pt[_IB_ACCD] = wpd.data_ptr(), d.data_ptr(), accd.data_ptr()
+        pt[_IB_BND_G], pt[_IB_BND_B], pt[_IB_BND_RM], pt[_IB_BND_RV] = (dbn[0].data_ptr(), dbn[1].data_ptr(),
+                                                                        dbn[2].data_ptr(), dbn[3].data_ptr())
+        pt[_IB_COEFD], pt[_IB_IDN] = kd.data_ptr(), idn.data_ptr()
+        it[_II_HAS_DS], it[_II_KOPD], it[_II_DS_STRIDE] = 1, wpd.shape[0], dstride
+        ft[6], ft[7] = dbn[4], dbn[5]
+    pt[_IB_BN3_G], pt[_IB_BN3_B], pt[_IB_BN3_RM], pt[_IB_BN3_RV] = (bn3[0].data_ptr(), bn3[1].data_ptr(),
+                                                                    bn3[2].data_ptr(), bn3[3].data_ptr())
+    pt[_IB_COEF3], pt[_IB_OUT] = k3.data_ptr(), out.data_ptr()
+    pt[_IB_ACC_OUT] = ostats.data_ptr() if emit else None
+    (it[_II_N], it[_II_H], it[_II_W], it[_II_CINP], it[_II_COUTP], it[_II_KOP1], it[_II_KOP2], it[_II_STRIDE], it[_II_P],
+     it[_II_Q]) = n, h, w, cinp, coutp, wp1.shape[0], wp2.shape[0], stride, p_, q_
+    ft[0], ft[1], ft[2], ft[3], ft[4], ft[5] = bn1[4], bn1[5], bn2[4], bn2[5], bn3[4], bn3[5]
+    call("msml_iblock_fwd", pt, it, ft)
+    for b in ((bn1, bn2, bn3) if ds is None else (bn1, bn2, ds[1], bn3)):
+        ops.bn_counter(b[6])
+    return o1, c1, o2, c2, d, k1, k2, k3, kd, out, ostats
+
+
 class _IBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bp, xstats, pc2, pk3, *params):
+        if _iblock_fwd_applies(x, bp):
+            fast = _iblock_fwd_fast(x, bp, xstats)
+            if fast is not None:
+                o1, c1, o2, c2, d, k1, k2, k3, kd, out, ostats = fast
+                if ostats is None:
+                    ostats = out.new_empty(0)
+                ctx.bp = bp
+                ctx.set_materialize_grads(False)
+                bp["_last_bn3"] = (c2, k3) if bp["emit_stats"] else None
+                ctx.save_for_backward(x, o1, c1, o2, c2, d, k1, k2, k3, kd, pc2, pk3)
+                ctx.mark_non_differentiable(ostats)
+                return out, ostats
         # params (for autograd bookkeeping only): conv1.w, conv2.w, [down.w], bn1 g/b, bn2 g/b, prelu,
         # bn3 g/b, [down bn g/b] -- the arithmetic reads them from the cached pack
         ds = bp["ds"]

@@ -15,7 +15,8 @@ from msml_amd import ops  # noqa: E402
 
 
 def main():
-    args = argparse.Namespace(frb="iresnet50", batch=256, classes=85742, dtype="bf16", mode="train")
+    args = argparse.Namespace(frb="iresnet50", batch=256, classes=85742, dtype="bf16", mode="train", emulate_world=1,
+                              data="resident")
     tr = bench.Trainer(args, 0, 0, 1)
     ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
     for _ in range(5):
