@@ -373,8 +373,11 @@ OSB_STREAM = None
 BLOCK_FUNCTION = os.environ.get("MSML_NO_BLOCK_FUNCTION") is None
 BOTTLE_FUNCTION = os.environ.get("MSML_NO_BOTTLE_FUNCTION") is None       # FM resblock_bottle as one node
 FUSE_BN_BWD = os.environ.get("MSML_NO_FUSE_BN_BWD") is None
-# One C call per IBasicBlock forward (msml_iblock_fwd, csrc/block.hip) instead of 6-8 launches issued from Python
-BLOCK_C_ENTRY = os.environ.get("MSML_NO_BLOCK_C_ENTRY") is None
+# One C call per IBasicBlock forward (msml_iblock_fwd, csrc/block.hip) instead of 6-8 launches issued from Python: host
+# issue time 20.1 -> 18.6-19.3 ms per step, bit-identical results -- but the GPU-bound step measured 0.09 ms SLOWER with
+# it on one box (31.41 / 31.45 -> 31.50 / 31.55 ms: the burstier issue shifts the interleaving of the streams), so it is
+# opt-in for hosts that cannot keep ahead of the GPU: MSML_BLOCK_C_ENTRY=1
+BLOCK_C_ENTRY = os.environ.get("MSML_BLOCK_C_ENTRY") is not None
 # FMCnn: the two gradients of the stage input (same_conv path + act / arith / skip path) summed in same_conv's backward-data
 # epilogue instead of by autograd's fan-out add
 FM_TEE = os.environ.get("MSML_NO_FM_TEE") is None
