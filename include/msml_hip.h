@@ -536,6 +536,20 @@ int msml_bn_act_bwd_apply_next(const void* dy, const void* x, const float* scale
                                int C, float* coef_ws, const void* next_x, const float* next_mean,
                                const float* next_invstd, float* next_partial, int dtype, void* stream);
 
+/* Training-mode BatchNorm (+ PReLU) -> 3x3 / stride-1 / pad-1 conv in ONE launch with accumulator-mode statistics on
+ * both sides (bn1 -> conv1 and bn2 -> prelu -> conv2 of IBasicBlock, backbones/frb/iresnet.py:58-62): coefficients from
+ * acc_in (double[8][2][c0p], the producer's sums) in the kernel prologue, the normalised input applied in LDS and written
+ * to act_out (NHWC like in0; the weight gradient reads it), coef_out = float[4][c0p] (scale, shift, mean, invstd), running
+ * statistics updated, the output's sums added to acc_out (zero-initialised double[8][2][coutp]).  Bit-identical to
+ * msml_bn_fin_act_fwd + msml_conv2d_acc.  Shapes: msml_conv2d_bnin_acc_applies (the halo-tile conv). */
+int msml_conv2d_bnin_acc_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                                 int pad_h, int pad_w);
+int msml_conv2d_bnin_acc(const void* in0, int c0p, const double* acc_in, double count, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         float* coef_out, const float* in_alpha, void* act_out, const void* wp, int kop, void* out,
+                         int coutp, double* acc_out, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                         int pad_h, int pad_w, void* stream);
+
 /* Block-level entry point: every launch of one IBasicBlock forward (backbones/frb/iresnet.py:56-67; the OSB encoder's
  * copy backbones/osb/unet.py:80-91) in the bf16 training path with accumulator-mode statistics, enqueued by ONE call:
  * bn1 -> conv1 -> bn2 + PReLU -> conv2 (stride) [-> downsample conv 1x1 -> its BatchNorm] -> bn3 + identity, i.e. the

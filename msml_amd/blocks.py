@@ -134,6 +134,14 @@ def _bn_conv_fwd(x, stats, bnp, alpha, cp):
     if not (ops.FUSE_BN_IN and stats is None):
         stats = _own_stats(x, stats)
     if _is_acc(stats):
+        w, (cout, cin, r, s), stride, ph, pw = cp
+        n, h, wd, cp_in = x.shape
+        if ph == pw and ops.bnin_acc_applies(n, h, wd, cp_in, cpad(cout), r, s, stride, ph):
+            # the BatchNorm is applied in the conv's prologue (coefficients from the accumulator, write-through of o)
+            wp = ops.PACKS.get(w, False, 0, cout, 0, cin, cin, 0, BF16)
+            o, coef, y, st = ops.conv2d_bnin_acc(x, stats, bnp, alpha, wp, cpad(cout), real=(cin, cout))
+            ops.bn_counter(bnp[6])
+            return o, coef, y, st
         o, coef = _bn_fin_apply(x, stats, bnp, alpha, None)
         y, st = _conv_fwd(o, cp)
         return o, coef, y, st

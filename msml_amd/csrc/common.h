@@ -187,6 +187,20 @@ struct BnIn {
   const float* scale;      // nullptr: no input transform
   const float* shift;
   const float* alpha;      // nullptr: no PReLU
+  // Accumulator mode (acc != nullptr, conv_halo.hip only): the coefficients are DERIVED in the kernel's prologue from the
+  // producer's f64 sums double[MSML_ACC_ROWS][2][C] exactly as k_bn_fin_act_fwd derives them (bn.hip), workgroup (0, 0)
+  // writes coef_out = float[4][C] (scale, shift, mean, invstd) and updates the running statistics, and the normalised
+  // image is also WRITTEN OUT (store, same NHWC shape as the input: the weight gradient reads it) -- the BatchNorm apply
+  // launch in front of the conv disappears.
+  const double* acc = nullptr;
+  double count = 0.0;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float* rmean = nullptr;
+  float* rvar = nullptr;
+  float momentum = 0.f, eps = 0.f;
+  float* coef_out = nullptr;
+  unsigned short* store = nullptr;
 };
 // tab: LDS table [3][C] (scale, shift, alpha) filled by bn_in_fill
 __device__ __forceinline__ void bn_in_fill(const BnIn& f, float* tab, int c0, int C, int t, int nt) {
@@ -194,6 +208,39 @@ __device__ __forceinline__ void bn_in_fill(const BnIn& f, float* tab, int c0, in
     tab[i] = f.scale[c0 + i];
     tab[C + i] = f.shift[c0 + i];
     tab[2 * C + i] = f.alpha ? f.alpha[c0 + i] : 1.f;
+  }
+}
+// Accumulator mode: the table from the producer's f64 sums (the arithmetic of k_bn_fin_act_fwd's prologue, bn.hip --
+// bit-identical coefficients); `writer` (one workgroup of the launch) also stores them and updates the running statistics.
+__device__ __forceinline__ void bn_in_fill_acc(const BnIn& f, float* tab, int C, int t, int nt, bool writer) {
+  for (int c = t; c < C; c += nt) {
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < MSML_ACC_ROWS; r++) {
+      s += f.acc[(r * 2 + 0) * C + c];
+      ss += f.acc[(r * 2 + 1) * C + c];
+    }
+    const double m = s / f.count;
+    double var = ss / f.count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m;
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    const float sc = g * invstd, sh = b - mean * g * invstd;
+    tab[c] = sc;
+    tab[C + c] = sh;
+    tab[2 * C + c] = f.alpha ? f.alpha[c] : 1.f;
+    if (writer) {
+      f.coef_out[c] = sc;
+      f.coef_out[C + c] = sh;
+      f.coef_out[2 * C + c] = mean;
+      f.coef_out[3 * C + c] = invstd;
+      if (f.rmean) {
+        const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+        f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * mean;
+        f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * (float)unbiased;
+      }
+    }
   }
 }
 __device__ __forceinline__ void bn_in_chunk(char* lds16, const float* tab, int C, int ch, bool has_alpha) {

@@ -142,8 +142,15 @@ k_conv_halo(const ConvHaloArgs p) {
       const int j = wave + i * NW;
       const int hp = j * 8 + (lane >> 3);
       const int logical = (lane & 7) ^ skey(hp);
-      if (j < NAJ && aoff[i] != HALO_OOB)
+      if (j < NAJ && aoff[i] != HALO_OOB) {
         bn_in_chunk(a + j * 1024 + lane * 16, xtab, p.C, cs * 64 + logical * 8, has_alpha);
+        // write-through of the normalised image (accumulator mode): the pixels this tile OWNS (not its halo), once
+        // per pixel tile (the first channel block of the grid)
+        const int hy = hp >> PL2, hx = hp & (PITCH - 1);
+        if (p.xin.store && blockIdx.y == 0 && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.xin.store) + aoff[i] + cs * 128u) =
+              *reinterpret_cast<const u32x4*>(a + j * 1024 + lane * 16);
+      }
     }
   };
   auto issue_b = [&](int cs, int tap, int buf) {
@@ -191,7 +198,10 @@ k_conv_halo(const ConvHaloArgs p) {
   const int nslab = p.C >> 6, nstage = nslab * 9;
   issue_a(0, 0);
   issue_b(0, 0, 0);
-  if (XF) bn_in_fill(p.xin, xtab, 0, p.C, t, NT);
+  if (XF) {
+    if (p.xin.acc) bn_in_fill_acc(p.xin, xtab, p.C, t, NT, blockIdx.x == 0 && blockIdx.y == 0);
+    else bn_in_fill(p.xin, xtab, 0, p.C, t, NT);
+  }
   __syncthreads();                                     // (drains vmcnt first)
   if (XF) {
     xform(0, 0);

@@ -561,6 +561,49 @@ extern "C" int msml_conv2d_bnin(const void* in0, int c0p, const float* in_scale,
   return MSML_OK;
 }
 
+// 1 when msml_conv2d_bnin_acc serves the shape (the halo-tile conv; the weights-stationary 64-channel kernel gains nothing
+// from the in-LDS transform and is not offered).
+extern "C" int msml_conv2d_bnin_acc_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                                            int stride, int pad_h, int pad_w) {
+  if (getenv("MSML_NO_FAST_CONV") || c0p > 1024 || c0p % 8 || 256 % (c0p / 8) || (long)N * P * Q >= (1L << 24)) return 0;
+  const int bn = msml_conv_tile_n(coutp), kop = cdiv(coutp, bn) * bn;
+  return msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, true) ? 1 : 0;
+}
+
+// Training-mode BatchNorm (+ PReLU) -> 3x3 / stride-1 / pad-1 conv in ONE launch, accumulator-mode statistics on both
+// sides: the BatchNorm's coefficients are derived from `acc_in` (the f64 sums its producer accumulated) in the conv
+// kernel's prologue, the normalised input is applied per slab in LDS AND written to `act_out` (the weight gradient reads
+// it), `coef_out` = float[4][c0p] (scale, shift, mean, invstd) and the running statistics are written by one workgroup,
+// the conv output's (sum, sumsq) go to `acc_out`.  Replaces msml_bn_fin_act_fwd + msml_conv2d_acc for the shapes of
+// msml_conv2d_bnin_acc_applies, bit for bit (same coefficient arithmetic, same rounding of the activation, same MFMA
+// order); reference: bn1 -> conv1 and bn2 -> prelu -> conv2 of IBasicBlock, backbones/frb/iresnet.py:58-62.
+extern "C" int msml_conv2d_bnin_acc(const void* in0, int c0p, const double* acc_in, double count, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, float momentum,
+                                    float eps, float* coef_out, const float* in_alpha, void* act_out, const void* wp,
+                                    int kop, void* out, int coutp, double* acc_out, int N, int H, int W, int P, int Q,
+                                    int R, int S, int stride, int pad_h, int pad_w, void* stream) {
+  MSML_CHECK(in0 && wp && out && acc_in && coef_out && act_out && acc_out, MSML_ERR_SHAPE, "conv2d_bnin_acc: null pointer");
+  MSML_CHECK(N > 0 && H > 0 && W > 0 && c0p > 0 && coutp > 0 && count > 0.0, MSML_ERR_SHAPE, "conv2d_bnin_acc: bad dims");
+  const int bn = msml_conv_tile_n(coutp);
+  MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_bnin_acc: packed weight rows");
+  MSML_CHECK(msml_conv2d_bnin_acc_applies(c0p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w), MSML_ERR_UNSUPPORTED,
+             "conv2d_bnin_acc: shape not covered by the halo-tile kernel");
+  BnIn xin{nullptr, nullptr, in_alpha};
+  xin.scale = coef_out;                                // (non-null marks the transform; the kernel fills its own table)
+  xin.shift = coef_out + c0p;
+  xin.acc = acc_in; xin.count = count; xin.gamma = gamma; xin.beta = beta;
+  xin.rmean = running_mean; xin.rvar = running_var; xin.momentum = momentum; xin.eps = eps;
+  xin.coef_out = coef_out; xin.store = (unsigned short*)act_out;
+  msml_tl_stats_acc = 1;
+  const bool ok = msml_conv_halo_dispatch(in0, c0p, wp, kop, nullptr, out, coutp, reinterpret_cast<float*>(acc_out), N, H,
+                                          W, P, Q, R, S, stride, pad_h, pad_w, 0, (hipStream_t)stream, nullptr, nullptr,
+                                          nullptr, 0, nullptr, nullptr, &xin);
+  msml_tl_stats_acc = 0;
+  MSML_CHECK(ok, MSML_ERR_UNSUPPORTED, "conv2d_bnin_acc: launch refused");
+  MSML_LAUNCH_OK("conv2d_bnin_acc");
+  return MSML_OK;
+}
+
 // Name of the kernel msml_conv2d / msml_conv2d_fused / msml_conv2d_bnbwd launches for a shape
 // (profiling labels: bench.py's roofline names the kernel it measured).
 extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, int H, int W, int P, int Q,

@@ -266,6 +266,45 @@ def bnin_applies(n, h, w, cin_p, cout_p, a_real, b_real):
     return ok
 
 
+# Accumulator-mode BatchNorm (+ PReLU) applied in the NEXT conv's prologue with write-through of the normalised tensor
+# (msml_conv2d_bnin_acc): the BatchNorm apply launch in front of the conv disappears.  Only where the in-LDS transform is
+# nearly free -- one workgroup per image tile and >= four 64-channel slabs per tile, i.e. >= 256 input channels
+# (tools/bench_bnin.py: 256 -> 256 @ 14x14 bn 12 + conv 65 us -> 67-70 us; 128 @ 28x28 only 18 + 82 -> 96).
+BNIN_ACC = os.environ.get("MSML_NO_BNIN_ACC") is None
+BNIN_ACC_MIN_C = int(os.environ.get("MSML_BNIN_ACC_MIN_C", "256"))
+_BNIN_ACC_OK = {}
+
+
+def bnin_acc_applies(n, h, w, cin_p, cout_p, r, s, stride, pad):
+    key = (n, h, w, cin_p, cout_p, r, s, stride, pad)
+    ok = _BNIN_ACC_OK.get(key)
+    if ok is None:
+        ok = bool(BNIN_ACC and ACC_STATS and cin_p >= BNIN_ACC_MIN_C and r == 3 and s == 3 and stride == 1 and pad == 1 and
+                  acc_applies(cin_p, BF16) and acc_applies(cout_p, BF16) and
+                  _lib.value("msml_conv2d_bnin_acc_applies", cin_p, cout_p, n, h, w, h, w, 3, 3, 1, 1, 1))
+        _BNIN_ACC_OK[key] = ok
+    return ok
+
+
+def conv2d_bnin_acc(x, acc_in, bnp, alpha, wp, coutp, real=None):
+    """BatchNorm (training mode, statistics in the accumulator acc_in) (+ PReLU alpha) -> 3x3 / stride-1 / pad-1 conv in one
+    launch.  bnp = (gamma, beta, running_mean, running_var, momentum, eps, ...).  Returns (normalised activation,
+    coef[4][C], conv output, accumulator of the conv output's statistics)."""
+    n, h, w, c0p = x.shape
+    act = torch.empty_like(x)
+    out = torch.empty(n, h, w, coutp, dtype=torch.bfloat16, device=x.device)
+    coef = torch.empty(4, c0p, dtype=torch.float32, device=x.device)
+    acc_out = stats_acc(coutp, x.device)
+    cin, cout = real if real is not None else (c0p, coutp)
+    name = "conv_igemm"
+    if PROFILE.on:
+        name = conv_label("N+bn", c0p, 0, coutp, n, h, w, h, w, 3, 3, 1, 1, 1, 0, BF16, BF16, True)
+    with PROFILE.rec(name, 2.0 * n * h * w * cin * cout * 9):
+        call("msml_conv2d_bnin_acc", x, c0p, acc_in, float(n * h * w), bnp[0], bnp[1], bnp[2], bnp[3], bnp[4], bnp[5], coef,
+             alpha, act, wp, wp.shape[0], out, coutp, acc_out, n, h, w, h, w, 3, 3, 1, 1, 1)
+    return act, coef, out, acc_out
+
+
 def conv2d_bnin(x, coef, alpha, wp, coutp, real=None):
     """3x3 / stride-1 / pad-1 forward conv on PReLU(x * coef[0] + coef[1]) applied in LDS
     (msml_conv2d_bnin); returns (out, statistics partial rows of out)."""

@@ -778,3 +778,45 @@ def test_conv_small_map_tiles(shape):
         want = torch.stack((gg.sum(0), (gg * xh).sum(0), (gq * torch.clamp(z, max=0)).sum(0))).double()
         have = acc.sum(0)
         assert torch.allclose(have, want, rtol=2e-3, atol=2e-3 * want.abs().max().item())
+
+
+@pytest.mark.parametrize("with_alpha", [False, True])
+@pytest.mark.parametrize("shape", [(7, 256, 256, 14, 14), (4, 256, 128, 13, 27), (3, 512, 256, 14, 14), (5, 256, 512, 14, 14),
+                                   (9, 128, 128, 28, 28), (6, 128, 256, 28, 28)])
+def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
+    """msml_conv2d_bnin_acc: training-mode BatchNorm (+ PReLU) -> 3x3 conv in ONE launch (coefficients derived from the
+    producer's f64 accumulator in the kernel prologue, normalised tile applied in LDS and written through, running
+    statistics updated by one workgroup) against msml_bn_fin_act_fwd + msml_conv2d_acc: activation, conv output, saved
+    coefficients and running statistics bit for bit, output statistics to the order of the f64 adds."""
+    n, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(sum(shape) + int(with_alpha))
+    x = ops.to_nhwc((torch.randn(n, cin, h, w_, generator=g) * 1.7 + 0.3).cuda(), _lib.BF16)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).cuda()
+    gamma = (torch.rand(cin, generator=g) + 0.5).cuda()
+    beta = (torch.randn(cin, generator=g) * 0.5).cuda()
+    alpha = (torch.rand(cin, generator=g) * 0.3).cuda() if with_alpha else None
+    wp = ops.pack_weight(w, False, cin, 0, _lib.BF16)
+    m = n * h * w_
+    assert _lib.value("msml_conv2d_bnin_acc_applies", cin, cout, n, h, w_, h, w_, 3, 3, 1, 1, 1) == 1
+
+    def stats_of_x():
+        acc = ops.stats_acc(cin, x.device)
+        _lib.call("msml_bn_stats_acc", x, m, cin, acc, _lib.BF16)
+        return acc
+    # reference: two launches
+    rm_a, rv_a = torch.zeros(cin, device="cuda"), torch.ones(cin, device="cuda")
+    coef_a = torch.empty(4, cin, device="cuda")
+    act_a = torch.empty_like(x)
+    _lib.call("msml_bn_fin_act_fwd", stats_of_x(), float(m), gamma, beta, rm_a, rv_a, 0.1, 1e-5, coef_a[0], coef_a[1],
+              coef_a[2], coef_a[3], x, alpha, None, 0, act_a, m, cin, None, _lib.BF16)
+    y_a, st_a = ops.conv2d(act_a, None, wp, None, cout, 3, 3, 1, 1, 1, False, want_stats=True)
+    assert st_a.dtype == torch.float64
+    # one launch
+    rm_b, rv_b = torch.zeros(cin, device="cuda"), torch.ones(cin, device="cuda")
+    act_b, coef_b, y_b, st_b = ops.conv2d_bnin_acc(x, stats_of_x(), (gamma, beta, rm_b, rv_b, 0.1, 1e-5), alpha, wp, cout)
+    torch.cuda.synchronize()
+    assert torch.equal(act_b, act_a)
+    assert torch.equal(y_b, y_a)
+    assert torch.equal(coef_b, coef_a)
+    assert torch.equal(rm_b, rm_a) and torch.equal(rv_b, rv_a)
+    assert torch.allclose(st_b.sum(0), st_a.sum(0), rtol=1e-12, atol=0)
