@@ -550,6 +550,23 @@ int msml_conv2d_bnin_acc(const void* in0, int c0p, const double* acc_in, double 
                          int coutp, double* acc_out, int N, int H, int W, int P, int Q, int R, int S, int stride,
                          int pad_h, int pad_w, void* stream);
 
+/* BatchNorm BACKWARD -> 3x3 / stride-1 backward-data conv -> sums of the next BatchNorm backward, ONE launch in
+ * accumulator mode (the backward of conv2 / conv1 of IBasicBlock with bn3 / bn2 in front, backbones/frb/iresnet.py:59-65):
+ * in0 = dy of the upper BatchNorm, up_x its saved input, up_scale ... up_invstd its saved coefficients, up_acc the three
+ * sums double[8][3][c0p] its producer accumulated; dc = the BatchNorm's input gradient is formed in LDS, written to dc_out
+ * (NHWC like in0; the weight gradient reads it) and convolved; dgamma / dbeta / dalpha (+)= its parameter gradients; the
+ * epilogue adds the sums of the LOWER BatchNorm (bn_*, acc) exactly like msml_conv2d_bnbwd_acc.  Bit-identical to
+ * msml_bn_fin_bwd_apply + msml_conv2d_bnbwd_acc.  Shapes: msml_conv2d_bnbwd_in_acc_applies. */
+int msml_conv2d_bnbwd_in_acc_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                                     int pad_h, int pad_w);
+int msml_conv2d_bnbwd_in_acc(const void* in0, int c0p, const void* up_x, const float* up_scale, const float* up_shift,
+                             const float* up_alpha, const float* up_mean, const float* up_invstd, const double* up_acc,
+                             float* dgamma, float* dbeta, float* dalpha, int accumulate, void* dc_out, const void* wp,
+                             int kop, void* out, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                             int pad_h, int pad_w, const void* bn_x, const float* bn_scale, const float* bn_shift,
+                             const float* bn_alpha, const float* bn_mean, const float* bn_invstd, double* acc,
+                             void* stream);
+
 /* Block-level entry point: every launch of one IBasicBlock forward (backbones/frb/iresnet.py:56-67; the OSB encoder's
  * copy backbones/osb/unet.py:80-91) in the bf16 training path with accumulator-mode statistics, enqueued by ONE call:
  * bn1 -> conv1 -> bn2 + PReLU -> conv2 (stride) [-> downsample conv 1x1 -> its BatchNorm] -> bn3 + identity, i.e. the

@@ -201,6 +201,22 @@ def _dgrad(dy, cp, h, w, bn_x=None, coef=None, alpha=None):
     return dx, None
 
 
+def _bn_bwd_dgrad(dy, up_x, up_k, up_alpha, pgr, part, cp, h, w, bn_x, coef, alpha):
+    """BatchNorm backward + the backward-data conv behind it in one launch (ops.conv_dgrad_bnbwd_in) when the shape is
+    covered and the BatchNorm's sums arrived in an accumulator; None otherwise.  Returns (dc, dx, lower sums)."""
+    if part is None or part.dtype != torch.float64 or dy.dtype != torch.bfloat16:
+        return None
+    wparam, (cout, cin, r, s), stride, ph, pw = cp
+    n, hh, ww, c_dy = dy.shape
+    if ph != pw or hh != h or ww != w or not ops.bnbwd_in_applies(n, hh, ww, c_dy, cpad(cin), r, s, stride, ph):
+        return None
+    wp = ops.PACKS.get(wparam, True, 0, cout, 0, cin, cout, 0, BF16)
+    dc, dx, acc = ops.conv_dgrad_bnbwd_in(dy, up_x, up_k, up_alpha, part, pgr.tg, pgr.inplace, wp, cpad(cin), bn_x, coef,
+                                          alpha, real=(cout, cin))
+    pgr.done()
+    return dc, dx, acc
+
+
 _UNIT = {}
 
 
@@ -493,15 +509,30 @@ class _IBlock(torch.autograd.Function):
         part3 = dout.__dict__.pop("_msml_bn3_partial", None) if bp["emit_stats"] else None
         if part3 is not None:
             ops.COUNTERS["bn3_partial_hits"] += 1
-        dc2 = _bn_bwd(dout, c2, k3, None, g3, part3)
-        # conv2: dW beside, dX with bn2's backward sums from the epilogue
-        dw2 = _wgrad(dc2, o2, bp["c2"]) if o2 is not None else _wgrad(dc2, c1, bp["c2"], (k2, alpha))
-        do2, part2 = _dgrad(dc2, bp["c2"], c1.shape[1], c1.shape[2], c1, k2, alpha)
+        # bn3's backward -> conv2's backward-data (+ bn2's sums): one launch where the halo kernel takes the BatchNorm
+        # backward as an input transform (ops.bnbwd_in_applies), else apply kernel + conv
+        fused = _bn_bwd_dgrad(dout, c2, k3, None, g3, part3, bp["c2"], c1.shape[1], c1.shape[2], c1, k2, alpha) \
+            if (o2 is not None and ops.FUSE_BN_BWD) else None
+        if fused is not None:
+            dc2, do2, part2 = fused
+            dw2 = _wgrad(dc2, o2, bp["c2"])
+        else:
+            dc2 = _bn_bwd(dout, c2, k3, None, g3, part3)
+            # conv2: dW beside, dX with bn2's backward sums from the epilogue
+            dw2 = _wgrad(dc2, o2, bp["c2"]) if o2 is not None else _wgrad(dc2, c1, bp["c2"], (k2, alpha))
+            do2, part2 = _dgrad(dc2, bp["c2"], c1.shape[1], c1.shape[2], c1, k2, alpha)
         g2 = _ParamGrads((bn2[0], bn2[1], alpha), c1.shape[-1], dev)
-        dc1 = _bn_bwd(do2, c1, k2, alpha, g2, part2)
-        # conv1
-        dw1 = _wgrad(dc1, o1, bp["c1"]) if o1 is not None else _wgrad(dc1, x, bp["c1"], (k1, None))
-        do1, part1 = _dgrad(dc1, bp["c1"], h, w, x, k1, None)
+        # bn2 (+ PReLU) backward -> conv1's backward-data (+ bn1's sums)
+        fused = _bn_bwd_dgrad(do2, c1, k2, alpha, g2, part2, bp["c1"], h, w, x, k1, None) \
+            if (o1 is not None and ops.FUSE_BN_BWD) else None
+        if fused is not None:
+            dc1, do1, part1 = fused
+            dw1 = _wgrad(dc1, o1, bp["c1"])
+        else:
+            dc1 = _bn_bwd(do2, c1, k2, alpha, g2, part2)
+            # conv1
+            dw1 = _wgrad(dc1, o1, bp["c1"]) if o1 is not None else _wgrad(dc1, x, bp["c1"], (k1, None))
+            do1, part1 = _dgrad(dc1, bp["c1"], h, w, x, k1, None)
         # identity / downsample path
         dwd, gd = None, None
         if ds is not None:

@@ -282,6 +282,83 @@ struct BnBwdFuse {
   int acc;                 // accumulator mode: partial is a zero-initialised double[MSML_ACC_ROWS][3][C]
 };
 
+// ---- BatchNorm BACKWARD applied to a backward-data conv's input in LDS (conv_halo.hip, accumulator mode) -----------
+// The conv input dc = d(loss)/d(BatchNorm input) is computed from the BatchNorm's output gradient dy (the tensor the
+// conv DMA-loads), its saved input x (loaded by the lane that transforms the chunk) and the three backward sums the
+// producer accumulated (double[MSML_ACC_ROWS][3][C]: sum g, sum g * xhat, sum dy * min(z, 0)) -- the arithmetic of
+// k_bn_fin_bwd_apply (bn.hip): g = dy * prelu'(z), dc = scale * (g - s0 / n - xhat * s1 / n); one workgroup adds the
+// parameter gradients (dgamma, dbeta, dalpha) and the transformed image is written through to `store` for the weight
+// gradient.  The separate backward-apply launch in front of the conv disappears.
+struct BnBwdIn {
+  const unsigned short* x = nullptr;     // nullptr: no backward input transform
+  const float* scale = nullptr;
+  const float* shift = nullptr;
+  const float* alpha = nullptr;          // nullptr: no PReLU
+  const float* mean = nullptr;
+  const float* invstd = nullptr;
+  const double* acc = nullptr;
+  double count = 0.0;
+  float* dgamma = nullptr;
+  float* dbeta = nullptr;
+  float* dalpha = nullptr;
+  int accumulate = 0;
+  unsigned short* store = nullptr;
+};
+// tab: LDS table [7][C]: scale, shift, alpha, mean, invstd, k1 = s0 / n, k2 = s1 / n
+__device__ __forceinline__ void bnbin_fill_acc(const BnBwdIn& f, float* tab, int C, int t, int nt, bool writer) {
+  for (int c = t; c < C; c += nt) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < MSML_ACC_ROWS; r++) {
+      s0 += f.acc[(r * 3 + 0) * C + c];
+      s1 += f.acc[(r * 3 + 1) * C + c];
+      s2 += f.acc[(r * 3 + 2) * C + c];
+    }
+    tab[c] = f.scale[c];
+    tab[C + c] = f.shift[c];
+    tab[2 * C + c] = f.alpha ? f.alpha[c] : 1.f;
+    tab[3 * C + c] = f.mean[c];
+    tab[4 * C + c] = f.invstd[c];
+    tab[5 * C + c] = (float)(s0 / f.count);
+    tab[6 * C + c] = (float)(s1 / f.count);
+    if (writer) {
+      if (f.dbeta) f.dbeta[c] = (f.accumulate ? f.dbeta[c] : 0.f) + (float)s0;
+      if (f.dgamma) f.dgamma[c] = (f.accumulate ? f.dgamma[c] : 0.f) + (float)s1;
+      if (f.dalpha) f.dalpha[c] = (f.accumulate ? f.dalpha[c] : 0.f) + (float)s2;
+    }
+  }
+}
+// one 16-B chunk (8 channels from `ch`) of the LDS image holds dy; xraw = the same chunk of the saved BatchNorm input
+__device__ __forceinline__ void bnbin_chunk(char* lds16, const u32x4& xraw, const float* tab, int C, int ch, bool has_alpha) {
+#pragma unroll 1
+  for (int hf = 0; hf < 2; hf++) {
+    u32x2 raw = *reinterpret_cast<const u32x2*>(lds16 + hf * 8);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + ch + hf * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(tab + C + ch + hf * 4);
+    const f32x4 al = *reinterpret_cast<const f32x4*>(tab + 2 * C + ch + hf * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + 3 * C + ch + hf * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(tab + 4 * C + ch + hf * 4);
+    const f32x4 k1 = *reinterpret_cast<const f32x4*>(tab + 5 * C + ch + hf * 4);
+    const f32x4 k2 = *reinterpret_cast<const f32x4*>(tab + 6 * C + ch + hf * 4);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned int gw = raw[j >> 1], xw = xraw[hf * 2 + (j >> 1)];
+      float gg = (j & 1) ? __uint_as_float(gw & 0xffff0000u) : __uint_as_float(gw << 16);
+      const float v = (j & 1) ? __uint_as_float(xw & 0xffff0000u) : __uint_as_float(xw << 16);
+      if (has_alpha) {
+        float z = v * sc[j] + sh[j];
+        if (z <= 0.f) gg *= al[j];
+      }
+      float xh = (v - mu[j]) * is[j];
+      o[j] = sc[j] * (gg - k1[j] - xh * k2[j]);
+    }
+    raw[0] = (unsigned int)f2bf(o[0]) | ((unsigned int)f2bf(o[1]) << 16);
+    raw[1] = (unsigned int)f2bf(o[2]) | ((unsigned int)f2bf(o[3]) << 16);
+    *reinterpret_cast<u32x2*>(lds16 + hf * 8) = raw;
+  }
+}
+
 struct BnbCoef {
   float sc[8], sh[8], al[8], is[8], nm[8];     // nm = -mean * invstd: xhat = x * is + nm
 };

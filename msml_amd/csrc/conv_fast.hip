@@ -559,7 +559,8 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
                              int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
                              const float* scale, const float* alpha, const void* residual, int res_first,
-                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin = nullptr, int x3 = 0);
+                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin = nullptr, int x3 = 0,
+                             const BnBwdIn* bin = nullptr);
 
 // Called by msml_conv2d (conv_igemm.hip) when the fast-path conditions hold.  Returns false if
 // this kernel does not apply.

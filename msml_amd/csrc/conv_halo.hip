@@ -46,6 +46,7 @@ struct ConvHaloArgs {
   int stats_acc;      // accumulator mode (common.h): stats is double[MSML_ACC_ROWS][2][coutp]
   BnBwdFuse bnb;      // bnb.partial != nullptr: fused BatchNorm backward-reduce (common.h)
   BnIn xin;           // xin.scale != nullptr: BatchNorm(+PReLU) applied to the input image in LDS (common.h)
+  BnBwdIn bin;        // bin.x != nullptr: BatchNorm BACKWARD applied to the input image in LDS (common.h; XB kernels)
 };
 
 #define HALO_OOB 0x78000000u
@@ -63,7 +64,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // M16: the MFMAs are v_mfma_f32_16x16x32_bf16 (28 accumulator tiles of 16 channels x 16 pixels per wave instead of 7 of
 // 32 x 32): same fragments, LDS reads and FLOP per stage, but the chip holds a higher clock under a 16x16x32 stream
 // (MI355X_MICROARCH.md, DVFS give-back item 7).  Plain forward and FUSE launches only (no XF / X3).
-template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false>
+// XB: backward-data launch whose input is the BatchNorm backward of (in = dy, bin.x = the BatchNorm's saved input), applied
+// per slab in LDS from the producer's accumulated sums, written through to bin.store (M16 + FUSE instantiations only).
+template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo(const ConvHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -123,6 +126,7 @@ k_conv_halo(const ConvHaloArgs p) {
     const int logical = (lane & 7) ^ skey(row);
     boffg[i] = (unsigned int)((n0 + kg * 32 + row) * p.Ktot) * 2u + logical * 16u;
   }
+  u32x4 xr2[XB ? NAI : 1];                             // XB: this lane's chunks of the BatchNorm's saved input
   auto issue_a = [&](int cs, int buf) {
     char* a = As + buf * ABYTES;
 #pragma unroll
@@ -130,6 +134,11 @@ k_conv_halo(const ConvHaloArgs p) {
       const int j = wave + i * NW;
       if (j < NAJ)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(a + j * 1024), 16, aoff[i] + cs * 128u, 0, 0, 0);
+      if constexpr (XB) {
+        xr2[i] = (j < NAJ && aoff[i] != HALO_OOB)
+                     ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.bin.x) + aoff[i] + cs * 128u)
+                     : u32x4{0, 0, 0, 0};
+      }
     }
   };
   // XF: every wave normalises the chunks it DMA'd itself (ordered by its own vmcnt wait); the
@@ -143,12 +152,14 @@ k_conv_halo(const ConvHaloArgs p) {
       const int hp = j * 8 + (lane >> 3);
       const int logical = (lane & 7) ^ skey(hp);
       if (j < NAJ && aoff[i] != HALO_OOB) {
-        bn_in_chunk(a + j * 1024 + lane * 16, xtab, p.C, cs * 64 + logical * 8, has_alpha);
+        if constexpr (XB) bnbin_chunk(a + j * 1024 + lane * 16, xr2[i], xtab, p.C, cs * 64 + logical * 8, p.bin.alpha != nullptr);
+        else bn_in_chunk(a + j * 1024 + lane * 16, xtab, p.C, cs * 64 + logical * 8, has_alpha);
         // write-through of the normalised image (accumulator mode): the pixels this tile OWNS (not its halo), once
         // per pixel tile (the first channel block of the grid)
         const int hy = hp >> PL2, hx = hp & (PITCH - 1);
-        if (p.xin.store && blockIdx.y == 0 && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW)
-          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.xin.store) + aoff[i] + cs * 128u) =
+        unsigned short* through = XB ? p.bin.store : p.xin.store;
+        if (through && blockIdx.y == 0 && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(through) + aoff[i] + cs * 128u) =
               *reinterpret_cast<const u32x4*>(a + j * 1024 + lane * 16);
       }
     }
@@ -164,6 +175,7 @@ k_conv_halo(const ConvHaloArgs p) {
   // D = W_frag x X_frag: accumulator rows = output channels, columns (lanes) = pixels, so a lane
   // ends up with 4 consecutive channels of one pixel per register quad (8-B LDS stores below)
   static_assert(!M16 || !X3, "the 16x16x32 variant serves the plain forward, FUSE and XF launches");
+  static_assert(!XB || (M16 && FUSE && !XF), "the backward input transform rides on the 16x16x32 FUSE launch");
   constexpr int NG = 2 * MTW, NGH = NG / 2;            // M16: 16-pixel groups of one wave (at most), per pipeline phase
   f32x16 acc[M16 ? 1 : MTW];
   f32x4 acc4[M16 ? NG : 1][2];                         // M16: [pixel group][channel half]: channels 16 g + 4 q + j
@@ -202,8 +214,9 @@ k_conv_halo(const ConvHaloArgs p) {
     if (p.xin.acc) bn_in_fill_acc(p.xin, xtab, p.C, t, NT, blockIdx.x == 0 && blockIdx.y == 0);
     else bn_in_fill(p.xin, xtab, 0, p.C, t, NT);
   }
+  if (XB) bnbin_fill_acc(p.bin, xtab, p.C, t, NT, blockIdx.x == 0 && blockIdx.y == 0);
   __syncthreads();                                     // (drains vmcnt first)
-  if (XF) {
+  if (XF || XB) {
     xform(0, 0);
     __syncthreads();
   }
@@ -223,7 +236,7 @@ k_conv_halo(const ConvHaloArgs p) {
     }
 #endif
     // (the image chunks requested one stage ago have landed for this wave: the wait above)
-    if (XF && tr == 0 && ts == 1 && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
+    if ((XF || XB) && tr == 0 && ts == 1 && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
 #ifndef HALO_ABLATE_COMPUTE
     const int r = p.flip ? 2 - tr : tr, s = p.flip ? 2 - ts : ts;
@@ -586,19 +599,20 @@ k_conv_halo(const ConvHaloArgs p) {
 #endif
 }
 
-template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false>
+template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false>
 static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;      // two halo images + eight private weight rings
   size_t olds = (size_t)224 * (BN + 8) * 2;
   if (olds > lds) lds = olds;
   if (XF) lds += 3 * 1024 * sizeof(float);             // coefficient table, C <= 1024
+  if (XB) lds += 7 * 512 * sizeof(float);              // backward coefficient table, C <= 512
   static std::once_flag attr_once;                     // (per template instantiation; launches come from
   std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF, X3, M16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   dim3 grid(a.N * a.tpy * a.tpx, a.coutp / BN);
-  k_conv_halo<BN, NWM, FUSE, XF, X3, M16><<<grid, dim3(512), lds, st>>>(a);
+  k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB><<<grid, dim3(512), lds, st>>>(a);
 }
 
 // Shape test shared by the dispatch and by msml_conv2d_kernel (the name query).
@@ -625,9 +639,10 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
                              int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
                              const float* scale, const float* alpha, const void* residual, int res_first,
-                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin, int x3) {
+                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin, int x3, const BnBwdIn* bin) {
   if (!msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
     return false;
+  if (bin && (!bnb || !transposed || x3 || xin || c0p > 512)) return false;
   if (x3 && (bnb || xin || stats || transposed)) return false;
   if (bnb && (bias || scale || alpha || residual || stats)) return false;
   if (xin && (bnb || transposed || c0p > 1024)) return false;
@@ -647,12 +662,19 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   if (bnb) a.bnb = *bnb;
   a.xin = BnIn{nullptr, nullptr, nullptr};
   if (xin) a.xin = *xin;
+  a.bin = BnBwdIn{};
+  if (bin) a.bin = *bin;
   if (bnb_rows) *bnb_rows = (int)tiles;
   const bool wide = coutp % 256 == 0;
   // the 16x16x32 MFMA variant serves the plain forward / FUSE launches (round 4: +4...8 % on every shape, interleaved
   // A/B on one box, LDS conflicts 0.7 %).  MSML_HALO_M16=0 restores the 32x32x16 kernels, 1 limits
   // the variant to the 256-channel tile.
   static const int m16 = getenv("MSML_HALO_M16") ? atoi(getenv("MSML_HALO_M16")) : 2;
+  if (bin) {                             // BatchNorm backward in the prologue: 16x16x32 FUSE instantiations only
+    if (wide) launch_halo<256, 1, true, false, false, true, true>(a, st);
+    else launch_halo<128, 2, true, false, false, true, true>(a, st);
+    return true;
+  }
   if (m16 && !x3 && (wide || m16 >= 2)) {
     if (xin) {                           // (same tiling as the plain launch: the two stay bit-identical)
       if (wide) launch_halo<256, 1, false, true, false, true>(a, st);

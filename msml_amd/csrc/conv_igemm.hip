@@ -522,7 +522,7 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
                              int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
                              const float* scale, const float* alpha, const void* residual, int res_first,
-                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin, int x3 = 0);
+                             const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin, int x3 = 0, const BnBwdIn* bin = nullptr);
 bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out,
                            int coutp, float* stats, int N, int H, int W, int P, int Q, int R, int S,
                            int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
@@ -601,6 +601,52 @@ extern "C" int msml_conv2d_bnin_acc(const void* in0, int c0p, const double* acc_
   msml_tl_stats_acc = 0;
   MSML_CHECK(ok, MSML_ERR_UNSUPPORTED, "conv2d_bnin_acc: launch refused");
   MSML_LAUNCH_OK("conv2d_bnin_acc");
+  return MSML_OK;
+}
+
+// 1 when msml_conv2d_bnbwd_in_acc serves the shape: 3x3 / stride-1 backward-data conv on the halo-tile kernel, <= 512
+// input channels (the LDS coefficient table), accumulator-mode sums on both BatchNorms.
+extern "C" int msml_conv2d_bnbwd_in_acc_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S,
+                                                int stride, int pad_h, int pad_w) {
+  if (getenv("MSML_NO_FAST_CONV") || c0p > 512 || c0p % 8 || 256 % (c0p / 8) || coutp % 8 || 256 % (coutp / 8) ||
+      (long)N * P * Q >= (1L << 24))
+    return 0;
+  const int bn = msml_conv_tile_n(coutp), kop = cdiv(coutp, bn) * bn;
+  return msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, false) ? 1 : 0;
+}
+
+// BatchNorm backward -> backward-data conv -> (sums of the next BatchNorm backward) in ONE launch, accumulator mode:
+// in0 = dy, the gradient of the UPPER BatchNorm's output (bn3 of an IBasicBlock for conv2's backward-data, bn2 (+ PReLU)
+// for conv1's: backbones/frb/iresnet.py:59-65); up_* describe that BatchNorm (saved input up_x, coefficients, the three
+// sums up_acc = double[8][3][c0p] its producer accumulated); its input gradient dc = scale * (g - s0 / n - xhat * s1 / n)
+// is formed per slab in LDS, written through to dc_out (the weight gradient reads it) and convolved; one workgroup adds
+// dgamma / dbeta / dalpha.  The conv epilogue then accumulates the sums of the LOWER BatchNorm (bn_*: msml_conv2d_bnbwd_acc).
+// Replaces msml_bn_fin_bwd_apply (no add / next) + msml_conv2d_bnbwd_acc bit for bit.
+extern "C" int msml_conv2d_bnbwd_in_acc(const void* in0, int c0p, const void* up_x, const float* up_scale,
+                                        const float* up_shift, const float* up_alpha, const float* up_mean,
+                                        const float* up_invstd, const double* up_acc, float* dgamma, float* dbeta,
+                                        float* dalpha, int accumulate, void* dc_out, const void* wp, int kop, void* out,
+                                        int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                                        int pad_h, int pad_w, const void* bn_x, const float* bn_scale,
+                                        const float* bn_shift, const float* bn_alpha, const float* bn_mean,
+                                        const float* bn_invstd, double* acc, void* stream) {
+  MSML_CHECK(in0 && up_x && up_scale && up_shift && up_mean && up_invstd && up_acc && dc_out && wp && out && bn_x &&
+                 bn_scale && bn_shift && bn_mean && bn_invstd && acc, MSML_ERR_SHAPE, "conv2d_bnbwd_in_acc: null pointer");
+  const int bn = msml_conv_tile_n(coutp);
+  MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_bnbwd_in_acc: packed weight rows");
+  MSML_CHECK(msml_conv2d_bnbwd_in_acc_applies(c0p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w), MSML_ERR_UNSUPPORTED,
+             "conv2d_bnbwd_in_acc: shape not covered by the halo-tile kernel");
+  BnBwdFuse f{(const unsigned short*)bn_x, bn_scale, bn_shift, bn_alpha, bn_mean, bn_invstd, reinterpret_cast<float*>(acc), 1};
+  BnBwdIn b;
+  b.x = (const unsigned short*)up_x; b.scale = up_scale; b.shift = up_shift; b.alpha = up_alpha; b.mean = up_mean;
+  b.invstd = up_invstd; b.acc = up_acc; b.count = (double)N * H * W; b.dgamma = dgamma; b.dbeta = dbeta; b.dalpha = dalpha;
+  b.accumulate = accumulate; b.store = (unsigned short*)dc_out;
+  int rows = 0;
+  const bool ok = msml_conv_halo_dispatch(in0, c0p, wp, kop, nullptr, out, coutp, nullptr, N, H, W, P, Q, R, S, stride,
+                                          pad_h, pad_w, 1, (hipStream_t)stream, nullptr, nullptr, nullptr, 0, &f, &rows,
+                                          nullptr, 0, &b);
+  MSML_CHECK(ok, MSML_ERR_UNSUPPORTED, "conv2d_bnbwd_in_acc: launch refused");
+  MSML_LAUNCH_OK("conv2d_bnbwd_in_acc");
   return MSML_OK;
 }
 

@@ -305,6 +305,45 @@ def conv2d_bnin_acc(x, acc_in, bnp, alpha, wp, coutp, real=None):
     return act, coef, out, acc_out
 
 
+# The backward counterpart (msml_conv2d_bnbwd_in_acc): the BatchNorm backward-apply in front of a backward-data conv is
+# formed in that conv's prologue from the producer's accumulated sums, written through for the weight gradient.
+# Measured (round 4, one box, 12 steps, twice): bit-identical but NOT faster -- 30.27 / 30.34 ms without, 30.41 / 30.41 ms
+# with (the transform needs the BatchNorm's saved input as a second operand, 25 MB more per launch through the conv's
+# load path, and lands on a kernel that already sits at 245 VGPRs), so it is opt-in: MSML_BNBWD_IN=1.
+BNBWD_IN = os.environ.get("MSML_BNBWD_IN") is not None
+BNBWD_IN_MIN_C = int(os.environ.get("MSML_BNBWD_IN_MIN_C", "256"))
+_BNBWD_IN_OK = {}
+
+
+def bnbwd_in_applies(n, h, w, c_dy, c_dx, r, s, stride, pad):
+    key = (n, h, w, c_dy, c_dx, r, s, stride, pad)
+    ok = _BNBWD_IN_OK.get(key)
+    if ok is None:
+        ok = bool(BNBWD_IN and ACC_STATS and FUSE_BN_BWD and c_dy >= BNBWD_IN_MIN_C and r == 3 and s == 3 and stride == 1
+                  and pad == 1 and _lib.value("msml_conv2d_bnbwd_in_acc_applies", c_dy, c_dx, n, h, w, h, w, 3, 3, 1, 1, 1))
+        _BNBWD_IN_OK[key] = ok
+    return ok
+
+
+def conv_dgrad_bnbwd_in(dy, up_x, up_coef, up_alpha, up_acc, tg, accumulate, wp, coutp, bn_x, coef, alpha, real=None):
+    """BatchNorm backward (upper BatchNorm: saved input up_x, coef[4][C], sums up_acc, parameter-gradient targets tg =
+    (dgamma, dbeta, dalpha)) -> 3x3 / stride-1 backward-data conv -> sums of the lower BatchNorm (bn_x, coef, alpha) in
+    one launch.  Returns (dc = the upper BatchNorm's input gradient, dx of the conv, accumulator of the lower sums)."""
+    n, h, w, c0p = dy.shape
+    dc = torch.empty_like(dy)
+    out = torch.empty(n, h, w, coutp, dtype=torch.bfloat16, device=dy.device)
+    acc = stats_acc(coutp, dy.device, 3)
+    cin, cout = real if real is not None else (c0p, coutp)
+    name = "conv_igemm"
+    if PROFILE.on:
+        name = conv_label("T+bnb+bn", c0p, 0, coutp, n, h, w, h, w, 3, 3, 1, 1, 1, 1, BF16, BF16, False)
+    with PROFILE.rec(name, 2.0 * n * h * w * cin * cout * 9):
+        call("msml_conv2d_bnbwd_in_acc", dy, c0p, up_x, up_coef[0], up_coef[1], up_alpha, up_coef[2], up_coef[3], up_acc,
+             tg[0], tg[1], tg[2], int(accumulate), dc, wp, wp.shape[0], out, coutp, n, h, w, h, w, 3, 3, 1, 1, 1,
+             bn_x, coef[0], coef[1], alpha, coef[2], coef[3], acc)
+    return dc, out, acc
+
+
 def conv2d_bnin(x, coef, alpha, wp, coutp, real=None):
     """3x3 / stride-1 / pad-1 forward conv on PReLU(x * coef[0] + coef[1]) applied in LDS
     (msml_conv2d_bnin); returns (out, statistics partial rows of out)."""

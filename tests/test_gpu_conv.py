@@ -820,3 +820,48 @@ def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     assert torch.equal(coef_b, coef_a)
     assert torch.equal(rm_b, rm_a) and torch.equal(rv_b, rv_a)
     assert torch.allclose(st_b.sum(0), st_a.sum(0), rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("with_alpha", [False, True])
+@pytest.mark.parametrize("shape", [(7, 256, 256, 14, 14), (4, 256, 128, 13, 27), (3, 512, 256, 14, 14), (5, 256, 512, 14, 14),
+                                   (9, 128, 128, 28, 28)])
+def test_conv_dgrad_bn_backward_in_the_prologue(shape, with_alpha):
+    """msml_conv2d_bnbwd_in_acc: BatchNorm backward (sums from the producer's accumulator) -> 3x3 backward-data conv ->
+    sums of the next BatchNorm backward in ONE launch, against msml_bn_fin_bwd_apply + msml_conv2d_bnbwd_acc: the
+    BatchNorm's input gradient (written through), the conv's input gradient and the parameter gradients bit for bit,
+    the lower sums to the order of the f64 adds."""
+    n, cdy, cdx, h, w_ = shape            # dy has cdy channels (the conv's output side), dx cdx
+    g = torch.Generator().manual_seed(sum(shape) + int(with_alpha))
+    rnd = lambda *s: torch.randn(*s, generator=g)       # noqa: E731
+    dy = ops.to_nhwc(rnd(n, cdy, h, w_).cuda(), _lib.BF16)
+    up_x = ops.to_nhwc((rnd(n, cdy, h, w_) * 1.3 + 0.2).cuda(), _lib.BF16)
+    up_coef = torch.stack([torch.rand(cdy, generator=g) + 0.5, rnd(cdy) * 0.3, rnd(cdy) * 0.2,
+                           torch.rand(cdy, generator=g) + 0.5]).cuda()
+    up_alpha = (torch.rand(cdy, generator=g) * 0.3).cuda() if with_alpha else None
+    m = n * h * w_
+    up_acc = (torch.randn(8, 3, cdy, generator=g, dtype=torch.float64) * (m ** 0.5) / 8).cuda()
+    w = (rnd(cdy, cdx, 3, 3) * (2.0 / (cdx * 9)) ** 0.5).cuda()
+    wp = ops.pack_weight(w, True, cdy, 0, _lib.BF16)
+    bn_x = ops.to_nhwc(rnd(n, cdx, h, w_).cuda(), _lib.BF16)
+    coef = torch.stack([torch.rand(cdx, generator=g) + 0.5, rnd(cdx) * 0.3, rnd(cdx) * 0.2,
+                        torch.rand(cdx, generator=g) + 0.5]).cuda()
+    alpha = (torch.rand(cdx, generator=g) * 0.3).cuda()
+    assert _lib.value("msml_conv2d_bnbwd_in_acc_applies", cdy, cdx, n, h, w_, h, w_, 3, 3, 1, 1, 1) == 1
+    # two launches
+    pg_a = [torch.full((cdy,), 0.25, device="cuda") for _ in range(3)]
+    dc_a = torch.empty_like(dy)
+    _lib.call("msml_bn_fin_bwd_apply", dy, up_x, up_coef[0], up_coef[1], up_alpha, up_coef[2], up_coef[3], up_acc, None,
+              None, 0, 0, dc_a, None, pg_a[0], pg_a[1], pg_a[2] if with_alpha else None, 1, m, cdy, None, None, None, None,
+              _lib.BF16)
+    dx_a, acc_a = ops.conv_dgrad_bnbwd(dc_a, wp, cdx, 3, 3, 1, 1, 1, h, w_, bn_x, coef, alpha)
+    # one launch
+    pg_b = [torch.full((cdy,), 0.25, device="cuda") for _ in range(3)]
+    dc_b, dx_b, acc_b = ops.conv_dgrad_bnbwd_in(dy, up_x, up_coef, up_alpha, up_acc,
+                                                (pg_b[0], pg_b[1], pg_b[2] if with_alpha else None), True, wp, cdx, bn_x,
+                                                coef, alpha)
+    torch.cuda.synchronize()
+    assert torch.equal(dc_b, dc_a)
+    assert torch.equal(dx_b, dx_a)
+    for a, b in zip(pg_a[:3 if with_alpha else 2], pg_b):
+        assert torch.equal(a, b)
+    assert acc_a.dtype == torch.float64 and torch.allclose(acc_b.sum(0), acc_a.sum(0), rtol=1e-11, atol=1e-9)
