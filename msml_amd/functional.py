@@ -227,7 +227,9 @@ class _BnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, stats, gamma, beta, alpha, residual, rmean, rvar, training, momentum, eps,
-                res_first):
+                res_first, emit=False):
+        # emit (accumulator mode only): also return the (sum, sumsq) accumulator of the OUTPUT -- the statistics the next
+        # BatchNorm needs (the stem's output feeds layer1's first bn1: no separate statistics pass over 64 x 112 x 112)
         c = x.shape[-1]
         m = x.numel() // c
         dtype = DTYPE_OF[x.dtype]
@@ -240,14 +242,18 @@ class _BnAct(torch.autograd.Function):
         if training and stats is not None and stats.dtype == torch.float64:
             # accumulator-mode statistics (ops.ACC_STATS): finalize + apply in one launch
             y = torch.empty_like(x)
+            yacc = ops.stats_acc(c, dev) if emit else None
             with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
                 call("msml_bn_fin_act_fwd", stats, float(m), gamma, beta, rmean, rvar, momentum, eps, coef[0], coef[1],
-                     coef[2], coef[3], x, alpha, residual, int(res_first), y, m, c, None, dtype)
+                     coef[2], coef[3], x, alpha, residual, int(res_first), y, m, c, yacc, dtype)
             ctx.training = training
             ctx.has = (gamma is not None, beta is not None, alpha is not None, residual is not None)
             ctx.res_first = bool(res_first) and residual is not None and alpha is not None
             ctx.params = (gamma, beta, alpha)
             ctx.save_for_backward(x, coef, alpha, residual if ctx.res_first else None)
+            if emit:
+                ctx.mark_non_differentiable(yacc)
+                return y, yacc
             return y
         if training:
             if stats is None:
@@ -271,7 +277,7 @@ class _BnAct(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_dacc):
         x, coef, alpha, res = ctx.saved_tensors
         if not ctx.training:
             raise RuntimeError("msml_amd: backward through eval-mode BatchNorm is not supported")
@@ -310,20 +316,30 @@ class _BnAct(torch.autograd.Function):
                 pg[0] if want[0] and not inplace else None,
                 pg[1] if want[1] and not inplace else None,
                 pg[2] if want[2] and not inplace else None,
-                dy if has_r else None, None, None, None, None, None, None)
+                dy if has_r else None, None, None, None, None, None, None, None)
 
 
-def bn_act(x, stats, bn, prelu=None, residual=None, res_first=False):
+def bn_act(x, stats, bn, prelu=None, residual=None, res_first=False, emit_stats=False):
     """Apply an nn.BatchNorm module `bn` (+ optional nn.PReLU, + residual) to an NHWC tensor.
-    res_first: prelu(bn(x) + residual) instead of prelu(bn(x)) + residual."""
+    res_first: prelu(bn(x) + residual) instead of prelu(bn(x)) + residual.
+    emit_stats: (training, accumulator-mode statistics) attach the output's (sum, sumsq) accumulator to the result as
+    `_msml_stats`, where a following one-node IBasicBlock picks it up for its bn1 (blocks.iblock)."""
     if isinstance(x, SplitT):
         return bn_act_x3(x, bn, prelu, residual, res_first)
     training = bn.training
     if training:
         ops.bn_counter(bn)
-    return _BnAct.apply(x, stats, bn.weight, bn.bias, prelu.weight if prelu is not None else None,
-                        residual, bn.running_mean, bn.running_var, training,
-                        0.1 if bn.momentum is None else bn.momentum, bn.eps, res_first)
+    c = x.shape[-1]
+    emit = bool(emit_stats and training and ops.EMIT_STEM_STATS and x.dtype == torch.bfloat16 and ops.acc_applies(c, BF16)
+                and (stats is None or stats.dtype == torch.float64) and 256 % (c // 8) == 0)
+    out = _BnAct.apply(x, stats, bn.weight, bn.bias, prelu.weight if prelu is not None else None,
+                       residual, bn.running_mean, bn.running_var, training,
+                       0.1 if bn.momentum is None else bn.momentum, bn.eps, res_first, emit)
+    if emit:
+        y, yacc = out
+        y._msml_stats = yacc
+        return y
+    return out
 
 
 class _FmFuse(torch.autograd.Function):
@@ -790,7 +806,8 @@ def stem_conv_bn(raw, conv_m, bn_m, prelu):
                  1, 0, 0, 0)
         return out
     y, stats = _StemConv.apply(conv_m.weight, conv_m, raw.raw)
-    return bn_act(y, stats if stats.numel() else None, bn_m, prelu)
+    # (the stem's output is the input of layer1's first bn1: its statistics ride on this BatchNorm's apply pass)
+    return bn_act(y, stats if stats.numel() else None, bn_m, prelu, emit_stats=True)
 
 
 # ---------------------------------------------------------------------------------------------

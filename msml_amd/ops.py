@@ -456,6 +456,8 @@ FUSE_BN_BWD = os.environ.get("MSML_NO_FUSE_BN_BWD") is None
 # it on one box (31.41 / 31.45 -> 31.50 / 31.55 ms: the burstier issue shifts the interleaving of the streams), so it is
 # opt-in for hosts that cannot keep ahead of the GPU: MSML_BLOCK_C_ENTRY=1
 BLOCK_C_ENTRY = os.environ.get("MSML_BLOCK_C_ENTRY") is not None
+# The stem's BatchNorm + PReLU pass also emits the statistics of its output for layer1's first bn1 (no bn_stats pass)
+EMIT_STEM_STATS = os.environ.get("MSML_NO_EMIT_STEM_STATS") is None
 # FMCnn: the two gradients of the stage input (same_conv path + act / arith / skip path) summed in same_conv's backward-data
 # epilogue instead of by autograd's fan-out add
 FM_TEE = os.environ.get("MSML_NO_FM_TEE") is None
