@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int i0 = 2 * mg, nmt = mg < 3 ? 2 : 1;         // this wave's 32-pixel tiles [i0, i0 + nmt)
   const int r32 = lane & 31, h = lane >> 5;
   const int l16 = lane & 15, q16 = lane >> 4;          // M16: row inside a 16-group, 8-deep k block
-  static_assert(!M16 || !XF, "the 16x16x32 variant serves the plain and FUSE launches");
+  
   auto skey = [](int p_) { return M16 ? (p_ & 7) : ((p_ >> 1) & 7); };      // chunk swizzle of LDS row p (conv_halo.hip)
   const int tpi = p.tpy * p.tpx;
 
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int i = 0; i < 4; i++) {
       const int j = wave + i * 8;
       const int hp = j * 8 + (lane >> 3);
-      const int logical = (lane & 7) ^ ((hp >> 1) & 7);
+      const int logical = (lane & 7) ^ skey(hp);
       const int iy = y0 + (hp >> PL2) - 1, ix = x0 + (hp & (PITCH - 1)) - 1;
       if (((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W))
         bn_in_chunk(a + j * 1024 + lane * 16, xtab, C, logical * 8, has_alpha);
@@ -212,6 +212,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int step = 0; step < 18; step++) {
         const int cb = step & 1, nb = cb ^ 1;
+        if (XF && step == 8 && tile + (int)gridDim.x < p.ntiles) {     // next image: requested at the top of this tile
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          xform(tile + gridDim.x, cur ^ 1);
+        }
         if (step + 1 < 18) frags(step + 1, a16[nb], b16[nb]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -465,7 +469,7 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
   // 16x16x32 variant: measured neutral here (64 -> 64 @ 112x112 forward 426 -> 408 us, backward-data and the 56x56 maps
   // +-1 %: this kernel waits on its image loads and transposes, not on the MFMA clock) -- opt-in, MSML_WS_M16=1
   static const bool m16 = getenv("MSML_WS_M16") && atoi(getenv("MSML_WS_M16")) != 0;
-  if (xin) launch_ws<false, true>(a, st);
+  if (xin) { if (m16) launch_ws<false, true, true>(a, st); else launch_ws<false, true>(a, st); }   // (same tiling as the plain launch)
   else if (bnb) { if (m16) launch_ws<true, false, true>(a, st); else launch_ws<true>(a, st); }
   else { if (m16) launch_ws<false, false, true>(a, st); else launch_ws<false>(a, st); }
   return true;
