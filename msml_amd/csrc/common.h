@@ -265,6 +265,27 @@ __device__ __forceinline__ void bn_in_chunk(char* lds16, const float* tab, int C
   }
 }
 
+// bn_in_chunk with the lane's coefficients in registers (the 16x16x32 halo conv: a lane transforms the SAME 8 channels in
+// every chunk of a slab, so the table is read once per slab instead of once per chunk); same arithmetic and rounding.
+__device__ __forceinline__ void bn_in_chunk_r(char* lds16, const f32x4 (&sc)[2], const f32x4 (&sh)[2], const f32x4 (&al)[2],
+                                              bool has_alpha) {
+#pragma unroll
+  for (int hf = 0; hf < 2; hf++) {
+    u32x2 raw = *reinterpret_cast<const u32x2*>(lds16 + hf * 8);
+    float z[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float x = (j & 1) ? __uint_as_float(raw[j >> 1] & 0xffff0000u) : __uint_as_float(raw[j >> 1] << 16);
+      float y = x * sc[hf][j] + sh[hf][j];
+      if (has_alpha) y = y > 0.f ? y : y * al[hf][j];
+      z[j] = y;
+    }
+    raw[0] = (unsigned int)f2bf(z[0]) | ((unsigned int)f2bf(z[1]) << 16);
+    raw[1] = (unsigned int)f2bf(z[2]) | ((unsigned int)f2bf(z[3]) << 16);
+    *reinterpret_cast<u32x2*>(lds16 + hf * 8) = raw;
+  }
+}
+
 // ---- BatchNorm backward-reduce fused into a backward-data conv epilogue ---------------------
 // The conv's output dX is the gradient dy of a training-mode BatchNorm(+PReLU) output; the conv
 // epilogue accumulates that BatchNorm's backward sums from the bf16-rounded dX it stores and the

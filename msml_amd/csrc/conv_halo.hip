@@ -146,6 +146,18 @@ k_conv_halo(const ConvHaloArgs p) {
   auto xform = [&](int cs, int buf) {
     char* a = As + buf * ABYTES;
     const bool has_alpha = p.xin.alpha != nullptr;
+    // 16x16x32 tiling (key p & 7): hp & 7 == (lane >> 3) & 7 for every chunk of this lane, i.e. ONE channel chunk per
+    // lane and slab -- its coefficients are read from the table once
+    f32x4 rsc[2], rsh[2], ral[2];
+    if constexpr (M16 && !XB) {
+      const float* tb = xtab + cs * 64 + (((lane & 7) ^ ((lane >> 3) & 7)) << 3);
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        rsc[hf] = *reinterpret_cast<const f32x4*>(tb + hf * 4);
+        rsh[hf] = *reinterpret_cast<const f32x4*>(tb + p.C + hf * 4);
+        ral[hf] = *reinterpret_cast<const f32x4*>(tb + 2 * p.C + hf * 4);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NAI; i++) {
       const int j = wave + i * NW;
@@ -153,6 +165,7 @@ k_conv_halo(const ConvHaloArgs p) {
       const int logical = (lane & 7) ^ skey(hp);
       if (j < NAJ && aoff[i] != HALO_OOB) {
         if constexpr (XB) bnbin_chunk(a + j * 1024 + lane * 16, xr2[i], xtab, p.C, cs * 64 + logical * 8, p.bin.alpha != nullptr);
+        else if constexpr (M16) bn_in_chunk_r(a + j * 1024 + lane * 16, rsc, rsh, ral, has_alpha);
         else bn_in_chunk(a + j * 1024 + lane * 16, xtab, p.C, cs * 64 + logical * 8, has_alpha);
         // write-through of the normalised image (accumulator mode): the pixels this tile OWNS (not its halo), once
         // per pixel tile (the first channel block of the grid)
