@@ -51,3 +51,61 @@ def test_state_dict_layout_matches_oracle():
     assert list(sm) == list(so)
     for k in sm:
         assert sm[k].shape == so[k].shape and sm[k].dtype == so[k].dtype, k
+
+
+def test_pmc_summary_tools_on_a_synthetic_counter_dump(tmp_path):
+    """tools/pmc_step.py / tools/pmc_traffic.py (the round's PMC summaries, profiles/r04_pmc_*.json) on a synthetic rocprofv3
+    counter_collection CSV: units (KB per dispatch), the gfx950 FETCH_SIZE doubling, family sums per step, the
+    one-layer / four-layer weight-gradient split by dispatch order."""
+    import csv
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def dump(path, rows):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            w.writerows(rows)
+    # whole-step dump: 2 steps (6 k_sgd launches), one conv kernel twice per step, one BatchNorm kernel once per step
+    step = tmp_path / "step"
+    rows, d = [], 0
+    for _ in range(2):
+        for name, f, wv in (("void k_conv_halo<256, 1, false>(ConvHaloArgs)", 1000.0, 500.0),
+                            ("void k_conv_halo<256, 1, false>(ConvHaloArgs)", 3000.0, 1500.0),
+                            ("void k_bn_fin_act_fwd<unsigned short, false>(double const*)", 100.0, 100.0),
+                            ("k_sgd(float*)", 10.0, 10.0), ("k_sgd(float*)", 10.0, 10.0), ("k_sgd(float*)", 10.0, 10.0)):
+            d += 1
+            rows.append((d, name, "FETCH_SIZE", f))
+            rows.append((d, name, "WRITE_SIZE", wv))
+    dump(str(step / "p1" / "x_counter_collection.csv"), rows)
+    out = tmp_path / "step.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_step.py"), str(step), str(out)], check=True,
+                   capture_output=True)
+    js = json.load(open(out))
+    assert js["_steps_per_pass"] == 2
+    k = js["kernels"]["k_conv_halo<256, 1, false>"]
+    assert k["launches_per_step"] == 2 and k["hbm_bytes_per_launch"] == int((2 * 2000.0 + 1000.0) * 1024)
+    assert js["families"]["conv"]["launches_per_step"] == 2
+    assert js["families"]["conv"]["hbm_bytes_per_step"] == 2 * k["hbm_bytes_per_launch"]
+    assert js["families"]["bn"]["hbm_bytes_per_launch"] == int(300.0 * 1024)
+    # dominant-launch dump: forward, backward-data, weight gradient of one layer / of four layers (alternating)
+    shp = tmp_path / "shapes"
+    seq = [("void k_conv_halo<256, 1, false, false, false, true>(ConvHaloArgs)", 10.0, 20.0),
+           ("void k_conv_halo<256, 1, true, false, false, true>(ConvHaloArgs)", 30.0, 20.0),
+           ("void k_wgrad_halo<128, false, false>(WgradHaloArgs)", 50.0, 70.0), ("k_wgrad_reduce_rows(float const*)", 5.0, 2.0),
+           ("void k_wgrad_halo<128, false, false>(WgradHaloArgs)", 120.0, 80.0), ("k_wgrad_reduce_rows(float const*)", 20.0, 9.0)]
+    for cname, idx in (("FETCH_SIZE", 1), ("WRITE_SIZE", 2)):
+        rows = [(i + 1, s[0], cname, s[idx]) for i, s in enumerate(seq + seq)]
+        dump(str(shp / ("fetch" if idx == 1 else "write") / "y_counter_collection.csv"), rows)
+    out2 = tmp_path / "traffic.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), str(shp), str(out2)], check=True,
+                   capture_output=True)
+    tj = json.load(open(out2))
+    key = "conv T+bnb c256+0->256 14x14 k3x3 s1 n256 [k_conv_halo<14x14 px x 256 ch, 8 waves>]"
+    assert tj[key]["hbm_bytes"] == int((2 * 30.0 + 20.0) * 1024)
+    assert tj["wgrad u256 v256 14x14 k3x3 s1 n256"]["hbm_bytes"] == int((2 * 55.0 + 72.0) * 1024)
+    assert tj["wgrad u256 v256 14x14 k3x3 s1 n256 x4"]["hbm_bytes"] == int((2 * 140.0 + 89.0) * 1024)
