@@ -5,10 +5,11 @@ the forward rounding of 50-100 layers: its bounds sit at 20-35 % norm-wise and c
 Here every hand-written backward of the step bench.py times -- one-node IBasicBlocks of the FRB (reference
 backbones/frb/iresnet.py:56-67) and of the OSB encoder (backbones/osb/unet.py:80-91), the FM operators'
 resblock_bottle (backbones/fm/fmoperator.py:53-68) -- is checked ON ITS OWN: msml_amd.blocks.TAP hands out the block's
-actual bf16 input, the BatchNorm coefficients it saved, the gradient it received and the gradient it returned; the
+actual bf16 input, the BatchNorm coefficients it saved, the gradient it received and the gradient it returned (module
+hooks add the block's forward OUTPUT); the
 parameter gradients are read from the flat arena (every parameter is used once, the arena was zeroed).  ONE block is
 then recomputed in f64 torch on the CPU (the oracle's block class, filled with the HIP model's parameters) from those
-same tensors, and dX, dW, dgamma, dbeta, dalpha and the saved statistics must agree to what bf16 storage costs THAT
+same tensors, and the forward output, dX, dW, dgamma, dbeta, dalpha and the saved statistics must agree to what bf16 storage costs THAT
 block on THOSE operands: the bound of every quantity is 2 x the error of the same block recomputed on the CPU under
 the bf16 rounding model of oracle/bf16_emul.py (three draws) -- a few per cent for an IBasicBlock, 5-7 % for the FM
 bottlenecks' weight gradients (three BatchNorm backward projections in a row), instead of the 20-35 % of the global
@@ -51,9 +52,12 @@ def _step_with_taps(frb, bs, fault=""):
     label = synthetic.labels(bs, 1000, seed=1)
     opt = FlatSGD([{"params": [p for p in m.parameters() if p.requires_grad], "lr": 0.1 / 512 * bs}], 0.9, 5e-4, 5.0)
     taps = []
+    outs = {}                     # id(conv1.weight) -> the block's forward output (module hooks)
 
     def tap(kind, bp, t):
         taps.append((kind, id(bp["c1"][0]), {k: (v.detach().clone() if v is not None else None) for k, v in t.items()}))
+    hooks = [mod.register_forward_hook(lambda md, inp, out: outs.__setitem__(id(md.conv1.weight), out.detach().clone()))
+             for name, mod in m.named_modules() if name and hasattr(mod, "conv1") and hasattr(mod, "bn3")]
     assert ops.BLOCK_FUNCTION and ops.FUSE_BN_BWD and ops.BOTTLE_FUNCTION
     ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
     blocks.TAP, blocks.FAULT = tap, fault
@@ -70,6 +74,10 @@ def _step_with_taps(frb, bs, fault=""):
         blocks.TAP, blocks.FAULT = None, ""
         ops.WGRAD_STREAM = ops.OSB_STREAM = None
         opt.release()
+        for h in hooks:
+            h.remove()
+    for _, wid, t in taps:
+        t["out"] = outs.get(wid)
     return m, taps, grads
 
 
@@ -147,13 +155,18 @@ def _check_block(kind, name, mod, t, grads):
     for mname, m in ref.named_modules():
         if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.PReLU)):
             watch(mname, m)
-    ref(x64).backward(dout64)
+    y64 = ref(x64)
+    y64.backward(dout64)
     for h in hooks:
         h.remove()
     want = {"dx": x64.grad.numpy()}
+    if t.get("out") is not None:           # the block's FORWARD output from the same input (train-mode statistics)
+        want["out"] = y64.detach().numpy()
     want.update({pn: p.grad.numpy() for pn, p in ref.named_parameters()})
     got = {"dx": _nchw64(t["dx"], cin).numpy()}
-    got.update({pn: grads[prefix + pn].double().numpy() for pn in want if pn != "dx"})
+    if "out" in want:
+        got["out"] = _nchw64(t["out"], cout).numpy()
+    got.update({pn: grads[prefix + pn].double().numpy() for pn in want if pn not in ("dx", "out")})
     h_tens, h_chan = _errors(got, want, terms)
     # the local bf16 floor: the same block, f32, under the rounding model, three draws
     f_tens, f_chan = {}, {}
@@ -163,10 +176,13 @@ def _check_block(kind, name, mod, t, grads):
         bf16_emul.GRID_SHIFT = shift
         try:
             xe = x64.detach().float().requires_grad_()
-            emu(xe).backward(dout64.float())
+            ye = emu(xe)
+            ye.backward(dout64.float())
         finally:
             bf16_emul.GRID_SHIFT = 0.0
         ge = {"dx": bf16_emul._r(xe.grad).double().numpy()}
+        if "out" in want:
+            ge["out"] = bf16_emul._r(ye.detach()).double().numpy()
         ge.update({pn: p.grad.double().numpy() for pn, p in emu.named_parameters()})
         a, b = _errors(ge, want, terms)
         for k, (e, fr) in a.items():
@@ -226,6 +242,7 @@ def test_deep_bf16_backward_block_by_block_f64(frb, bs, n_iblocks):
     step against ONE-block f64 recomputations from the block's own operands."""
     m, rows, n_i, n_b = _run_local_check(frb, bs)
     assert n_i == n_iblocks and n_b == 8, (n_i, n_b)
+    assert sum(1 for r in rows["norm-wise"] if r[0].endswith(".out")) == n_i + n_b       # every block's forward output too
     assert not _bad(rows), _bad(rows)[:10]
     # the bounds themselves stay small: a local bound has power (the global ones sit at 0.2-0.35)
     assert max(b for _, _, b in rows["norm-wise"]) < 0.16
