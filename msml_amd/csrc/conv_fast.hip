@@ -545,6 +545,12 @@ static void launch_fast(ConvFastArgs& a, hipStream_t st) {
   }
   size_t olds = X3 ? (size_t)BM * (BN + 4) * 4 : (sizeof(TOUT) == 2 ? (size_t)BM * (BN + 8) * 2 : 0);
   if (olds > lds) lds = olds;
+  // the fused BatchNorm backward sums meet in LDS as [threads per channel chunk][3][BN] floats: 24.5 KB for the 64-row
+  // tiles -- more than ONE stage of those tiles holds (a single-stage 1x1 launch on 64 x 64 / 64 x 128 tiles wrote past
+  // its allocation and returned wrong sums; found by the pointwise-kernel test of round 4, no layer of the MSML
+  // networks takes that combination)
+  const size_t rlds = FUSE ? (size_t)(WGM * WGN * 64 / (BN / 8)) * 3 * BN * 4 : 0;
+  if (rlds > lds) lds = rlds;
   if (lds > 64 * 1024) {                               // above the default dynamic-LDS limit
     static std::once_flag once;
     std::call_once(once, [] {
@@ -570,6 +576,11 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
                            const float* scale, const float* alpha, const void* residual, int res_first,
                            const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin = nullptr);
 
+bool msml_conv_pw_dispatch(const void* in0, int c0p, const void* wp, int kop, int ktot, const float* bias, void* out,
+                           int coutp, float* stats, int stats_acc, int N, int H, int W, int P, int Q, int R, int S,
+                           int stride, int pad_h, int pad_w, hipStream_t st, const float* scale, const float* alpha,
+                           const void* residual, int res_first, const BnBwdFuse* bnb);
+
 bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
@@ -582,6 +593,13 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   if (bnb && (out_dtype != MSML_BF16 || stats)) return false;
   if ((scale || alpha || residual) && out_dtype != MSML_BF16 && !x3) return false;
   if (c0p % 32 != 0 || (in1 && c1p % 32 != 0)) return false;
+  // 1x1 / stride-1 layers (FM bottlenecks, im2col'd stems and their backward-data convs): conv_pw.hip
+  if (!in1 && out_dtype == MSML_BF16 &&
+      msml_conv_pw_dispatch(in0, c0p, wp, kop, R * S * c0p, bias, out, coutp, stats, stats ? msml_tl_stats_acc : 0, N, H,
+                            W, P, Q, R, S, stride, pad_h, pad_w, st, scale, alpha, residual, res_first, bnb)) {
+    if (bnb_rows) *bnb_rows = 1;
+    return true;
+  }
   if (!in1 && out_dtype == MSML_BF16 &&
       msml_conv_ws_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h,
                             pad_w, transposed, st, scale, alpha, residual, res_first, bnb, bnb_rows))

@@ -229,6 +229,10 @@ def _run_local_check(frb, bs, fault=""):
         top = sorted(rr, key=lambda r: -r[1] / r[2])[:4]
         print("   %s, closest to their bounds: " % fam + "; ".join("%s %.2e (bound %.2e)" % r for r in top))
         print("      largest error %.3e, largest bound %.3e" % (max(r[1] for r in rr), max(r[2] for r in rr)))
+        fo = [r for r in rr if r[0].endswith(".out")]
+        if fo and fam == "norm-wise":
+            print("      forward outputs (%d blocks): largest error %.3e, its bound %.3e"
+                  % ((len(fo),) + max(fo, key=lambda r: r[1])[1:]))
     return m, rows, n_i, n_b
 
 

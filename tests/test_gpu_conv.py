@@ -865,3 +865,79 @@ def test_conv_dgrad_bn_backward_in_the_prologue(shape, with_alpha):
     for a, b in zip(pg_a[:3 if with_alpha else 2], pg_b):
         assert torch.equal(a, b)
     assert acc_a.dtype == torch.float64 and torch.allclose(acc_b.sum(0), acc_a.sum(0), rtol=1e-11, atol=1e-9)
+
+
+# Pointwise kernel (conv_pw.hip): 1x1 / stride-1 layers of the FM bottlenecks and the im2col'd stems -- every mode against
+# the general kernel ON THE SAME OPERANDS (bit-identical outputs: same MFMA shape, k order and rounding points) and
+# against an f64 reference; M = n h h is a multiple of 32 / of the 64- / 128-pixel work units or neither
+@pytest.mark.parametrize("shape", [(32, 64, 9, 13), (64, 32, 8, 28), (64, 64, 3, 7), (64, 128, 5, 14), (128, 64, 4, 28),
+                                   (32, 64, 1, 5), (128, 64, 1, 3)])
+def test_pointwise_conv_kernel_matches_the_general_kernel(shape, monkeypatch):
+    cin, cout, n, h = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout + n + h)
+    x = ops.to_nhwc(torch.randn(n, cin, h, h, generator=g).cuda(), _lib.BF16)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).bfloat16().float().cuda()
+    wp = ops.pack_weight(w, False, cin, 0, _lib.BF16)
+    m = n * h * h
+    monkeypatch.setattr(ops, "ACC_STATS", True)
+
+    def both(fn):
+        monkeypatch.setenv("MSML_PW_CONV", "all")      # every case the kernel supports (the default policy takes a few)
+        a = fn()
+        monkeypatch.setenv("MSML_PW_CONV", "0")
+        b = fn()
+        monkeypatch.delenv("MSML_PW_CONV", raising=False)
+        return a, b
+
+    # forward + statistics accumulator
+    (o1, s1), (o2, s2) = both(lambda: ops.conv2d(x, None, wp, None, cout, 1, 1, 1, 0, 0, False, want_stats=True))
+    assert s1.dtype == torch.float64 and s1.shape == (8, 2, cout)
+    assert torch.equal(o1, o2)
+    ref = F.conv2d(ops.to_nchw(x, cin).double(), w.double()).float()
+    assert (ops.to_nchw(o1, cout) - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+    f1, f2 = s1.sum(0), s2.sum(0)
+    assert torch.allclose(f1, f2, rtol=1e-5, atol=1e-5 * f2.abs().max().item()), (f1 - f2).abs().max()
+    # plain backward-data (transposed pack): cout -> cin
+    dy = ops.to_nhwc(torch.randn(n, cout, h, h, generator=g).cuda(), _lib.BF16)
+    wpt = ops.pack_weight(w, True, cout, 0, _lib.BF16)
+    (d1, _), (d2, _) = both(lambda: ops.conv2d(dy, None, wpt, None, cin, 1, 1, 1, 0, 0, True, p=h, q=h))
+    assert torch.equal(d1, d2)
+    # backward-data + another gradient in the epilogue (msml_conv2d_fused, unit scale / zero shift)
+    other = ops.to_nhwc(torch.randn(n, cin, h, h, generator=g).cuda(), _lib.BF16)
+    ones, zeros = torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda")
+
+    def plus():
+        out = torch.empty(n, h, h, cin, dtype=torch.bfloat16, device="cuda")
+        _lib.call("msml_conv2d_fused", dy, cout, None, 0, wpt, wpt.shape[0], ones, zeros, None, other, 0, out, cin,
+                  n, h, h, h, h, 1, 1, 1, 0, 0, 1)
+        return out
+    p1, p2 = both(plus)
+    assert torch.equal(p1, p2)
+    assert (p1.float() - (d1.float() + other.float())).abs().max().item() <= 2e-2 * p1.float().abs().max().item()
+    # ... with a real per-channel scale / shift
+    sc, sh = torch.rand(cin, generator=g).cuda() + 0.5, torch.randn(cin, generator=g).cuda() * 0.1
+
+    def affine():
+        out = torch.empty(n, h, h, cin, dtype=torch.bfloat16, device="cuda")
+        _lib.call("msml_conv2d_fused", dy, cout, None, 0, wpt, wpt.shape[0], sc, sh, None, other, 0, out, cin,
+                  n, h, h, h, h, 1, 1, 1, 0, 0, 1)
+        return out
+    a1, a2 = both(affine)
+    assert torch.equal(a1, a2)
+    # backward-data + the BatchNorm(+PReLU) backward sums of the layer in front (accumulator protocol)
+    xbn = ops.to_nhwc(torch.randn(n, cin, h, h, generator=g).cuda(), _lib.BF16)
+    coef = torch.stack([torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3,
+                        torch.randn(cin, generator=g) * 0.2, torch.rand(cin, generator=g) + 0.5]).cuda()
+    for alpha in (None, (torch.rand(cin, generator=g) * 0.5).cuda()):
+        (b1, q1), (b2, q2) = both(lambda: ops.conv_dgrad_bnbwd(dy, wpt, cin, 1, 1, 1, 0, 0, h, h, xbn, coef, alpha))
+        assert torch.equal(b1, b2) and torch.equal(b1, d1)
+        assert q1.shape == (8, 3, cin) and q1.dtype == torch.float64
+        # both against the sums recomputed in f64 from the stored gradient (bn.hip's k_bn_bwd_reduce arithmetic)
+        d, xs = b1.double().reshape(-1, cin), xbn.double().reshape(-1, cin)
+        z = xs * coef[0].double() + coef[1].double()
+        neg = (z <= 0) if alpha is not None else torch.zeros_like(z, dtype=torch.bool)
+        gg = torch.where(neg, d * alpha.double(), d) if alpha is not None else d
+        xh = (xs - coef[2].double()) * coef[3].double()
+        want = torch.stack([gg.sum(0), (gg * xh).sum(0), torch.where(neg, d * z, torch.zeros_like(z)).sum(0)])
+        for got in (q1.sum(0), q2.sum(0)):
+            assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-6, (got - want).abs().max()
