@@ -3,9 +3,11 @@
 IResNet-18 encoder (stem stride 2) + Global-Convolution modules (7x1/1x7, biased) + transposed
 convolutions on cat(seg, gcm) (two-segment implicit GEMM, concat never materialised) + DAP.
 Returns [seg0, seg1, seg2, seg3 (detached NHWC 18-channel maps), seg5 (NCHW f32 (B,2,H,W))]."""
+import torch
 import torch.nn as nn
 
 from ... import functional as Fh
+from ... import ops
 from .._nn import conv, conv_bn
 from ..frb.iresnet import IBasicBlock, make_layer
 
@@ -23,7 +25,14 @@ class _GlobalConvModule(nn.Module):
         self.conv_r2 = nn.Conv2d(out_dim, out_dim, kernel_size=(kernel_size[0], 1), padding=(pad0, 0))
 
     def forward(self, x):
-        xl, _ = conv(self.conv_l1, x)
+        if (ops.GCM_TEE and torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad
+                and x.dtype == torch.bfloat16 and (x.shape[1] in (56, 28) or ops.GCM_TEE == "all")):
+            # (the levels whose line convs run on k_conv_line; below, the sum is a few-MB add and the general kernel's
+            # residual epilogue costs more than it)
+            # x feeds both branches: their two input gradients meet in conv_l1's backward-data epilogue
+            xl, _, x = conv(self.conv_l1, x, tee=True)
+        else:
+            xl, _ = conv(self.conv_l1, x)
         xl, _ = conv(self.conv_l2, xl)
         xr, _ = conv(self.conv_r1, x)
         xr, _ = conv(self.conv_r2, xr)

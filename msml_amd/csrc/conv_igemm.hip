@@ -317,7 +317,8 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
 bool msml_conv_line_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
                             int pad_w);
 bool msml_conv_line_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
-                             int N, int H, int W, int R, int S, int transposed, hipStream_t st);
+                             int N, int H, int W, int R, int S, int transposed, hipStream_t st,
+                             const float* scale = nullptr, const void* residual = nullptr);
 
 bool msml_deconv4_applies(int c0p, int c1p, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
                           int pad_h, int pad_w, int transposed);
@@ -432,6 +433,15 @@ extern "C" int msml_conv2d_fused(const void* in0, int c0p, const void* in1, int 
   MSML_CHECK(c0p % 32 == 0 && c1p % 32 == 0 && coutp % 8 == 0, MSML_ERR_SHAPE, "conv2d_fused: channel padding");
   const int bn = msml_conv_tile_n(coutp);
   MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_fused: packed weight rows");
+  // 7x1 / 1x7 line convs (the OSB's Global-Convolution modules: the backward-data conv of conv_l1 takes conv_r1's input
+  // gradient as its residual, functional.py _ConvTee): conv_line.hip with scale / shift / residual in its epilogue
+  if (!in1 && !alpha && !(residual && res_first) && !getenv("MSML_NO_FAST_CONV") &&
+      msml_conv_line_applies(c0p, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) &&
+      msml_conv_line_dispatch(in0, c0p, wp, kop, shift, out, coutp, N, H, W, R, S, transposed, (hipStream_t)stream, scale,
+                              residual)) {
+    MSML_LAUNCH_OK("conv2d_fused(line)");
+    return MSML_OK;
+  }
   MSML_CHECK(msml_conv_fast_dispatch(in0, c0p, in1, c1p, wp, kop, shift, out, coutp, nullptr, N, H, W, P, Q,
                                      R, S, stride, pad_h, pad_w, transposed, MSML_BF16, MSML_BF16, bn,
                                      (hipStream_t)stream, scale, alpha, residual, res_first, nullptr, nullptr),

@@ -25,6 +25,9 @@ struct ConvLineArgs {
   const unsigned short* wp; unsigned int w_bytes;       // packed [COUT rows][7 * CIN]
   unsigned short* out;                                  // [N][L][L][COUT]
   const float* bias;                                    // [COUT] or null
+  const float* scale;                                   // [COUT] or null: out = acc * scale + bias
+  const unsigned short* residual;                       // [N][L][L][COUT] or null: added to the ROUNDED output, as
+                                                        // msml_conv2d_fused's general kernel does (conv_fast.hip)
   int N, L, B, tiles_per_img, ntiles;
   int vertical;                                         // 1: taps along y (7x1), 0: along x (1x7)
   int flip;                                             // 1: transposed gather (backward-data): tap t reads a + 3 - t
@@ -78,13 +81,16 @@ __global__ void __launch_bounds__(512) k_conv_line(const ConvLineArgs p) {
 
   const int r32 = lane & 31, h = lane >> 5;
   const int nblk = npix / 32;                           // 7 pixel blocks per tile
-  float bv[NCO][4][4];
+  float bv[NCO][4][4], sv[NCO][4][4];
 #pragma unroll
   for (int i = 0; i < NCO; i++)
 #pragma unroll
     for (int g = 0; g < 4; g++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) bv[i][g][j] = p.bias ? p.bias[i * 32 + 8 * g + 4 * h + j] : 0.f;
+      for (int j = 0; j < 4; j++) {
+        bv[i][g][j] = p.bias ? p.bias[i * 32 + 8 * g + 4 * h + j] : 0.f;
+        sv[i][g][j] = p.scale ? p.scale[i * 32 + 8 * g + 4 * h + j] : 1.f;
+      }
 
   int tile = blockIdx.x;
   if (tile < p.ntiles) issue(tile, 0);
@@ -132,7 +138,7 @@ __global__ void __launch_bounds__(512) k_conv_line(const ConvLineArgs p) {
         for (int g = 0; g < 4; g++) {
           float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = acc[i][g * 4 + j] + bv[i][g][j];
+          for (int j = 0; j < 4; j++) v[j] = p.scale ? acc[i][g * 4 + j] * sv[i][g][j] + bv[i][g][j] : acc[i][g * 4 + j] + bv[i][g][j];
           pk[g][0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
           pk[g][1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
         }
@@ -143,6 +149,21 @@ __global__ void __launch_bounds__(512) k_conv_line(const ConvLineArgs p) {
           auto r23 = __builtin_amdgcn_permlane32_swap(pk[2][e], pk[3][e], false, false);
           lo[e] = r01[0]; lo[2 + e] = r01[1];
           hi[e] = r23[0]; hi[2 + e] = r23[1];
+        }
+        if (valid && p.residual) {                      // (uniform branch; lane: channels 8 h .. and 16 + 8 h .. of block i)
+          const unsigned short* rp = p.residual + (o - p.out) + i * 32;
+          const u32x4 r0 = *reinterpret_cast<const u32x4*>(rp), r1 = *reinterpret_cast<const u32x4*>(rp + 16);
+          Vec8 a0 = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&lo));
+          Vec8 a1 = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&hi));
+          const Vec8 b0 = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&r0));
+          const Vec8 b1 = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&r1));
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            a0.v[q] += b0.v[q];
+            a1.v[q] += b1.v[q];
+          }
+          store8<unsigned short>(reinterpret_cast<unsigned short*>(&lo), a0);
+          store8<unsigned short>(reinterpret_cast<unsigned short*>(&hi), a1);
         }
         if (valid) {
           *reinterpret_cast<u32x4*>(o + i * 32) = lo;
@@ -185,8 +206,10 @@ static void cl_launch(const ConvLineArgs& a, hipStream_t st) {
 }
 
 bool msml_conv_line_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
-                             int N, int H, int W, int R, int S, int transposed, hipStream_t st) {
+                             int N, int H, int W, int R, int S, int transposed, hipStream_t st, const float* scale,
+                             const void* residual) {
   ConvLineArgs a;
+  a.scale = scale; a.residual = (const unsigned short*)residual;
   a.in = (const unsigned short*)in0; a.in_bytes = (unsigned int)((long)N * H * W * c0p * 2);
   a.wp = (const unsigned short*)wp; a.w_bytes = (unsigned int)((long)kop * 7 * c0p * 2);
   a.out = (unsigned short*)out; a.bias = bias;

@@ -461,6 +461,10 @@ EMIT_STEM_STATS = os.environ.get("MSML_NO_EMIT_STEM_STATS") is None
 # FMCnn: the two gradients of the stage input (same_conv path + act / arith / skip path) summed in same_conv's backward-data
 # epilogue instead of by autograd's fan-out add
 FM_TEE = os.environ.get("MSML_NO_FM_TEE") is None
+# The same for the OSB's Global-Convolution modules (unet.py:16-38 of the reference): x feeds conv_l1 (7x1) AND conv_r1
+# (1x7); conv_r1's input gradient is the residual of conv_l1's backward-data launch (k_conv_line's epilogue at the
+# 56x56 / 28x28 levels) instead of an autograd fan-out add over the feature map.  MSML_NO_GCM_TEE=1: plain graph.
+GCM_TEE = os.environ.get("MSML_NO_GCM_TEE") is None
 # 1x1 / stride-2 downsample backward kept compact and scatter-added by bn1's apply kernel
 SPARSE_DOWNSAMPLE_GRAD = os.environ.get("MSML_NO_SPARSE_DOWNSAMPLE_GRAD") is None
 
