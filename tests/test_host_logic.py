@@ -95,6 +95,7 @@ def test_pmc_summary_tools_on_a_synthetic_counter_dump(tmp_path):
     # dominant-launch dump: forward, backward-data, weight gradient of one layer / of four layers (alternating)
     shp = tmp_path / "shapes"
     seq = [("void k_conv_halo<256, 1, false, false, false, true>(ConvHaloArgs)", 10.0, 20.0),
+           ("void k_conv_halo<256, 1, false, true, false, true, false>(ConvHaloArgs)", 12.0, 44.0),      # BatchNorm in the prologue
            ("void k_conv_halo<256, 1, true, false, false, true>(ConvHaloArgs)", 30.0, 20.0),
            ("void k_wgrad_halo<128, false, false>(WgradHaloArgs)", 50.0, 70.0), ("k_wgrad_reduce_rows(float const*)", 5.0, 2.0),
            ("void k_wgrad_halo<128, false, false>(WgradHaloArgs)", 120.0, 80.0), ("k_wgrad_reduce_rows(float const*)", 20.0, 9.0)]
@@ -107,5 +108,7 @@ def test_pmc_summary_tools_on_a_synthetic_counter_dump(tmp_path):
     tj = json.load(open(out2))
     key = "conv T+bnb c256+0->256 14x14 k3x3 s1 n256 [k_conv_halo<14x14 px x 256 ch, 8 waves>]"
     assert tj[key]["hbm_bytes"] == int((2 * 30.0 + 20.0) * 1024)
+    assert tj[key.replace("T+bnb", "N+bn")]["hbm_bytes"] == int((2 * 12.0 + 44.0) * 1024)
+    assert tj[key.replace("T+bnb", "N")]["hbm_bytes"] == int((2 * 10.0 + 20.0) * 1024)
     assert tj["wgrad u256 v256 14x14 k3x3 s1 n256"]["hbm_bytes"] == int((2 * 55.0 + 72.0) * 1024)
     assert tj["wgrad u256 v256 14x14 k3x3 s1 n256 x4"]["hbm_bytes"] == int((2 * 140.0 + 89.0) * 1024)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """The dominant launches of the training step in isolation, for rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE,
 SQ_* in separate runs): the 256 -> 256 @ 14x14 backward-data conv with the fused BatchNorm backward sums
-(k_conv_halo<256>, bench label `conv T+bnb c256+0->256 14x14 k3x3 s1 n256`), the forward conv of the same layer and
+(k_conv_halo<256>, bench label `conv T+bnb c256+0->256 14x14 k3x3 s1 n256`), the forward conv of the same layer (plain, and
+with the BatchNorm + PReLU in front of it formed in its prologue: `conv N+bn ...`, the step's dominant launch since round 4) and
 its weight gradient as the step issues it -- four layers per launch pair (msml_conv_wgrad_group, label
 `wgrad u256 v256 14x14 k3x3 s1 n256 x4`) -- and, for comparison, the single-layer launch.
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/pmc_shapes.py
@@ -32,8 +33,18 @@ def main():
     need = _lib.value("msml_conv_wgrad_workspace", C, C, N, H, H, 3, 3)
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     arr = ctypes.c_void_p * 4
+    gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    rmean, rvar = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    m = N * H * H
+    accs = []
+    for r in range(REPS):                               # the statistics of each input, as its producer would have left them
+        acc = ops.stats_acc(C, xs[r].device)
+        _lib.call("msml_bn_stats_acc", xs[r], m, C, acc, _lib.BF16)
+        accs.append(acc)
     for r in range(REPS):
         ops.conv2d(xs[r], None, wp, None, C, 3, 3, 1, 1, 1, False, want_stats=True)                    # forward
+        # forward with the BatchNorm + PReLU in front of it formed in the prologue (bench label `conv N+bn ...`)
+        ops.conv2d_bnin_acc(xs[r], accs[r], (gamma, beta, rmean, rvar, 0.1, 1e-5), alpha, wp, C)
         ops.conv_dgrad_bnbwd(dys[r], wpt, C, 3, 3, 1, 1, 1, H, H, xs[r], coef, alpha)                  # backward-data + bnb
         ops.conv_wgrad(dys[r], xs[r], dws[0], C, C, C, 0, 3, 3, 1, 1, 1, accumulate=True)              # one layer
         idx = [(r + i) % REPS for i in range(4)]
@@ -41,7 +52,7 @@ def main():
                   arr(*[d.data_ptr() for d in dws]), 4, C, C, C, C, C, 0, N, H, H, H, H, 3, 3, 1, 1, 1, 1, ws, ws.numel(),
                   _lib.BF16)                                                                           # four layers
     torch.cuda.synchronize()
-    print("launched %d x (fwd, dgrad+bnb, wgrad x1, wgrad x4) at %d x %d x %d x %d" % (REPS, N, H, H, C))
+    print("launched %d x (fwd, bn+fwd, dgrad+bnb, wgrad x1, wgrad x4) at %d x %d x %d x %d" % (REPS, N, H, H, C))
 
 
 if __name__ == "__main__":

@@ -37,9 +37,9 @@ def per_kind(d, counter):
         if cn != counter:
             continue
         kind = None
-        m = re.search(r"k_conv_halo<\d+, \d+, (true|false)", name)       # third template argument = FUSE
+        m = re.search(r"k_conv_halo<\d+, \d+, (true|false), (true|false)", name)       # third / fourth template argument = FUSE / XF
         if m:
-            kind = "dgrad" if m.group(1) == "true" else "fwd"
+            kind = "dgrad" if m.group(1) == "true" else ("fwd_bn" if m.group(2) == "true" else "fwd")
         elif "k_wgrad_halo" in name:
             kind = "wgrad"
         elif "k_wgrad_reduce" in name:
@@ -65,6 +65,10 @@ def main():
           "backward-data conv with the fused BatchNorm backward sums: dY + saved BatchNorm input read, dX written")
     entry("conv N c256+0->256 14x14 k3x3 s1 n256 " + halo, "k_conv_halo<256, 1, forward, 16x16x32 MFMA>",
           mean(f["fwd"]), mean(w["fwd"]), 2 * ACT + WB, "forward conv + statistics: input once, output once")
+    if f.get("fwd_bn"):
+        entry("conv N+bn c256+0->256 14x14 k3x3 s1 n256 " + halo, "k_conv_halo<256, 1, forward, BatchNorm in the prologue, 16x16x32 MFMA>",
+              mean(f["fwd_bn"]), mean(w["fwd_bn"]), 3 * ACT + WB,
+              "BatchNorm + PReLU + conv in one launch: raw input read, normalised input written through, output written")
     # weight gradients: dispatches alternate one layer / four layers
     for which, label, layers in ((0, "wgrad u256 v256 14x14 k3x3 s1 n256", 1), (1, "wgrad u256 v256 14x14 k3x3 s1 n256 x4", 4)):
         fk = mean(f["wgrad"][which::2]) + mean(f["reduce"][which::2])
