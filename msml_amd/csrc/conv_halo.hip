@@ -235,6 +235,9 @@ k_conv_halo(const ConvHaloArgs p) {
   }
   int cs = 0, tr = 0, ts = 0;                          // slab, tap row / column of stage q
   u32x4 a[2][MTW], b[2];
+#ifdef HALO_ABLATE_READS
+  u32x4 a16x[2][MTW], b16x[2][2];                      // (ablation build: fragments read once, reused by every stage)
+#endif
   for (int q = 0; q < nstage; q++) {
     int ncs = cs, ntr = tr, nts = ts + 1;
     if (nts == 3) { nts = 0; ntr++; }
@@ -261,15 +264,27 @@ k_conv_halo(const ConvHaloArgs p) {
       const int arow = l16 + s, asw = skey(arow);
       const char* Arow = As + (cs & 1) * ABYTES + (((r << PL2) + i0 * 32) * 128) + arow * 128;
       const char* B = Bs + (q & 1) * 4096;
+#ifdef HALO_ABLATE_READS
+      if (q == 0) {
+#pragma unroll
+        for (int j = 0; j < NGH; j++) a16x[0][j] = a16x[1][j] = *reinterpret_cast<const u32x4*>(Arow + ((q16 ^ asw) << 4) + j * 2048);
+#pragma unroll
+        for (int g = 0; g < 2; g++) b16x[0][g] = b16x[1][g] = *reinterpret_cast<const u32x4*>(B + bfr16[g][0]);
+      }
+      u32x4 (&a16)[2][NGH] = a16x;
+      u32x4 (&b16)[2][2] = b16x;
+#else
       u32x4 a16[2][NGH], b16[2][2];
 #pragma unroll
       for (int j = 0; j < NGH; j++)
         if (j < ng) a16[0][j] = *reinterpret_cast<const u32x4*>(Arow + ((q16 ^ asw) << 4) + j * 2048);
 #pragma unroll
       for (int g = 0; g < 2; g++) b16[0][g] = *reinterpret_cast<const u32x4*>(B + bfr16[g][0]);
+#endif
 #pragma unroll
       for (int ph = 0; ph < 4; ph++) {
         const int cb = ph & 1, nb = cb ^ 1, w = ph >> 1, hf = ph & 1;
+#ifndef HALO_ABLATE_READS
         if (ph + 1 < 4) {
           const int nw = (ph + 1) >> 1, nhf = (ph + 1) & 1;
           const int ao = ((4 * nw + q16) ^ asw) << 4;
@@ -281,6 +296,7 @@ k_conv_halo(const ConvHaloArgs p) {
             for (int g = 0; g < 2; g++) b16[nw & 1][g] = *reinterpret_cast<const u32x4*>(B + bfr16[g][nw]);
           }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NGH; j++)
