@@ -359,7 +359,7 @@ def extra_modes(args, rank, local_rank):
     for prec in ("bf16x3", "bf16"):
         a.dtype, a.precision = "bf16", prec
         r = Inferer(a, rank, local_rank, 1)
-        dt = timed(r.step, 4, 2)
+        dt = timed(r.step, 4, 3)
         out["infer_" + prec] = {"value": round(a.batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 2),
                                 "batch": a.batch, "what": "%s-MSML embedding extraction, orig + h-flip" % args.frb}
         del r
@@ -384,7 +384,7 @@ def extra_modes(args, rank, local_rank):
     from msml_amd import ops
     ops.WGRAD_STREAM = ops.OSB_STREAM = None
     r = Trainer(a, rank, local_rank, 1)
-    dt = timed(r.step, 2, 1)
+    dt = timed(r.step, 3, 2)
     out["train_f32"] = {"value": round(a.batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 2),
                         "batch": a.batch, "what": "the headline training step on the exact-f32 MFMA path"}
     del r
