@@ -27,6 +27,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--fused", default="", choices=["", "add", "bnb"],
+                    help="1x1 backward-data launches with another gradient added / the BatchNorm backward sums in the epilogue")
     args = ap.parse_args()
     n = args.batch
     dt = _lib.BF16
@@ -47,7 +49,22 @@ def main():
         w = torch.randn(cout, cin, r, r, device="cuda") * 0.05
         wp = ops.pack_weight(w, tr, cout if tr else cin, 0, dt)
 
+        fused = tr and r == 1 and stride == 1 and args.fused          # the step's forms of the 1x1 backward-data launches
+        if fused:
+            others = [torch.randn(n, h, h, cin, device="cuda").to(torch.bfloat16) for _ in range(sets)]
+            coef = torch.rand(4, cin, device="cuda") + 0.5
+            alpha = torch.full((cin,), 0.25, device="cuda")
+            ones, zeros = torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda")
+            nbytes += 2 * n * h * h * cin                             # the second operand of the epilogue
+
         def run(i):
+            if fused and args.fused == "add":
+                out = torch.empty(n, h, h, cin, dtype=torch.bfloat16, device="cuda")
+                _lib.call("msml_conv2d_fused", xs[i % sets], cout, None, 0, wp, wp.shape[0], ones, zeros, None,
+                          others[i % sets], 0, out, cin, n, h, h, h, h, 1, 1, 1, 0, 0, 1)
+                return out
+            if fused:
+                return ops.conv_dgrad_bnbwd(xs[i % sets], wp, cin, 1, 1, 1, 0, 0, h, h, others[i % sets], coef, alpha)
             if tr:
                 return ops.conv2d(xs[i % sets], None, wp, None, cin, r, r, stride, pad, pad, True, p=h, q=h)
             return ops.conv2d(xs[i % sets], None, wp, None, cout, r, r, stride, pad, pad, False, want_stats=True)
@@ -71,9 +88,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         tc = e0.elapsed_time(e1) * 1e-3 / (args.iters * sets)
-        name = "%s %d->%d @%d k%d s%d x%d" % ("T" if tr else "N", cin, cout, h, r, stride, cnt)
+        name = "%s %d->%d @%d k%d s%d x%d" % (("T+" + args.fused if fused else "T") if tr else "N", cin, cout, h, r, stride, cnt)
         print("%-34s %9.1f %9.1f %9.0f %9.0f" % (name, nbytes / 1e6, t * 1e6, nbytes / t / 1e9, nbytes / tc / 1e9))
         del xs, src, dst
+        if fused:
+            del others
 
 
 if __name__ == "__main__":
