@@ -128,6 +128,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over the 32 lanes of each wave half, in every lane of the half: four DPP adds inside the 16-lane rows (quad
+// swaps, then the half-row and row mirrors: VALU only) and ONE cross-row exchange through the LDS crossbar.  A
+// __shfl_xor tree is five ds_bpermute per value; at 128 values per wave and 8-12 waves per CU that tree alone was a
+// fixed ~15 us at the end of every statistics launch (the crossbar moves 128 B per clock).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_half_sum(float v) {
+  v = dpp_add<0xB1>(v);                              // quad_perm [1, 0, 3, 2]
+  v = dpp_add<0x4E>(v);                              // quad_perm [2, 3, 0, 1]
+  v = dpp_add<0x141>(v);                             // row_half_mirror
+  v = dpp_add<0x140>(v);                             // row_mirror
+  return v + __shfl_xor(v, 16, 64);
+}
+
 // ... and of the three backward sums (rows [3][C])
 __device__ __forceinline__ void bnb_emit(float* partial, int acc_mode, long wg, int q, int C, int col, float v) {
   if (acc_mode)

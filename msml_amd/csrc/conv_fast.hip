@@ -576,6 +576,11 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
                            const float* scale, const float* alpha, const void* residual, int res_first,
                            const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin = nullptr);
 
+bool msml_conv_r32_dispatch(const void* in0, int c0p, const void* wp, int kop, int ktot, const float* bias, void* out,
+                            int coutp, float* stats, int stats_acc, int N, int H, int W, int P, int Q, int R, int S,
+                            int stride, int pad_h, int pad_w, int transposed, hipStream_t st, const float* scale,
+                            const float* alpha, const void* residual, const BnBwdFuse* bnb);
+
 bool msml_conv_pw_dispatch(const void* in0, int c0p, const void* wp, int kop, int ktot, const float* bias, void* out,
                            int coutp, float* stats, int stats_acc, int N, int H, int W, int P, int Q, int R, int S,
                            int stride, int pad_h, int pad_w, hipStream_t st, const float* scale, const float* alpha,
@@ -593,6 +598,13 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   if (bnb && (out_dtype != MSML_BF16 || stats)) return false;
   if ((scale || alpha || residual) && out_dtype != MSML_BF16 && !x3) return false;
   if (c0p % 32 != 0 || (in1 && c1p % 32 != 0)) return false;
+  // 32 -> 32 channel 3x3 layers (conv2 of the first FM stage's bottlenecks): conv_r32.hip
+  if (!in1 && out_dtype == MSML_BF16 &&
+      msml_conv_r32_dispatch(in0, c0p, wp, kop, R * S * c0p, bias, out, coutp, stats, stats ? msml_tl_stats_acc : 0, N, H,
+                             W, P, Q, R, S, stride, pad_h, pad_w, transposed, st, scale, alpha, residual, bnb)) {
+    if (bnb_rows) *bnb_rows = 1;
+    return true;
+  }
   // 1x1 / stride-1 layers (FM bottlenecks, im2col'd stems and their backward-data convs): conv_pw.hip
   if (!in1 && out_dtype == MSML_BF16 &&
       msml_conv_pw_dispatch(in0, c0p, wp, kop, R * S * c0p, bias, out, coutp, stats, stats ? msml_tl_stats_acc : 0, N, H,

@@ -45,22 +45,6 @@ struct ConvPwArgs {
 
 enum { PW_PLAIN = 0, PW_STATS = 1, PW_ADD = 2, PW_BNB = 3 };
 
-// Sum over the 32 lanes of each wave half, in every lane of the half: four DPP adds inside the 16-lane rows (quad
-// swaps, then the half-row and row mirrors: VALU only) and ONE cross-row exchange through the LDS crossbar.  A
-// __shfl_xor tree is five ds_bpermute per value; at 128 values per wave and 8-12 waves per CU that tree alone was a
-// fixed ~15 us at the end of every statistics launch (the crossbar moves 128 B per clock).
-template <int CTRL>
-__device__ __forceinline__ float pw_dpp_add(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float pw_half_sum(float v) {
-  v = pw_dpp_add<0xB1>(v);                              // quad_perm [1, 0, 3, 2]
-  v = pw_dpp_add<0x4E>(v);                              // quad_perm [2, 3, 0, 1]
-  v = pw_dpp_add<0x141>(v);                             // row_half_mirror
-  v = pw_dpp_add<0x140>(v);                             // row_mirror
-  return v + __shfl_xor(v, 16, 64);
-}
-
 // LDS map of a workgroup (4 waves): packed weights | epilogue table | end-of-kernel sums | per-wave scratch
 template <int CIN, int COUT>
 struct PwLds {
@@ -264,7 +248,7 @@ __global__ void __launch_bounds__(256) k_conv_pw(const ConvPwArgs p) {
       for (int g = 0; g < 4 * NCOW; g++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float a = pw_half_sum(s1[g][j]), b = pw_half_sum(s2[g][j]);
+          const float a = wave_half_sum(s1[g][j]), b = wave_half_sum(s2[g][j]);
           if (r32 == 0) {
             red[(wave * NQ + 0) * COUTW + 8 * g + 4 * h + j] = a;      // (g = 4 i + g': channel 32 i + 8 g' + 4 h + j)
             red[(wave * NQ + 1) * COUTW + 8 * g + 4 * h + j] = b;

@@ -941,3 +941,56 @@ def test_pointwise_conv_kernel_matches_the_general_kernel(shape, monkeypatch):
         want = torch.stack([gg.sum(0), (gg * xh).sum(0), torch.where(neg, d * z, torch.zeros_like(z)).sum(0)])
         for got in (q1.sum(0), q2.sum(0)):
             assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-6, (got - want).abs().max()
+
+
+# Row-streaming kernel for the 32 -> 32 channel 3x3 layers (conv_r32.hip: conv2 of the first FM stage's bottlenecks):
+# forward + statistics, plain backward-data, backward-data + BatchNorm backward sums against the general kernel on the
+# same operands (bit-identical outputs) and against f64; odd sizes, the widest row it takes, more strips than workers
+@pytest.mark.parametrize("shape", [(3, 56, 56), (2, 28, 28), (5, 14, 14), (2, 9, 13), (1, 60, 62), (1, 2, 8), (300, 56, 56)])
+def test_conv3x3_32_channel_row_kernel_matches_the_general_kernel(shape, monkeypatch):
+    n, h, w_ = shape
+    c = 32
+    g = torch.Generator().manual_seed(n * 7 + h + w_)
+    x = ops.to_nhwc(torch.randn(n, c, h, w_, generator=g).cuda(), _lib.BF16)
+    w = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5).bfloat16().float().cuda()
+    wp = ops.pack_weight(w, False, c, 0, _lib.BF16)
+    wpt = ops.pack_weight(w, True, c, 0, _lib.BF16)
+    monkeypatch.setattr(ops, "ACC_STATS", True)
+
+    def both(fn):
+        monkeypatch.delenv("MSML_NO_R32_CONV", raising=False)
+        a = fn()
+        monkeypatch.setenv("MSML_NO_R32_CONV", "1")
+        b = fn()
+        monkeypatch.delenv("MSML_NO_R32_CONV", raising=False)
+        return a, b
+
+    (o1, s1), (o2, s2) = both(lambda: ops.conv2d(x, None, wp, None, c, 3, 3, 1, 1, 1, False, want_stats=True))
+    assert torch.equal(o1, o2)
+    if n <= 8:
+        ref = F.conv2d(ops.to_nchw(x, c).double(), w.double(), None, 1, 1).float()
+        assert (ops.to_nchw(o1, c) - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+    f1, f2 = s1.sum(0), s2.sum(0)
+    assert torch.allclose(f1, f2, rtol=1e-5, atol=1e-5 * f2.abs().max().item()), (f1 - f2).abs().max()
+    (p1, _), (p2, _) = both(lambda: ops.conv2d(x, None, wp, None, c, 3, 3, 1, 1, 1, False))
+    assert torch.equal(p1, p2) and torch.equal(p1, o1)
+    dy = ops.to_nhwc(torch.randn(n, c, h, w_, generator=g).cuda(), _lib.BF16)
+    (d1, _), (d2, _) = both(lambda: ops.conv2d(dy, None, wpt, None, c, 3, 3, 1, 1, 1, True, p=h, q=w_))
+    assert torch.equal(d1, d2)
+    if n <= 8:
+        rdx = F.conv_transpose2d(ops.to_nchw(dy, c).double(), w.double(), None, 1, 1).float()
+        assert (ops.to_nchw(d1, c) - rdx).abs().max().item() <= 1.5e-2 * rdx.abs().max().item()
+    xbn = ops.to_nhwc(torch.randn(n, c, h, w_, generator=g).cuda(), _lib.BF16)
+    coef = torch.stack([torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3,
+                        torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5]).cuda()
+    for alpha in (None, (torch.rand(c, generator=g) * 0.5).cuda()):
+        (b1, q1), (b2, q2) = both(lambda: ops.conv_dgrad_bnbwd(dy, wpt, c, 3, 3, 1, 1, 1, h, w_, xbn, coef, alpha))
+        assert torch.equal(b1, b2) and torch.equal(b1, d1)
+        d, xs = b1.double().reshape(-1, c), xbn.double().reshape(-1, c)
+        z = xs * coef[0].double() + coef[1].double()
+        neg = (z <= 0) if alpha is not None else torch.zeros_like(z, dtype=torch.bool)
+        gg = torch.where(neg, d * alpha.double(), d) if alpha is not None else d
+        xh = (xs - coef[2].double()) * coef[3].double()
+        want = torch.stack([gg.sum(0), (gg * xh).sum(0), torch.where(neg, d * z, torch.zeros_like(z)).sum(0)])
+        for got in (q1.sum(0), q2.sum(0)):
+            assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-6, (got - want).abs().max()

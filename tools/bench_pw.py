@@ -49,7 +49,7 @@ def main():
         w = torch.randn(cout, cin, r, r, device="cuda") * 0.05
         wp = ops.pack_weight(w, tr, cout if tr else cin, 0, dt)
 
-        fused = tr and r == 1 and stride == 1 and args.fused          # the step's forms of the 1x1 backward-data launches
+        fused = tr and stride == 1 and args.fused and (r == 1 or args.fused == "bnb")      # the step's forms of the backward-data launches
         if fused:
             others = [torch.randn(n, h, h, cin, device="cuda").to(torch.bfloat16) for _ in range(sets)]
             coef = torch.rand(4, cin, device="cuda") + 0.5
@@ -64,7 +64,7 @@ def main():
                           others[i % sets], 0, out, cin, n, h, h, h, h, 1, 1, 1, 0, 0, 1)
                 return out
             if fused:
-                return ops.conv_dgrad_bnbwd(xs[i % sets], wp, cin, 1, 1, 1, 0, 0, h, h, others[i % sets], coef, alpha)
+                return ops.conv_dgrad_bnbwd(xs[i % sets], wp, cin, r, r, 1, pad, pad, h, h, others[i % sets], coef, alpha)
             if tr:
                 return ops.conv2d(xs[i % sets], None, wp, None, cin, r, r, stride, pad, pad, True, p=h, q=h)
             return ops.conv2d(xs[i % sets], None, wp, None, cout, r, r, stride, pad, pad, False, want_stats=True)
