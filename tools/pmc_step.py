@@ -23,7 +23,7 @@ import re
 import sys
 
 FAMILIES = {
-    "conv": re.compile(r"k_conv_(halo|fast|ws|igemm|line)|k_deconv4_"),
+    "conv": re.compile(r"k_conv_(halo|fast|ws|igemm|line|pw|r32)|k_deconv4_"),
     "wgrad": re.compile(r"k_wgrad_|k_conv_wgrad|k_fc_wgrad"),
     "bn": re.compile(r"k_bn_"),
 }
