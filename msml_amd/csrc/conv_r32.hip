@@ -15,6 +15,8 @@
 // order, 32 channels per tap as two 16-deep MFMAs): outputs bit-identical.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 struct ConvR32Args {
@@ -269,6 +271,13 @@ static void r32_launch(ConvR32Args& a, hipStream_t st) {
   a.strips = (a.H + rs - 1) / rs;
   a.nunits = a.N * a.strips;
   const size_t lds = 2304 + 4 * (size_t)(3 * (a.W + 2) * 64 + a.W * 64) + 1024;     // (+ masked lanes' reads past the last row)
+  if (lds > 64 * 1024) {                                // rows wider than 58 pixels: above the default dynamic-LDS limit
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_r32<MODE, FLIP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    });
+  }
   long grid = (a.nunits + 3) / 4;
   if (grid > 2L * cus) grid = 2L * cus;
   k_conv_r32<MODE, FLIP><<<dim3((unsigned)grid), dim3(256), lds, st>>>(a);
