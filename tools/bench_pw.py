@@ -16,8 +16,8 @@ from msml_amd import _lib, ops  # noqa: E402
 # (cin, cout, H, R, stride, transposed, launches per step)
 SHAPES = [
     (32, 64, 112, 1, 1, False, 1), (32, 64, 56, 1, 1, False, 3), (64, 32, 56, 1, 1, False, 2),
-    (64, 128, 28, 1, 1, False, 2), (128, 64, 28, 1, 1, False, 2), (128, 256, 14, 1, 1, False, 2),
-    (64, 32, 56, 1, 1, True, 2), (32, 64, 56, 1, 1, True, 2), (128, 64, 28, 1, 1, True, 2),
+    (64, 128, 28, 1, 1, False, 2), (128, 64, 28, 1, 1, False, 2), (128, 256, 14, 1, 1, False, 2), (256, 128, 14, 1, 1, False, 2),
+    (64, 32, 56, 1, 1, True, 2), (32, 64, 56, 1, 1, True, 2), (128, 64, 28, 1, 1, True, 2), (256, 128, 14, 1, 1, True, 2), (128, 256, 14, 1, 1, True, 2),
     (64, 64, 112, 1, 2, False, 1), (64, 64, 112, 3, 2, False, 1), (64, 64, 112, 3, 2, True, 1),
     (32, 32, 56, 3, 1, False, 2), (32, 32, 56, 3, 1, True, 2),
 ]
