@@ -35,6 +35,71 @@ F_FWD_GF = {"iresnet18": 8.446, "iresnet34": 12.146, "iresnet50": 15.845, "iresn
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
 JSON_OUT = None                                   # the process's real stdout (main() points fd 1 at stderr)
 
+# Box calibration.  MI355X devices hold different clocks under one and the same load, and the boxes this
+# bench has run on differ by +-4 % on an unchanged build: `calibration` measures, in the SAME run and right before the timed
+# region, (i) a register-resident bf16 MFMA loop on random operands (msml_probe_mfma, csrc/probe.hip) and (ii) a 2 x 512 MiB
+# device copy, and `value_normalised` rescales the headline to a reference box: every kernel family's share of the step's
+# kernel time (from the same run's `kernels` table) is scaled by the ratio of ITS yardstick to the reference constants below.
+# The constants are arbitrary but fixed (the first box of round 5): only ratios between runs mean anything.
+REF_MFMA_TFLOPS = 1400.0
+REF_COPY_TBS = 5.20
+MFMA_FAMILIES = ("conv_igemm", "conv_wgrad", "gemm_splitk", "conv_x3", "conv_fused")
+
+
+def _sclk_mhz():
+    """Current shader clock from sysfs (the starred line of pp_dpm_sclk), None when the box does not expose it."""
+    import glob
+    for path in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+        try:
+            for line in open(path):
+                if "*" in line:
+                    return float(line.split(":")[1].split("M")[0])
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
+def calibrate():
+    """(mfma TFLOP/s, copy TB/s) of this box, measured with HIP events on the current stream; ~0.4 s."""
+    from msml_amd import _lib
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(7)
+    seed = torch.randn(4096, generator=g).to(torch.bfloat16).to(dev)
+    wgs, iters = 512, 20000
+    out = torch.empty(wgs * 256, dtype=torch.float32, device=dev)
+    flop = wgs * 4 * iters * 16 * 2.0 * 16 * 16 * 32
+
+    def run(fn, n_warm, n_timed):
+        for _ in range(n_warm):
+            fn()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_timed + 1)]
+        evs[0].record()
+        for i in range(n_timed):
+            fn()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_timed))
+        return ts[len(ts) // 2] * 1e-3
+    t_mfma = run(lambda: _lib.call("msml_probe_mfma", seed, out, wgs, iters), 12, 15)
+    src = torch.empty(512 << 20, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    t_copy = run(lambda: dst.copy_(src), 4, 9)
+    nbytes = 2.0 * src.numel()
+    del src, dst
+    return flop / t_mfma / 1e12, nbytes / t_copy / 1e12
+
+
+def normalise(value, calib, kernels):
+    """value x (what this box costs relative to the reference box): the MFMA families' share of the kernel time scales with
+    REF_MFMA / probe, everything else (BatchNorm / element-wise / optimizer: HBM-bound) with REF_COPY / probe."""
+    share = 0.76                                       # (round-4 family table; used when the run has no kernel events)
+    if kernels:
+        tot = sum(v["ms_per_step"] for v in kernels.values())
+        if tot > 0:
+            share = sum(v["ms_per_step"] for k, v in kernels.items() if k in MFMA_FAMILIES) / tot
+    slow = share * REF_MFMA_TFLOPS / calib["mfma_tflops"] + (1.0 - share) * REF_COPY_TBS / calib["copy_tbs"]
+    return value * slow, share
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -59,6 +124,7 @@ def parse():
                          "(classes/E local rows, batch*E gathered feature rows, collectives omitted)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the box calibration probes (MFMA loop + device copy)")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
                     help="graph: replay ONE captured hipGraph per step; eager: issue the ~1300 launches "
                          "from Python with weight-gradient kernels on a second stream; auto: time both "
@@ -608,10 +674,21 @@ def main():
     inflight.clear()
     import gc
     gc.collect()
+    calib = None
+    if not args.no_calibration:           # every rank (the two extra steps below hold collectives); rank 0 reports
+        mf, cp = calibrate()
+        calib = {"mfma_tflops": round(mf, 1), "copy_tbs": round(cp, 3)}
+        for _ in range(2):        # the probes leave the caches and the clock in their own state: two steps of the workload again
+            throttled_step()
+        barrier()
+        inflight.clear()
+    sclk = []
     gc.disable()                  # no collector pauses inside the timed region (nothing is skipped)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = throttled_step()
+        if calib is not None:
+            sclk.append(_sclk_mhz())       # one sysfs read per step (~20 us of host time, the host runs ahead of the GPU)
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -724,6 +801,16 @@ def main():
                            "frac": round(tach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                            "algorithmic_flop": tv["flops"] / tv["n"], "launches": tv["n"],
                            "avg_us": round(tv["ms"] * 1e3 / tv["n"], 2)}
+        # the two launches that have carried `roofline` in earlier rounds, both on every line so that rounds stay comparable
+        # (round <= 3: the 256 -> 256 @ 14x14 backward-data conv with the fused BatchNorm sums, `T+bnb`; round 4: the forward
+        # conv of the same shape with BatchNorm + PReLU in its prologue, `N+bn`)
+        rec["roofline_labels"] = {}
+        for tag in ("conv N+bn c256+0->256 14x14 k3x3 s1", "conv T+bnb c256+0->256 14x14 k3x3 s1", "conv N c256+0->256 14x14 k3x3 s1"):
+            for n_, v_ in prof.items():
+                if n_.startswith(tag + " "):
+                    a_ = v_["flops"] / (v_["ms"] * 1e-3) / 1e12
+                    rec["roofline_labels"][tag.split()[1]] = {"launch": n_, "achieved": round(a_, 2), "frac": round(a_ / peak, 4),
+                                                              "launches": v_["n"], "avg_us": round(v_["ms"] * 1e3 / v_["n"], 2)}
         # and the heaviest launch of the OTHER family, so that neither hides behind the other
         for famname, pre in (("roofline_conv", "conv "), ("roofline_wgrad", "wgrad ")):
             sub = {n: v for n, v in prof.items() if n.startswith(pre.strip() if pre == "conv " else pre)}
@@ -748,6 +835,17 @@ def main():
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                                  "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                           for name, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+    if calib is not None:
+        vn, share = normalise(value, calib, rec.get("kernels"))
+        sc = [v for v in sclk if v is not None]
+        calib.update({"sclk_mhz_avg": round(sum(sc) / len(sc), 1) if sc else None,
+                      "ref_mfma_tflops": REF_MFMA_TFLOPS, "ref_copy_tbs": REF_COPY_TBS, "mfma_share_of_kernel_time": round(share, 4),
+                      "method": "msml_probe_mfma: 512 WGs x 4 waves x 20000 x 16 register-resident v_mfma_f32_16x16x32_bf16 on random "
+                                "operands, median of 15 launches after 12; copy: torch copy_ of 512 MiB (read + write), median of 9; "
+                                "both on the training stream right before the timed region; value_normalised = value x (share x "
+                                "ref_mfma / mfma + (1 - share) x ref_copy / copy), share = MFMA families' part of the kernel-event time"})
+        rec["calibration"] = calib
+        rec["value_normalised"] = round(vn, 2)
     if world == 1 and not args.no_extra_modes and args.mode == "train" and args.dtype == "bf16":
         runner = None
         graph = static = out = None

@@ -577,6 +577,12 @@ int msml_conv2d_bnbwd_in_acc(const void* in0, int c0p, const void* up_x, const f
 int msml_iblock_fwd_tables(int* nptr, int* nint, int* nflt);
 int msml_iblock_fwd(const void* const* ptrs, const int* ints, const float* flts, void* stream);
 
+/* Box calibration probe (bench.py `calibration`, not part of the hot path): `wgs` workgroups of four waves run `iters`
+ * rounds of 16 register-resident v_mfma_f32_16x16x32_bf16 on the random bf16 operands in seed[4096]; out[wgs * 256]
+ * receives the accumulator sums.  2 * 16 * 16 * 32 * 16 * iters FLOP per wave.  The reference has no counterpart: its
+ * benchmark prints images/sec only (train.py:303-318, utils/utils_callbacks.py). */
+int msml_probe_mfma(const void* seed, float* out, int wgs, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -586,6 +586,11 @@ bool msml_conv_pw_dispatch(const void* in0, int c0p, const void* wp, int kop, in
                            int stride, int pad_h, int pad_w, hipStream_t st, const float* scale, const float* alpha,
                            const void* residual, int res_first, const BnBwdFuse* bnb);
 
+bool msml_conv_halo2_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
+                              float* stats, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                              int pad_w, int transposed, hipStream_t st, const float* scale, const float* alpha,
+                              const void* residual, int res_first, const BnBwdFuse* bnb, int* bnb_rows);
+
 bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
@@ -619,6 +624,12 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   if (!in1 && out_dtype == MSML_BF16 &&
       msml_conv_halo_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h,
                               pad_w, transposed, st, scale, alpha, residual, res_first, bnb, bnb_rows))
+    return true;
+  // stride-2 3x3 layers (forward through parity planes, backward-data per output class) and 7x7 maps (2 x 2 image
+  // mosaics): conv_halo2.hip
+  if (!in1 && out_dtype == MSML_BF16 &&
+      msml_conv_halo2_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h, pad_w,
+                               transposed, st, scale, alpha, residual, res_first, bnb, bnb_rows))
     return true;
   // split-bf16 inference: 3x3 / stride-1 layers of the 28x28 / 14x14 stages on the halo kernel (c0p is 3 x logical)
   if (x3 && !in1 &&

@@ -518,6 +518,8 @@ extern "C" int msml_conv2d_bnbwd_acc(const void* in0, int c0p, const void* wp, i
   return rc;
 }
 
+int msml_conv_halo2_tiling(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                           int pad_h, int pad_w, int transposed);
 bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                             int stride, int pad_h, int pad_w, bool want_stats);
 bool msml_conv_ws_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
@@ -680,6 +682,14 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
   if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
       msml_conv_halo_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
     return coutp % 256 == 0 ? "k_conv_halo<14x14 px x 256 ch, 8 waves>" : "k_conv_halo<14x14 px x 128 ch, 8 waves>";
+  if (fast && c1p == 0 && out_dtype == MSML_BF16) {
+    const int t2 = msml_conv_halo2_tiling(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed);
+    if (t2 == 2) return stride == 1 ? "k_conv_halo2<mosaic of four 7x7 images x 128 ch>"
+                                    : (transposed ? "k_conv_halo2<stride-2 backward-data, 4 classes, 7x7 mosaic x 128 ch>"
+                                                  : "k_conv_halo2<stride-2 forward, 4 parity planes, 7x7 mosaic x 128 ch>");
+    if (t2 == 1) return transposed ? "k_conv_halo2<stride-2 backward-data, 4 output classes, 14x14 px>"
+                                   : "k_conv_halo2<stride-2 forward, 4 parity planes, 14x14 px>";
+  }
   if (fast) return bn == 128 ? "k_conv_fast<128 x 128, 4 waves>" : (bn == 64 ? "k_conv_fast<256 x 64, 4 waves>" : "k_conv_fast<256 x 32, 4 waves>");
   return bn == 128 ? "k_conv_igemm<128 x 128>" : (bn == 64 ? "k_conv_igemm<256 x 64>" : "k_conv_igemm<256 x 32>");
 }

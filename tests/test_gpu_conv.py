@@ -994,3 +994,76 @@ def test_conv3x3_32_channel_row_kernel_matches_the_general_kernel(shape, monkeyp
         want = torch.stack([gg.sum(0), (gg * xh).sum(0), torch.where(neg, d * z, torch.zeros_like(z)).sum(0)])
         for got in (q1.sum(0), q2.sum(0)):
             assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-6, (got - want).abs().max()
+
+
+# conv_halo2.hip: (N, Cin, Cout, H, stride).  Stride 2: forward through the four parity planes, backward-data per output
+# class; 7 x 7 GEMM grids (stride 1 at 7 x 7, stride 2 at 14 -> 7): 2 x 2 image mosaics (ragged batches: N % 4 != 0)
+HALO2 = [
+    (5, 128, 128, 28, 2),        # FRB layer2 entry at a quarter of the map: one tile per image, 128-channel tiling
+    (3, 128, 128, 56, 2),        # 2 x 2 tiles per image
+    (6, 256, 256, 28, 2),        # 256-channel tiling, four slabs x four planes
+    (4, 128, 256, 26, 2),        # ragged tile (13 x 13 outputs)
+    (9, 512, 512, 7, 1),         # mosaic, ragged batch (the last tile holds one image)
+    (8, 256, 128, 7, 1),
+    (64, 128, 128, 7, 1),
+    (6, 512, 512, 14, 2),        # stride 2 onto a 7 x 7 grid: mosaic of parity planes
+    (5, 256, 256, 14, 2),
+]
+
+
+@pytest.mark.parametrize("shape", HALO2)
+def test_conv_halo2_stride2_and_mosaic(shape):
+    """k_conv_halo2 (stride-2 3x3 layers on the halo tile, 7x7 maps as four-image mosaics): forward + accumulator-mode
+    statistics, backward-data, backward-data + residual and backward-data with the fused BatchNorm backward sums, against
+    f64 torch on the same bf16-rounded operands (backbones/frb/iresnet.py:56-67, stride-2 conv2 and the 512-channel stage)."""
+    n, cin, cout, h, stride = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, h, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).bfloat16().float()
+    ho = (h + 2 - 3) // stride + 1
+    name = _lib.value("msml_conv2d_kernel", cin, 0, cout, n, h, h, ho, ho, 3, 3, stride, 1, 1, 0, _lib.BF16, _lib.BF16, 1).decode()
+    assert "k_conv_halo2" in name, name
+    xd = x.double().requires_grad_(True)
+    ref = F.conv2d(xd, w.double(), None, stride, 1)
+    out, stats = run_conv(x, None, w, None, stride, 1, 1, _lib.BF16)
+    got = ops.to_nchw(out, cout).cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref.float()).abs().max().item() <= 1.5e-2 * scale
+    assert stats.dtype == torch.float64
+    ssum = stats.sum(0).float().cpu()
+    assert torch.allclose(ssum[0, :cout], ref.float().sum((0, 2, 3)), rtol=0, atol=1.5e-2 * scale * ref[:, 0].numel() ** 0.5)
+    assert torch.allclose(ssum[1, :cout], (ref.float() ** 2).sum((0, 2, 3)), rtol=2e-2)
+    # backward-data
+    dy = torch.randn(ref.shape, generator=g).bfloat16().float()
+    ref.backward(dy.double())
+    wpt = ops.pack_weight(w.cuda(), True, cout, 0, _lib.BF16)
+    dyd = ops.to_nhwc(dy.cuda(), _lib.BF16)
+    name = _lib.value("msml_conv2d_kernel", cout, 0, cin, n, ho, ho, h, h, 3, 3, stride, 1, 1, 1, _lib.BF16, _lib.BF16, 0).decode()
+    assert "k_conv_halo2" in name, name
+    dx, _ = ops.conv2d(dyd, None, wpt, None, cin, 3, 3, stride, 1, 1, True, p=h, q=h)
+    gx = ops.to_nchw(dx, cin).cpu().double()
+    gscale = xd.grad.abs().max().item()
+    assert (gx - xd.grad).abs().max().item() <= 1.5e-2 * gscale
+    # ... + residual (the FM `conv_tee` join, msml_conv2d_fused with unit scale / zero shift)
+    res = torch.randn(n, h, h, cin, generator=g).bfloat16().cuda()
+    dxr = torch.empty_like(dx)
+    one, zero = torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda")
+    _lib.call("msml_conv2d_fused", dyd, cout, None, 0, wpt, wpt.shape[0], one, zero, None, res, 0, dxr, cin, n, ho, ho, h, h,
+              3, 3, stride, 1, 1, 1)
+    want = (dx.float() + res.float()).bfloat16()
+    assert (dxr.float() - want.float()).abs().max().item() <= 8e-3 * max(1.0, want.float().abs().max().item())
+    # ... with the fused BatchNorm backward sums (accumulator mode): sum g, sum g * xhat, sum dy * min(z, 0)
+    bnx = torch.randn(n, h, h, cin, generator=g).bfloat16().cuda()
+    coef = (torch.rand(4, cin, generator=g) + 0.5).cuda()
+    alpha = torch.full((cin,), 0.25, device="cuda")
+    r2 = ops.conv_dgrad_bnbwd(dyd, wpt, cin, 3, 3, stride, 1, 1, h, h, bnx, coef, alpha)
+    assert r2 is not None
+    dx2, acc = r2
+    assert torch.equal(dx2, dx)
+    gq = dx2.float().reshape(-1, cin)
+    xf = bnx.float().reshape(-1, cin)
+    z = xf * coef[0] + coef[1]
+    gg = torch.where(z > 0, gq, gq * alpha)
+    xh = (xf - coef[2]) * coef[3]
+    want = torch.stack((gg.sum(0), (gg * xh).sum(0), (gq * torch.clamp(z, max=0)).sum(0))).double()
+    assert torch.allclose(acc.sum(0), want, rtol=2e-3, atol=2e-3 * want.abs().max().item())
