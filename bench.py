@@ -60,7 +60,8 @@ def _sclk_mhz():
 
 
 def calibrate():
-    """(mfma TFLOP/s, copy TB/s) of this box, measured with HIP events on the current stream; ~0.4 s."""
+    """(register-resident MFMA TFLOP/s, copy TB/s, LDS-fed MFMA TFLOP/s) of this box, measured with HIP events on the
+    current stream; ~0.6 s."""
     from msml_amd import _lib
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device="cpu").manual_seed(7)
@@ -81,12 +82,15 @@ def calibrate():
         ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_timed))
         return ts[len(ts) // 2] * 1e-3
     t_mfma = run(lambda: _lib.call("msml_probe_mfma", seed, out, wgs, iters), 12, 15)
-    src = torch.empty(512 << 20, dtype=torch.uint8, device=dev).random_(0, 255)
+    wgs2, iters2 = 256, 16000
+    flop2 = wgs2 * 8 * iters2 * 14 * 2.0 * 16 * 16 * 32
+    t_lds = run(lambda: _lib.call("msml_probe_mfma_lds", seed, out, wgs2, iters2), 12, 15)
+    src = torch.empty(128 << 20, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
     t_copy = run(lambda: dst.copy_(src), 4, 9)
-    nbytes = 2.0 * src.numel()
+    nbytes = 2.0 * src.numel() * 4
     del src, dst
-    return flop / t_mfma / 1e12, nbytes / t_copy / 1e12
+    return flop / t_mfma / 1e12, nbytes / t_copy / 1e12, flop2 / t_lds / 1e12
 
 
 def normalise(value, calib, kernels):
@@ -676,8 +680,8 @@ def main():
     gc.collect()
     calib = None
     if not args.no_calibration:           # every rank (the two extra steps below hold collectives); rank 0 reports
-        mf, cp = calibrate()
-        calib = {"mfma_tflops": round(mf, 1), "copy_tbs": round(cp, 3)}
+        mf, cp, ml = calibrate()
+        calib = {"mfma_tflops": round(mf, 1), "mfma_lds_tflops": round(ml, 1), "copy_tbs": round(cp, 3)}
         for _ in range(2):        # the probes leave the caches and the clock in their own state: two steps of the workload again
             throttled_step()
         barrier()

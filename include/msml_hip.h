@@ -582,6 +582,10 @@ int msml_iblock_fwd(const void* const* ptrs, const int* ints, const float* flts,
  * receives the accumulator sums.  2 * 16 * 16 * 32 * 16 * iters FLOP per wave.  The reference has no counterpart: its
  * benchmark prints images/sec only (train.py:303-318, utils/utils_callbacks.py). */
 int msml_probe_mfma(const void* seed, float* out, int wgs, int iters, void* stream);
+/* The same with every operand re-read from LDS in the mix of the halo-tile conv's main loop: `wgs` workgroups of eight
+ * waves (two per SIMD), per round 9 ds_read_b128 fragments feed 14 MFMAs; iters even; out[wgs * 512].
+ * 2 * 16 * 16 * 32 * 14 * iters FLOP per wave. */
+int msml_probe_mfma_lds(const void* seed, float* out, int wgs, int iters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -573,12 +573,14 @@ extern "C" int msml_conv2d_bnin(const void* in0, int c0p, const float* in_scale,
   return MSML_OK;
 }
 
-// 1 when msml_conv2d_bnin_acc serves the shape (the halo-tile conv; the weights-stationary 64-channel kernel gains nothing
-// from the in-LDS transform and is not offered).
+// 1 when msml_conv2d_bnin_acc serves the shape on the halo-tile conv, 2 on the weights-stationary 64-channel kernel
+// (round 5: the in-LDS transform of that kernel keeps a lane's coefficients in registers and staggers the two waves of a
+// SIMD, conv_ws.hip), 0 otherwise.
 extern "C" int msml_conv2d_bnin_acc_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                                             int stride, int pad_h, int pad_w) {
   if (getenv("MSML_NO_FAST_CONV") || c0p > 1024 || c0p % 8 || 256 % (c0p / 8) || (long)N * P * Q >= (1L << 24)) return 0;
   const int bn = msml_conv_tile_n(coutp), kop = cdiv(coutp, bn) * bn;
+  if (msml_conv_ws_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, true)) return 2;
   return msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, true) ? 1 : 0;
 }
 
@@ -607,7 +609,10 @@ extern "C" int msml_conv2d_bnin_acc(const void* in0, int c0p, const double* acc_
   xin.rmean = running_mean; xin.rvar = running_var; xin.momentum = momentum; xin.eps = eps;
   xin.coef_out = coef_out; xin.store = (unsigned short*)act_out;
   msml_tl_stats_acc = 1;
-  const bool ok = msml_conv_halo_dispatch(in0, c0p, wp, kop, nullptr, out, coutp, reinterpret_cast<float*>(acc_out), N, H,
+  const bool ok = msml_conv_ws_dispatch(in0, c0p, wp, kop, nullptr, out, coutp, reinterpret_cast<float*>(acc_out), N, H, W,
+                                        P, Q, R, S, stride, pad_h, pad_w, 0, (hipStream_t)stream, nullptr, nullptr, nullptr,
+                                        0, nullptr, nullptr, &xin) ||
+                  msml_conv_halo_dispatch(in0, c0p, wp, kop, nullptr, out, coutp, reinterpret_cast<float*>(acc_out), N, H,
                                           W, P, Q, R, S, stride, pad_h, pad_w, 0, (hipStream_t)stream, nullptr, nullptr,
                                           nullptr, 0, nullptr, nullptr, &xin);
   msml_tl_stats_acc = 0;

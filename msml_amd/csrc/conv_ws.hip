@@ -95,7 +95,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 
-  // XF: every wave normalises the chunks it DMA'd itself (after its own vmcnt wait); padding stays zero
+  // XF: every wave normalises the chunks it DMA'd itself (after its own vmcnt wait); padding stays zero.  A lane's
+  // chunks all hold the SAME 8 channels (chunk key (hp >> 1) & 7 = (4 (wave & 1) + (lane >> 4)) & 7, M16: hp & 7 =
+  // (lane >> 3) & 7 -- neither depends on the DMA pass i), so its coefficients live in registers for the whole kernel
+  // (xcoef, read from the LDS table once).  Accumulator mode (xin.acc): the transformed pixels this tile OWNS (not its
+  // halo) are also written to xin.store -- the weight gradient reads that tensor (conv_halo.hip, XF).
+  f32x4 xsc[2], xsh[2], xal[2];
   auto xform = [&](int tile, int buf) {
     const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
     const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
@@ -106,9 +111,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       const int j = wave + i * 8;
       const int hp = j * 8 + (lane >> 3);
       const int logical = (lane & 7) ^ skey(hp);
-      const int iy = y0 + (hp >> PL2) - 1, ix = x0 + (hp & (PITCH - 1)) - 1;
-      if (((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W))
-        bn_in_chunk(a + j * 1024 + lane * 16, xtab, C, logical * 8, has_alpha);
+      const int hy = hp >> PL2, hx = hp & (PITCH - 1);
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      if (((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W)) {
+        bn_in_chunk_r(a + j * 1024 + lane * 16, xsc, xsh, xal, has_alpha);
+        if (p.xin.store && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.xin.store) +
+                                    (size_t)((n * p.H + iy) * p.W + ix) * (size_t)(C * 2) + logical * 16u) =
+              *reinterpret_cast<const u32x4*>(a + j * 1024 + lane * 16);
+      }
     }
   };
 
@@ -153,9 +164,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   int tile = blockIdx.x;
   if (tile < p.ntiles) issue_a(tile, 0);
-  if (XF) bn_in_fill(p.xin, xtab, 0, C, t, NT);
+  if (XF) {
+    if (p.xin.acc) bn_in_fill_acc(p.xin, xtab, C, t, NT, blockIdx.x == 0);
+    else bn_in_fill(p.xin, xtab, 0, C, t, NT);
+  }
   __syncthreads();                                     // weights + first image landed (drains vmcnt)
   if (XF) {
+    const int ch = ((lane & 7) ^ skey(wave * 8 + (lane >> 3))) << 3;
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      xsc[hf] = *reinterpret_cast<const f32x4*>(xtab + ch + hf * 4);
+      xsh[hf] = *reinterpret_cast<const f32x4*>(xtab + C + ch + hf * 4);
+      xal[hf] = *reinterpret_cast<const f32x4*>(xtab + 2 * C + ch + hf * 4);
+    }
     if (tile < p.ntiles) xform(tile, 0);
     __syncthreads();
   }
@@ -212,7 +233,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int step = 0; step < 18; step++) {
         const int cb = step & 1, nb = cb ^ 1;
-        if (XF && step == 8 && tile + (int)gridDim.x < p.ntiles) {     // next image: requested at the top of this tile
+        if (XF && step == (wave < 4 ? 6 : 12) && tile + (int)gridDim.x < p.ntiles) {   // next image: requested at the top of this tile;
+          // waves 4-7 (the SIMD partners of 0-3) transform six steps later: one wave's VALU beside the other's MFMAs
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           xform(tile + gridDim.x, cur ^ 1);
         }
@@ -238,7 +260,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       const int arow = r32 + s, asw = (arow >> 1) & 7;
       const char* Arow = Abase + ((r << PL2) + arow) * 128;
       const char* B = Ws + tap * 8192;
-      if (XF && tap == 4 && tile + (int)gridDim.x < p.ntiles) {      // next image: requested 4 taps ago
+      if (XF && tap == (wave < 4 ? 3 : 6) && tile + (int)gridDim.x < p.ntiles) {   // next image: requested >= 3 taps ago; waves
+        // 4-7 (the SIMD partners of 0-3) transform three taps later: one wave's VALU beside the other's MFMAs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         xform(tile + gridDim.x, cur ^ 1);
       }

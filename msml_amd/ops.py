@@ -272,6 +272,14 @@ def bnin_applies(n, h, w, cin_p, cout_p, a_real, b_real):
 # (tools/bench_bnin.py: 256 -> 256 @ 14x14 bn 12 + conv 65 us -> 67-70 us; 128 @ 28x28 only 18 + 82 -> 96).
 BNIN_ACC = os.environ.get("MSML_NO_BNIN_ACC") is None
 BNIN_ACC_MIN_C = int(os.environ.get("MSML_BNIN_ACC_MIN_C", "256"))
+# ... and on the weights-stationary 64 -> 64 channel kernel (the 112x112 / 56x56 levels, where a BatchNorm pass is a
+# 0.2 - 0.8 GB round trip): built in round 5 with lane-resident coefficients, the two waves of a SIMD
+# transforming three taps apart and write-through -- bit-identical (test_conv_bn_from_accumulator_in_the_prologue), but
+# NOT faster: tools/bench_bnin_acc.py, cold operands, 64 -> 64 @ 56x56 bn + conv 146.8 us -> 155.4 us in one launch (conv
+# alone 106.1), @ 112x112 532.1 -> 523.2 (conv alone 367.4); without the write-through the transform alone adds 34 / 141 us
+# (tools/bench_bnin.py) -- exactly the cost of the separate pass.  With K = 576 a tile's 16 K elements are ~1 100 VALU
+# cycles per wave against 2 300 MFMA cycles and do not hide beside the partner wave's MFMAs.  Opt-in: MSML_BNIN_ACC_WS=1.
+BNIN_ACC_WS = os.environ.get("MSML_BNIN_ACC_WS") is not None
 _BNIN_ACC_OK = {}
 
 
@@ -279,9 +287,11 @@ def bnin_acc_applies(n, h, w, cin_p, cout_p, r, s, stride, pad):
     key = (n, h, w, cin_p, cout_p, r, s, stride, pad)
     ok = _BNIN_ACC_OK.get(key)
     if ok is None:
-        ok = bool(BNIN_ACC and ACC_STATS and cin_p >= BNIN_ACC_MIN_C and r == 3 and s == 3 and stride == 1 and pad == 1 and
-                  acc_applies(cin_p, BF16) and acc_applies(cout_p, BF16) and
-                  _lib.value("msml_conv2d_bnin_acc_applies", cin_p, cout_p, n, h, w, h, w, 3, 3, 1, 1, 1))
+        ok = False
+        if BNIN_ACC and ACC_STATS and r == 3 and s == 3 and stride == 1 and pad == 1 and acc_applies(cin_p, BF16) and \
+                acc_applies(cout_p, BF16):
+            kind = _lib.value("msml_conv2d_bnin_acc_applies", cin_p, cout_p, n, h, w, h, w, 3, 3, 1, 1, 1)
+            ok = (kind == 1 and cin_p >= BNIN_ACC_MIN_C) or (kind == 2 and BNIN_ACC_WS)
         _BNIN_ACC_OK[key] = ok
     return ok
 

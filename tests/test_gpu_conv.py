@@ -782,7 +782,9 @@ def test_conv_small_map_tiles(shape):
 
 @pytest.mark.parametrize("with_alpha", [False, True])
 @pytest.mark.parametrize("shape", [(7, 256, 256, 14, 14), (4, 256, 128, 13, 27), (3, 512, 256, 14, 14), (5, 256, 512, 14, 14),
-                                   (9, 128, 128, 28, 28), (6, 128, 256, 28, 28)])
+                                   (9, 128, 128, 28, 28), (6, 128, 256, 28, 28),
+                                   # the weights-stationary 64-channel kernel (round 5): more tiles than CUs, ragged tile column, 112 x 112
+                                   (24, 64, 64, 56, 56), (60, 64, 64, 28, 40), (3, 64, 64, 112, 112)])
 def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     """msml_conv2d_bnin_acc: training-mode BatchNorm (+ PReLU) -> 3x3 conv in ONE launch (coefficients derived from the
     producer's f64 accumulator in the kernel prologue, normalised tile applied in LDS and written through, running
@@ -797,7 +799,7 @@ def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     alpha = (torch.rand(cin, generator=g) * 0.3).cuda() if with_alpha else None
     wp = ops.pack_weight(w, False, cin, 0, _lib.BF16)
     m = n * h * w_
-    assert _lib.value("msml_conv2d_bnin_acc_applies", cin, cout, n, h, w_, h, w_, 3, 3, 1, 1, 1) == 1
+    assert _lib.value("msml_conv2d_bnin_acc_applies", cin, cout, n, h, w_, h, w_, 3, 3, 1, 1, 1) == (2 if cin == 64 else 1)
 
     def stats_of_x():
         acc = ops.stats_acc(cin, x.device)
