@@ -8,10 +8,13 @@
 //           over dY a class is a stride-1 conv with 1 / 2 / 2 / 4 taps at offsets {0, +1}; strided store; the fused
 //           BatchNorm backward sums (common.h) read the saved input at the strided pixels.
 //   GEOM 0  stride-1 forward / backward-data (the contract of conv_halo.hip), kept here for the MOSAIC tiling only:
-//   MOS     7x7 maps (the 512-channel stage, the deep OSB levels): a workgroup's tile is a 2 x 2 mosaic of FOUR images,
+//   MOS 7   7x7 maps (the 512-channel stage, the deep OSB levels): a workgroup's tile is a 2 x 2 mosaic of FOUR images,
 //           side by side on the 16-pixel LDS pitch with one zero pixel between them (1 + 7 + 1 + 7 columns = the
 //           pitch; the zero column / row is at once the right halo of one image and the left halo of the next): 196
 //           real pixels in 240 GEMM rows (the 14 x 14 tile: 49 of 224).
+//   MOS 4   4x4 maps (the OSB's deepest level, backbones/osb/unet.py:205-209): 3 x 2 images per tile (1 + 4 + 1 + 4 + 1 +
+//           4 + 1 columns, 9 GEMM row groups): 96 real pixels in 144 rows, 43 tiles x 4 channel blocks at batch 256
+//           (the im2col kernel: 128 workgroups of 56-stage K loops at 250 TFLOP/s).
 // Same machinery as k_conv_halo's 16x16x32 build: image + halo in LDS once per slab for all its taps (XOR chunk key
 // p & 7), wave-private two-stage weight rings filled by LDS-DMA, D = W_frag x X_frag on v_mfma_f32_16x16x32_bf16,
 // zero padding from out-of-range DMA offsets.  Statistics / fused BatchNorm sums in accumulator mode only.
@@ -47,18 +50,21 @@ struct ConvHalo2Args {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN, int NWM, int GEOM, bool MOS, bool FUSE>
+template <int BN, int NWM, int GEOM, int MOS, bool FUSE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo2(const ConvHalo2Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PL2 = 4, PITCH = 16, KG = BN / 32, NW = KG * NWM, NT = NW * 64;
-  constexpr int NGRP = MOS ? 15 : 14, BM = NGRP * 16;  // 16-pixel GEMM row groups of a tile
+  // mosaic geometry: images of IMG x IMG pixels every PER = IMG + 1 pixels, MC x MR of them per tile
+  constexpr int IMG = MOS, PER = MOS + 1, MC = MOS == 4 ? 3 : 2, MR = 2, MPT = MC * MR;
+  constexpr int NGRP = MOS ? MR * PER - 1 : 14, BM = NGRP * 16;  // 16-pixel GEMM row groups of a tile
   // LDS image: 16 rows of 16 pixels; MOS: + the zero row under the lower images + the 8 pixels behind it (the tap
   // (+1, +1) of the mosaic's last pixel, GEMM row 14 * 16 + 14, reads LDS pixel 272: zero-filled like the row)
-  constexpr int HPX = MOS ? 17 * 16 + 8 : 16 * 16;
+  constexpr int HPX = MOS ? (NGRP + 2) * 16 + 8 : 16 * 16;
   constexpr int ABYTES = HPX * 128;
   constexpr int NAJ = HPX / 8, NAI = (NAJ + NW - 1) / NW;
-  constexpr int NGW = NWM == 1 ? NGRP : 8;             // groups of one wave (at most)
+  constexpr int GS = MOS == 4 ? 5 : 8;                 // NWM == 2: groups of the first pixel-row half
+  constexpr int NGW = NWM == 1 ? NGRP : GS;            // groups of one wave (at most)
   constexpr int NGH = (NGW + 1) / 2;                   // ... per pipeline phase
   static_assert(NW == 8 && HPX % 8 == 0, "tile config");
 
@@ -70,7 +76,7 @@ k_conv_halo2(const ConvHalo2Args p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   auto skey = [](int p_) { return p_ & 7; };           // chunk key of LDS row p (conv_halo.hip, 16x16x32 lane map)
   const int kg = wave % KG, mg = wave / KG;
-  const int g0 = mg * 8, ng = NWM == 1 ? NGRP : (mg == 0 ? 8 : NGRP - 8);   // this wave's groups [g0, g0 + ng)
+  const int g0 = mg * GS, ng = NWM == 1 ? NGRP : (mg == 0 ? GS : NGRP - GS);   // this wave's groups [g0, g0 + ng)
   const int tile = blockIdx.x;
   const int n0 = blockIdx.y * BN;
   const int cy = GEOM == 2 ? (int)(blockIdx.z >> 1) : 0, cx = GEOM == 2 ? (int)(blockIdx.z & 1) : 0;
@@ -84,13 +90,14 @@ k_conv_halo2(const ConvHalo2Args p) {
   // GEMM row m = 16 my + mx  ->  is it a real output pixel, and where does it go
   auto pix_ok = [&](int m) {
     const int my = m >> 4, mx = m & 15;
-    if constexpr (MOS) return ((my & 7) != 7) & ((mx & 7) != 7) & (4 * tile + 2 * (my >> 3) + (mx >> 3) < p.N);
+    if constexpr (MOS) return (my % PER != IMG) & (mx % PER != IMG) & (mx < MC * PER - 1) &
+                              (MPT * tile + MC * (my / PER) + mx / PER < p.N);
     else return (mx < 14) & (x0 + mx < p.GW) & (y0 + my < p.GH);
   };
   auto pix_off = [&](int m) {
     const int my = m >> 4, mx = m & 15;
     int n, gy, gx;
-    if constexpr (MOS) { n = 4 * tile + 2 * (my >> 3) + (mx >> 3); gy = my & 7; gx = mx & 7; }
+    if constexpr (MOS) { n = MPT * tile + MC * (my / PER) + mx / PER; gy = my % PER; gx = mx % PER; }
     else { n = tn; gy = y0 + my; gx = x0 + mx; }
     if constexpr (GEOM == 2) { gy = 2 * gy + cy; gx = 2 * gx + cx; }
     return ((long)(n * p.OH + gy) * p.OW + gx) * p.coutp;
@@ -112,9 +119,11 @@ k_conv_halo2(const ConvHalo2Args p) {
     bool v = j < NAJ;
     if constexpr (MOS) {
       const int ty_ = hy - 1, tx_ = hx - 1;
-      v = v & (ty_ >= 0) & (tx_ >= 0) & (ty_ < 15) & ((ty_ & 7) != 7) & ((tx_ & 7) != 7);
-      n = 4 * tile + 2 * (ty_ >> 3) + (tx_ >> 3);
-      by = ty_ & 7; bx = tx_ & 7;
+      v = v & (ty_ >= 0) & (tx_ >= 0) & (ty_ < NGRP) & (tx_ < MC * PER - 1);
+      const int uy = ty_ < 0 ? 0 : ty_, ux = tx_ < 0 ? 0 : tx_;
+      v = v & (uy % PER != IMG) & (ux % PER != IMG);
+      n = MPT * tile + MC * (uy / PER) + ux / PER;
+      by = uy % PER; bx = ux % PER;
       v = v & (n < p.N) & (by < p.GH) & (bx < p.GW);
     } else {
       n = tn; by = y0 + hy - 1; bx = x0 + hx - 1;
@@ -397,9 +406,9 @@ k_conv_halo2(const ConvHalo2Args p) {
 #endif
 }
 
-template <int BN, int NWM, int GEOM, bool MOS, bool FUSE>
+template <int BN, int NWM, int GEOM, int MOS, bool FUSE>
 static void launch_halo2(ConvHalo2Args& a, hipStream_t st) {
-  constexpr int HPX = MOS ? 17 * 16 + 8 : 16 * 16, BM = (MOS ? 15 : 14) * 16;
+  constexpr int NGRP = MOS ? 2 * (MOS + 1) - 1 : 14, HPX = MOS ? (NGRP + 2) * 16 + 8 : 16 * 16, BM = NGRP * 16;
   size_t lds = 2 * (size_t)HPX * 128 + 8 * 8192;        // two halo images + eight private weight rings
   const size_t olds = (size_t)BM * (BN + 8) * 2;        // transposed output tile
   const size_t slds = (size_t)8 * 64 * 33 * 4;          // statistics meet
@@ -412,13 +421,13 @@ static void launch_halo2(ConvHalo2Args& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo2<BN, NWM, GEOM, MOS, FUSE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  const int tiles = MOS ? cdiv(a.N, 4) : a.N * a.tpy * a.tpx;
+  const int tiles = MOS ? cdiv(a.N, MOS == 4 ? 6 : 4) : a.N * a.tpy * a.tpx;
   dim3 grid(tiles, a.coutp / BN, GEOM == 2 ? 4 : 1);
   k_conv_halo2<BN, NWM, GEOM, MOS, FUSE><<<grid, dim3(512), lds, st>>>(a);
 }
 
 // geom: 0 stride 1, 1 stride-2 forward, 2 stride-2 backward-data.  Returns the tiling (0 none, 1 plain 14 x 14 tiles,
-// 2 mosaic of four 7 x 7 images) this family takes the shape with.
+// 2 mosaic of four 7 x 7 images, 3 mosaic of six 4 x 4 images) this family takes the shape with.
 int msml_conv_halo2_tiling(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
                            int pad_h, int pad_w, int transposed) {
   static const bool off = getenv("MSML_NO_HALO2_CONV") != nullptr;
@@ -434,7 +443,13 @@ int msml_conv_halo2_tiling(int c0p, int kop, int coutp, int N, int H, int W, int
   if (in_bytes >= 0x70000000L || w_bytes >= 0x70000000L || (long)N * P * Q * coutp * 2 >= 0x7fffffffL * 2) return 0;
   static const bool no_mos = getenv("MSML_NO_HALO2_MOSAIC") != nullptr;
   static const bool no_s2 = getenv("MSML_NO_HALO2_S2") != nullptr;
-  if (gh == 7 && gw == 7) return (no_mos || (stride == 2 && no_s2) || N < 4) ? 0 : 2;
+  // mosaics run 128-channel tiles: below ~160 workgroups (256 -> 256 @ 7x7: 128, 128 -> 128 @ 7x7: 64, the forward of
+  // 256 @ 14 -> 7: 128) the im2col kernel's 64-row tiles fill the chip better (tools/bench_small.py: 37.4 -> 34.9 us,
+  // 17.6 -> 19.7 us, 36.1 -> 37.7 us); a backward-data launch has four slices per tile
+  const long cblk = coutp / 128, slices = (stride == 2 && transposed) ? 4 : 1;
+  if (gh == 7 && gw == 7)
+    return (no_mos || (stride == 2 && no_s2) || cdiv(N, 4) * cblk * slices < 160) ? 0 : 2;
+  if (gh == 4 && gw == 4 && stride == 1) return (no_mos || cdiv(N, 6) * cblk < 160) ? 0 : 3;
   if (stride == 1 || no_s2) return 0;                   // stride-1 maps with real tiles: conv_halo.hip
   const long tiles = (long)N * cdiv(gh, 14) * cdiv(gw, 14);
   if ((long)N * gh * gw * 10 < tiles * 224 * 7) return 0;           // < 70 % real GEMM rows: im2col kernel wins
@@ -468,21 +483,23 @@ bool msml_conv_halo2_dispatch(const void* in0, int c0p, const void* wp, int kop,
   a.stats = stats;
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
-  const bool mos = tiling == 2;
+  const bool mos = tiling >= 2;
   const bool wide = coutp % 256 == 0 && !mos;           // mosaic: N / 4 tiles -- 128-channel tiles fill the chip sooner
-  if (bnb_rows) *bnb_rows = (mos ? cdiv(N, 4) : N * a.tpy * a.tpx) * (geom == 2 ? 4 : 1);
+  if (bnb_rows) *bnb_rows = (mos ? cdiv(N, tiling == 3 ? 6 : 4) : N * a.tpy * a.tpx) * (geom == 2 ? 4 : 1);
 #define H2_CASE(GEOM, MOS)                                                              \
   if (bnb) { if (wide) launch_halo2<256, 1, GEOM, MOS, true>(a, st); else launch_halo2<128, 2, GEOM, MOS, true>(a, st); } \
   else { if (wide) launch_halo2<256, 1, GEOM, MOS, false>(a, st); else launch_halo2<128, 2, GEOM, MOS, false>(a, st); }
-  if (mos) {
-    if (geom == 0) { if (bnb) launch_halo2<128, 2, 0, true, true>(a, st); else launch_halo2<128, 2, 0, true, false>(a, st); }
-    else if (geom == 1) { if (bnb) return false; launch_halo2<128, 2, 1, true, false>(a, st); }
-    else { if (bnb) launch_halo2<128, 2, 2, true, true>(a, st); else launch_halo2<128, 2, 2, true, false>(a, st); }
+  if (tiling == 3) {
+    if (bnb) launch_halo2<128, 2, 0, 4, true>(a, st); else launch_halo2<128, 2, 0, 4, false>(a, st);
+  } else if (mos) {
+    if (geom == 0) { if (bnb) launch_halo2<128, 2, 0, 7, true>(a, st); else launch_halo2<128, 2, 0, 7, false>(a, st); }
+    else if (geom == 1) { if (bnb) return false; launch_halo2<128, 2, 1, 7, false>(a, st); }
+    else { if (bnb) launch_halo2<128, 2, 2, 7, true>(a, st); else launch_halo2<128, 2, 2, 7, false>(a, st); }
   } else if (geom == 1) {
     if (bnb) return false;
-    if (wide) launch_halo2<256, 1, 1, false, false>(a, st); else launch_halo2<128, 2, 1, false, false>(a, st);
+    if (wide) launch_halo2<256, 1, 1, 0, false>(a, st); else launch_halo2<128, 2, 1, 0, false>(a, st);
   } else {
-    H2_CASE(2, false)
+    H2_CASE(2, 0)
   }
 #undef H2_CASE
   return true;

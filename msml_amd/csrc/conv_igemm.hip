@@ -689,6 +689,7 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
     return coutp % 256 == 0 ? "k_conv_halo<14x14 px x 256 ch, 8 waves>" : "k_conv_halo<14x14 px x 128 ch, 8 waves>";
   if (fast && c1p == 0 && out_dtype == MSML_BF16) {
     const int t2 = msml_conv_halo2_tiling(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed);
+    if (t2 == 3) return "k_conv_halo2<mosaic of six 4x4 images x 128 ch>";
     if (t2 == 2) return stride == 1 ? "k_conv_halo2<mosaic of four 7x7 images x 128 ch>"
                                     : (transposed ? "k_conv_halo2<stride-2 backward-data, 4 classes, 7x7 mosaic x 128 ch>"
                                                   : "k_conv_halo2<stride-2 forward, 4 parity planes, 7x7 mosaic x 128 ch>");
