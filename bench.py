@@ -134,6 +134,10 @@ def parse():
                          "from Python with weight-gradient kernels on a second stream; auto: time both "
                          "during warm-up and keep the faster")
     ap.add_argument("--no-graph", action="store_true", help="alias of --launch eager")
+    ap.add_argument("--cpu-share", type=int, default=0,
+                    help="pin this process to the first K CPUs of its affinity mask before anything touches the GPU: what ONE "
+                         "rank of an 8-rank job gets on a 16-CPU box share is K = 2 (the eager step needs one Python thread "
+                         "at 60-80 %% duty; DESIGN section 6)")
     return ap.parse_args()
 
 
@@ -511,6 +515,11 @@ def launch_ranks(n):
 
 def main():
     args = parse()
+    if args.cpu_share > 0:
+        # (sched_setaffinity only: no exec, nothing GPU-side has been initialised yet; children of launch_ranks inherit it)
+        cpus = sorted(os.sched_getaffinity(0))[:args.cpu_share]
+        os.sched_setaffinity(0, cpus)
+        torch.set_num_threads(max(1, len(cpus)))
     if "WORLD_SIZE" in os.environ or args.gpus == 1:
         # stdout carries the JSON line and nothing else: keep the real stdout for it and point fd 1 at stderr, so that
         # whatever a library prints from C (gloo's "[Gloo] Rank 0 is connected to ...", ROCm notices) cannot land there
@@ -751,6 +760,7 @@ def main():
                    "global_batch": args.batch * world, "parallelism": "dp%d+class-parallel head" % world,
                    "launch": ("hipGraph replay" if graph is not None else
                               "eager, weight gradients + OSB on side streams" if args.mode == "train" else "eager"),
+                   "cpu_share": len(os.sched_getaffinity(0)),
                    "warmup_ms_per_step": {"eager": None if t_eager is None else round(t_eager * 1e3, 2),
                                           "graph": None if t_graph is None else round(t_graph * 1e3, 2)}},
     }

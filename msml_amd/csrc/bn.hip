@@ -26,6 +26,7 @@ __device__ __forceinline__ void slab_reduce(long M, int C, float* __restrict__ p
   float* red = reinterpret_cast<float*>(smem_raw);            // [PY][NQ][C]
   const int C8 = C / 8;
   const int PY = 256 / C8 > 0 ? 256 / C8 : 1;                 // pixel lanes per block
+  MSML_LDS_REGION(red, PY * NQ * C * 4);
   const int t = threadIdx.x;
   const int cx = t % C8, py = t / C8;
   float q[NQ][8];
@@ -381,6 +382,7 @@ __global__ void __launch_bounds__(256) k_bn_fin_act_fwd(const double* __restrict
                                                         T* __restrict__ y, long n8, int C8, double* __restrict__ acc_out) {
   extern __shared__ float cs[];                        // [2][C]: scale, shift
   const int C = C8 * 8, t = threadIdx.x;
+  MSML_LDS_REGION(cs, 2 * C * 4);
   for (int c = t; c < C; c += 256) {
     double s = 0.0, ss = 0.0;
 #pragma unroll
@@ -719,6 +721,7 @@ __global__ void __launch_bounds__(256) k_bn_fin_bwd_apply(const T* __restrict__ 
                                                           int aH, int aW) {
   extern __shared__ float ck[];                        // [2][C]: k1, k2
   const int C = C8 * 8, t = threadIdx.x;
+  MSML_LDS_REGION(ck, 2 * C * 4);
   for (int c = t; c < C; c += 256) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll

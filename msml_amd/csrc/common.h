@@ -45,6 +45,26 @@ void msml_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- LDS high-water guard --------------------------------------------------------------------
+// Every kernel with dynamic LDS derives its regions (tile rings, transpose tiles, reduction scratch, coefficient tables)
+// from one `extern __shared__` base, and the launch site computes the byte count as a max() of hand-derived terms; a
+// region that outgrows the allocation is silently dropped / zero-read by the hardware (round 3 shipped such a launch:
+// conv_fast.hip, `rlds`).  In a -DMSML_LDS_GUARD build (tools/build_variant.py --all MSML_LDS_GUARD) every region
+// declares its extent right where it is derived, and the kernel TRAPS when the region ends beyond the LDS the dispatch
+// was given: group_segment_size of the AQL packet = static + dynamic bytes of THIS launch.  No cost in the product build.
+#ifdef MSML_LDS_GUARD
+__device__ __forceinline__ void msml_lds_region(const void* p, size_t bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned int have = reinterpret_cast<const unsigned int*>(__builtin_amdgcn_dispatch_ptr())[7];   // group_segment_size
+  const unsigned int off = (unsigned int)(size_t)(__attribute__((address_space(3))) const char*)p;
+  if ((size_t)off + bytes > (size_t)have) __builtin_trap();
+#endif
+}
+#define MSML_LDS_REGION(p, bytes) msml_lds_region((p), (size_t)(bytes))
+#else
+#define MSML_LDS_REGION(p, bytes) ((void)0)
+#endif
+
 // ---- storage element helpers ------------------------------------------------------------
 // Activations are stored either as f32 or bf16; arithmetic is always f32.
 __device__ __forceinline__ float bf2f(unsigned short v) {

@@ -36,6 +36,8 @@ __global__ void __launch_bounds__(512) k_deconv4_fwd(const ConvD4Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ws = smem;                                                           // [2 segments][16 taps][32 co][64 B]
   char* Xs = smem + 2 * WPL;                                                 // [2 stages][2 planes][288 px][64 B]
+  MSML_LDS_REGION(Ws, 2 * WPL);
+  MSML_LDS_REGION(Xs, 2 * 2 * XPL);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int H = p.H;
@@ -202,6 +204,8 @@ __global__ void __launch_bounds__(512) k_deconv4_bwd(const ConvD4BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ws = smem;                                       // [2 segments][16 taps][32 ci][64 B of co]
   char* Xs = smem + 2 * WPL;                             // [2 stages][RPIX][64 B]
+  MSML_LDS_REGION(Ws, 2 * WPL);
+  MSML_LDS_REGION(Xs, 2 * XST);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int H = p.H, H2 = 2 * p.H;

@@ -90,6 +90,8 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
   constexpr int ABYTES = BM * 128, BBYTES = BN * 128;  // one stage of A / of B
   char* As = smem;                                     // [NST][BM][128 B]
   char* Bs = smem + p.lds_stages * ABYTES;             // [stages][BN][128 B]
+  MSML_LDS_REGION(As, p.lds_stages * ABYTES);
+  MSML_LDS_REGION(Bs, p.lds_stages * BBYTES);
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int row0 = t >> 3;                             // RPP rows per pass, lane l -> LDS slot l
@@ -355,6 +357,8 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
   constexpr int OPF = BN + 4;                          // pitch of the f32 tile (X3)
   unsigned short* otile = reinterpret_cast<unsigned short*>(smem);
   float* otf = reinterpret_cast<float*>(smem);
+  if (X3) MSML_LDS_REGION(otf, BM * OPF * 4);
+  else if (VIA_LDS) MSML_LDS_REGION(otile, BM * OP * 2);
   // fused BatchNorm backward-reduce: the saved BatchNorm input of this thread's copy-out chunks is
   // requested first, so the loads fly during the accumulator -> LDS transpose
   constexpr int C8 = BN / 8, ITERS = FUSE ? BM * C8 / NT : 1;
@@ -435,6 +439,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
       constexpr int G = NT / C8;
       __syncthreads();
       float* red = reinterpret_cast<float*>(smem);
+      MSML_LDS_REGION(red, G * 3 * BN * 4);
 #pragma unroll
       for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -500,6 +505,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
   if (p.stats) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
+    MSML_LDS_REGION(red, WGM * 2 * BN * 4);
 #pragma unroll
     for (int j = 0; j < TN; j++) {
       float s1 = s1v[j] + __shfl_xor(s1v[j], 32, 64);
@@ -550,7 +556,12 @@ static void launch_fast(ConvFastArgs& a, hipStream_t st) {
   // its allocation and returned wrong sums; found by the pointwise-kernel test of round 4, no layer of the MSML
   // networks takes that combination)
   const size_t rlds = FUSE ? (size_t)(WGM * WGN * 64 / (BN / 8)) * 3 * BN * 4 : 0;
+#ifdef MSML_LDS_GUARD
+  static const bool drop_rlds = getenv("MSML_LDS_GUARD_DROP_RLDS") != nullptr;   // guard self-test: the round-3 allocation
+  if (rlds > lds && !drop_rlds) lds = rlds;
+#else
   if (rlds > lds) lds = rlds;
+#endif
   if (lds > 64 * 1024) {                               // above the default dynamic-LDS limit
     static std::once_flag once;
     std::call_once(once, [] {

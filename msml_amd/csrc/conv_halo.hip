@@ -82,6 +82,10 @@ k_conv_halo(const ConvHaloArgs p) {
   char* As = smem;                                     // [2][HPX][128 B]
   char* Bs = smem + 2 * ABYTES;                        // [NW][2][32][128 B]
   float* xtab = reinterpret_cast<float*>(smem + 2 * ABYTES + NW * 8192);   // XF: [3][C] scale, shift, alpha
+  MSML_LDS_REGION(As, 2 * ABYTES);
+  MSML_LDS_REGION(Bs, NW * 8192);
+  if (XF) MSML_LDS_REGION(xtab, 3 * p.C * 4);
+  if (XB) MSML_LDS_REGION(xtab, 7 * p.C * 4);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // scalar: LDS-DMA bases go to M0
@@ -364,6 +368,7 @@ k_conv_halo(const ConvHaloArgs p) {
 #endif
   constexpr int OP = BN + 8;                           // 528-B rows
   unsigned short* otile = reinterpret_cast<unsigned short*>(smem);
+  MSML_LDS_REGION(otile, BM * OP * 2);
   // copy-out: thread t stores 16-B chunk c8 of rows (t + k NT) / C8.  With the fused BatchNorm
   // backward-reduce the saved BatchNorm input of those chunks is requested now, so the loads fly
   // during the accumulator -> LDS transpose.
@@ -576,6 +581,7 @@ k_conv_halo(const ConvHaloArgs p) {
     constexpr int G = NT / C8;
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
+    MSML_LDS_REGION(red, G * 3 * BN * 4);
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -595,6 +601,7 @@ k_conv_halo(const ConvHaloArgs p) {
     // zeroed so msml_bn_finalize can sum the whole [rows][2][C] block.
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem) + wave * 64 * 33;
+    MSML_LDS_REGION(smem, NW * 64 * 33 * 4);
 #pragma unroll
     for (int g = 0; g < (M16 ? 2 : 4); g++)
 #pragma unroll

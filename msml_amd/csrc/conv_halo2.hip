@@ -71,6 +71,8 @@ k_conv_halo2(const ConvHalo2Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                                     // [2][HPX][128 B]
   char* Bs = smem + 2 * ABYTES;                        // [NW][2][32][128 B]
+  MSML_LDS_REGION(As, 2 * ABYTES);
+  MSML_LDS_REGION(Bs, NW * 8192);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -278,6 +280,7 @@ k_conv_halo2(const ConvHalo2Args p) {
   // ---------------- epilogue ----------------------------------------------------------------------------------
   constexpr int OP = BN + 8;
   unsigned short* otile = reinterpret_cast<unsigned short*>(smem);
+  MSML_LDS_REGION(otile, BM * OP * 2);
   constexpr int C8 = BN / 8, ITERS = (BM * C8 + NT - 1) / NT;
   static_assert(NT % C8 == 0, "a thread keeps one 8-channel chunk in the copy-out loop");
   const int c8 = t % C8;
@@ -367,6 +370,7 @@ k_conv_halo2(const ConvHalo2Args p) {
     constexpr int G = NT / C8;
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
+    MSML_LDS_REGION(red, G * 3 * BN * 4);
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -384,6 +388,7 @@ k_conv_halo2(const ConvHalo2Args p) {
     // LDS and each lane of the pixel-row group 0 adds up one (statistic, channel) in a fixed order
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem) + wave * 64 * 33;
+    MSML_LDS_REGION(smem, NW * 64 * 33 * 4);
 #pragma unroll
     for (int g = 0; g < 2; g++)
 #pragma unroll

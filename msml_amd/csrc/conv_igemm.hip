@@ -121,6 +121,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u32x4* As = reinterpret_cast<u32x4*>(smem);                 // [2][BM][CPR]
   u32x4* Bs = As + 2 * BM * CPR;                              // [2][BN][CPR]
+  MSML_LDS_REGION(As, 2 * BM * CPR * 16);
+  MSML_LDS_REGION(Bs, 2 * BN * CPR * 16);
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int cc = t % CPR, row0 = t / CPR;
@@ -255,6 +257,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvArgs p) {
   const int h = lane >> 5, c32 = lane & 31;
   TOUT* outp = reinterpret_cast<TOUT*>(p.out);
   float* red = reinterpret_cast<float*>(smem);     // reuse LDS: [WGM][2][BN]
+  MSML_LDS_REGION(red, WGM * 2 * BN * 4);
   if (p.stats) __syncthreads();
 #pragma unroll
   for (int j = 0; j < TN; j++) {

@@ -44,6 +44,8 @@ __global__ void __launch_bounds__(512) k_conv_line(const ConvLineArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ws = smem;                                      // [tap][co][CIN], chunks swizzled by the row
   char* Xs = smem + WB;                                 // [2][XPIX][CIN], chunks swizzled by the pixel
+  MSML_LDS_REGION(Ws, WB);
+  MSML_LDS_REGION(Xs, 2 * XB);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int L = p.L, B = p.B, npix = L * B, nreg = (L + 6) * B;

@@ -74,6 +74,11 @@ __global__ void __launch_bounds__(256) k_conv_pw(const ConvPwArgs p) {
   const int r32 = lane & 31, h = lane >> 5;
   char* xin = smem + L::SCRATCH + wave * L::SCR;        // this wave's input block [32 px][CINB], chunks swizzled
   char* xout = xin + L::XINB;                           // ... and its output tile [32 px][COUTW], chunks swizzled
+  MSML_LDS_REGION(Ws, COUT * CINB);
+  MSML_LDS_REGION(ktab, 2 * COUT * 4);
+  MSML_LDS_REGION(red, 4 * 3 * 64 * 4);
+  MSML_LDS_REGION(xin, L::XINB);
+  MSML_LDS_REGION(xout, L::XOUTB);
   // the 16 rows one ds_read_b128 lane group touches must land on 16 different 16-B bank slots (conv_line.hip)
   auto key = [](int row) -> int { return CINB == 64 ? ((row >> 2) & 3) : (CINB == 128 ? ((row >> 1) & 7) : (row & 15)); };
   // output tile: the key of pixel p must not depend on which of a lane's NOJ linear chunks p belongs to, so that a lane

@@ -44,6 +44,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   float* ktab = reinterpret_cast<float*>(smem + 1536);  // R32_BNB: [5][32] scale, shift, alpha, invstd, -mean invstd
   char* ring = smem + 2304 + wave * scr;
   char* outt = ring + 3 * slotb;
+  MSML_LDS_REGION(red, 4 * 3 * 32 * 4);
+  MSML_LDS_REGION(ktab, 5 * 32 * 4);
+  MSML_LDS_REGION(ring, 3 * slotb);
+  MSML_LDS_REGION(outt, W * 64);
   // 64-B pixels: the 16 pixels one ds_read_b128 lane group touches need 16 different (quarter-bank, chunk) slots at
   // every tap shift -> key = (pixel >> 2) & 3 (conv_line.hip); the same key keeps a copy-out lane on ONE channel chunk
   auto key = [](int col) -> int { return (col >> 2) & 3; };

@@ -75,6 +75,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(const WgradArgs p) {
   constexpr int TM = BA / 64, TN = BB / 64;    // 2x2 waves, each (BA/2) x (BB/2)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  MSML_LDS_REGION(smem, 2 * WT::STAGE);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int btiles = (p.vp + BB - 1) / BB;
   const int a0 = blockIdx.x * BA;

@@ -56,6 +56,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   char* Ws = smem;                                     // [9 taps][64 rows][128 B]
   char* As = smem + WBYTES;                            // [2][256 px][128 B]
   float* xtab = reinterpret_cast<float*>(smem + WBYTES + 2 * ABYTES + 512);   // XF: [3][64]
+  MSML_LDS_REGION(Ws, WBYTES);
+  MSML_LDS_REGION(As, 2 * ABYTES + 2 * 128);           // (+ the two pixels the padding rows read past an image)
+  if (XF) MSML_LDS_REGION(xtab, 3 * C * 4);
+  MSML_LDS_REGION(As, BM * OP * 2);                    // the transposed output tile goes through an image buffer
+  MSML_LDS_REGION(As + ABYTES, BM * OP * 2);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -381,6 +386,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   if (FUSE) {
     constexpr int G = NT / C8;                         // 64 threads share a channel chunk
     float* red = reinterpret_cast<float*>(smem);
+    MSML_LDS_REGION(red, G * 3 * C * 4);
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -395,6 +401,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
   if (!FUSE && p.stats) {
     float* red = reinterpret_cast<float*>(smem) + wave * 64 * 33;
+    MSML_LDS_REGION(smem, 8 * 64 * 33 * 4);
 #pragma unroll
     for (int g = 0; g < (M16 ? 2 : 4); g++)
 #pragma unroll

@@ -116,6 +116,8 @@ __global__ void __launch_bounds__(512) k_fc_wgrad(const FcWgradArgs p) {
 
   // epilogue: two halves of 16 e-rows through LDS [16][32 * T] f32, then contiguous 16-byte row pieces
   float* tile = reinterpret_cast<float*>(smem);
+  MSML_LDS_REGION(smem, 3 * stage_bytes);
+  MSML_LDS_REGION(tile, 16 * 32 * T * 4);
   const int RL = 32 * T, RL4 = RL >> 2;
   const int h = lane >> 5, b = lane & 31;
   for (int hf = 0; hf < 2; hf++) {

@@ -190,6 +190,7 @@ __device__ __forceinline__ void pack_tile_body(const long* __restrict__ d, int l
   const int K1 = C2 > 0 ? (RS * C2p + 31) / 32 * 32 : 0;
   const int Ktot = K0 + K1;
   const int tiles_b = (B + BT - 1) / BT;
+  MSML_LDS_REGION(tile, 32 * (BT * RS + 1) * 4);
   const int a0 = (lt / tiles_b) * 32, b0 = (lt % tiles_b) * BT;
   const int na = A - a0 < 32 ? A - a0 : 32, nb = B - b0 < BT ? B - b0 : BT;
   const int run = nb * RS, pitch = BT * RS + 1;

@@ -263,6 +263,8 @@ __global__ void __launch_bounds__(256) k_occ_resize(const unsigned char* __restr
   }
   unsigned char* A = sm;                       // [h0][w0][4] premultiplied
   unsigned char* B = sm + h0 * w0 * 4;         // [h0][ow][4] after the horizontal pass
+  MSML_LDS_REGION(A, h0 * w0 * 4);
+  MSML_LDS_REGION(B, h0 * ow * 4);
   for (int i = t; i < h0 * w0; i += 256) {
     const unsigned int a = e[i * 4 + 3];
 #pragma unroll

@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(256) k_wgrad_fast(const WgradFastArgs p) {
   constexpr int UBYTES = 64 * BA * 2, STAGE = 64 * (BA + BB) * 2;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  MSML_LDS_REGION(smem, 2 * STAGE);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int btiles = NTW > 1 ? (p.vp + 63) / 64 : (p.vp + BB - 1) / BB;   // NTW > 1: 64-channel chunks
   const int a0 = blockIdx.x * BA;

@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   constexpr int GU = CO / 32, NI = CO / 64, UBLK = 7 * GU, NBLK = UBLK + 20, NISS = (NBLK + 7) / 8;
   constexpr int UB = UBLK * 1024, VB = 10 * 2 * 1024, STAGE = UB + VB;    // dY strip, X strip + halo (+ 1 row)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  MSML_LDS_REGION(smem, 2 * STAGE + (XF ? 3 * 64 * 4 : 0));
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int mp = wave & 1, nh = (wave >> 1) & 1, tg = wave >> 2;   // Cout tile pair, Cin half, tap group

@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(512) k_wgrad_n32(const WgradN32Args p) {
   constexpr int NBLK = SR + VR * NPL * 2, NISS = (NBLK + 7) / 8;
   static_assert(TAPS <= 16, "two taps per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  MSML_LDS_REGION(smem, 3 * STAGE);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int split = blockIdx.x;
@@ -244,6 +245,7 @@ __global__ void __launch_bounds__(512) k_wgrad_line(const WgradLineArgs p) {
   constexpr int UB = UBLK * 1024, VB = NH * VBLK * 1024, STAGE = UB + VB;
   constexpr int NBLK = UBLK + NH * VBLK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  MSML_LDS_REGION(smem, 2 * STAGE);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int split = blockIdx.x, L = p.L, B = p.B, nreg = (L + 6) * B;

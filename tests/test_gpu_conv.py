@@ -784,7 +784,7 @@ def test_conv_small_map_tiles(shape):
 @pytest.mark.parametrize("shape", [(7, 256, 256, 14, 14), (4, 256, 128, 13, 27), (3, 512, 256, 14, 14), (5, 256, 512, 14, 14),
                                    (9, 128, 128, 28, 28), (6, 128, 256, 28, 28),
                                    # the weights-stationary 64-channel kernel (round 5): more tiles than CUs, ragged tile column, 112 x 112
-                                   (24, 64, 64, 56, 56), (60, 64, 64, 28, 40), (3, 64, 64, 112, 112)])
+                                   (24, 64, 64, 56, 56), (60, 64, 64, 28, 40), (6, 64, 64, 112, 112)])
 def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     """msml_conv2d_bnin_acc: training-mode BatchNorm (+ PReLU) -> 3x3 conv in ONE launch (coefficients derived from the
     producer's f64 accumulator in the kernel prologue, normalised tile applied in LDS and written through, running
@@ -1009,7 +1009,7 @@ HALO2 = [
     (325, 256, 256, 7, 1),
     (162, 512, 512, 14, 2),      # stride 2 onto a 7 x 7 grid: mosaic of parity planes
     (241, 512, 512, 4, 1),       # 4 x 4 maps: 3 x 2 images per tile, ragged batch (the last tile holds one image)
-    (482, 128, 256, 4, 1),
+    (482, 256, 256, 4, 1),
     (81, 256, 256, 14, 2),       # backward-data only (four slices per tile): the forward has 42 workgroups
 ]
 

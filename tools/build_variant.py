@@ -12,7 +12,27 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 
+def build_all(defs):
+    """Every source with the extra defines (e.g. MSML_LDS_GUARD): variants/libmsml_<tag>.so"""
+    import concurrent.futures
+    outdir = os.path.join(ROOT, "variants", "obj_" + "_".join(d.replace("=", "") for d in defs))
+    os.makedirs(outdir, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(ge.CSRC) if f.endswith(".hip"))
+
+    def cc(f):
+        obj = os.path.join(outdir, f + ".o")
+        subprocess.run([ge.HIPCC] + ge.FLAGS + ["-D" + d for d in defs] + ["-c", os.path.join(ge.CSRC, f), "-o", obj], check=True)
+        return obj
+    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(cc, srcs))
+    lib = os.path.join(ROOT, "variants", "libmsml_%s.so" % "_".join(d.replace("=", "") for d in defs))
+    subprocess.run([ge.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
+    print(lib)
+
+
 def main():
+    if sys.argv[1] == "--all":
+        return build_all(sys.argv[2:])
     src, defs = sys.argv[1], sys.argv[2:]
     ge.build()
     outdir = os.path.join(ROOT, "variants")
