@@ -548,7 +548,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
-    from msml_amd import ops
+    from msml_amd import blocks, functional, ops
+    assert not blocks.FAULT and blocks.TAP is None and not functional.FAULT, "test instrumentation is on (MSML_FAULT?)"
     if args.no_graph or (world > 1 and args.launch == "auto"):
         # multi-rank: eager only -- capturing RCCL collectives into a hipGraph was verified with a
         # one-rank communicator only, and a capture that fails mid-collective cannot be retried

@@ -156,6 +156,12 @@ def conv(x0, x1, weight, bias, cfg, wp=None):
     return y, (stats if stats.numel() else None)
 
 
+# Test instrumentation (tests/test_gpu_module_local.py), default off: a deliberately wrong backward ("skip_tee": _ConvTee
+# drops the gradient of its second consumer) that the module-level f64 check must flag.  Never set by product code; bench.py
+# asserts it is empty.
+FAULT = ""
+
+
 class _ConvTee(torch.autograd.Function):
     """_Conv whose first input has a SECOND consumer: returns (y, statistics, alias of x0).  The caller hands the alias
     to the other consumer; its gradient then arrives HERE and is summed with the conv's input gradient inside the
@@ -173,6 +179,8 @@ class _ConvTee(torch.autograd.Function):
     def backward(ctx, dy, _dstats, dtee):
         cfg = ctx.cfg
         x0, x1, weight = ctx.saved_tensors
+        if FAULT == "skip_tee":      # test instrumentation (tests/test_gpu_module_local.py): the second gradient is dropped
+            dtee = None
         fused = None
         if (dy is not None and dtee is not None and ctx.needs_input_grad[0] and not cfg["deconv"] and cfg["stride"] == 1
                 and dy.dtype == torch.bfloat16 and dtee.dtype == torch.bfloat16 and dtee.shape == x0.shape):
