@@ -9,6 +9,7 @@
   the exact-f32 HIP path on the same inputs, and hipGraph replay == eager issue.
 """
 import argparse
+import os
 
 import numpy as np
 import pytest
@@ -145,6 +146,62 @@ def test_deep_train_step_bf16_fused(frb, bs):
             assert rel_err(sd[n].cpu().numpy(), g[key]) < tol["stat"], (n, rel_err(sd[n].cpu().numpy(), g[key]))
 
 
+# ---- sampled ONE-block f64 checks inside the full-size steps ---------------------------------------
+# The two full-size tests below compare the bf16 HIP path with the f32 HIP path -- a self-comparison.  A few blocks of
+# the SAME bf16 step (one per FRB stage, one FM bottleneck, one OSB block) are tapped at the FULL per-GPU batch and
+# recomputed on their own in f64 on the CPU from the tensors the HIP backward consumed, with the bounds of
+# tests/test_gpu_block_local.py (2 x the block's own emulated bf16 error, three draws): a reference-side assertion at the
+# batch the headline runs, where the block-by-block test stops at batch 32 / 16.
+class _Snap:
+    """A tapped block with the parameters it had BEFORE the optimizer step of the tapped training step."""
+
+    def __init__(self, mod):
+        self.conv1, self.conv2, self.downsample = mod.conv1, getattr(mod, "conv2", None), getattr(mod, "downsample", None)
+        self._sd = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+
+    def state_dict(self):
+        return self._sd
+
+
+def _tapped_step(model, names, step_fn):
+    """Run step_fn() with block taps on `names`; returns (step_fn's result, rows of the local f64 check)."""
+    from msml_amd import blocks
+    from tests.test_gpu_block_local import _check_block
+    mods = dict(model.named_modules())
+    snaps = {n: _Snap(mods[n]) for n in names}
+    by_w = {id(mods[n].conv1.weight): n for n in names}
+    taps = {}
+
+    def tap(kind, bp, t):
+        n = by_w.get(id(bp["c1"][0]))
+        if n is not None:
+            taps[n] = (kind, {k: (v.detach().clone() if v is not None else None) for k, v in t.items()})
+    blocks.TAP = tap
+    try:
+        out = step_fn()
+        torch.cuda.synchronize()
+    finally:
+        blocks.TAP = None
+    assert set(taps) == set(names), (sorted(taps), names)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rows = {"norm-wise": [], "element fraction": [], "per-channel": [], "statistic": []}
+    for n in names:
+        kind, t = taps[n]
+        grads = {n + "." + pn: p.grad.detach().float().cpu() for pn, p in mods[n].named_parameters()}
+        for fam, part in zip(rows, _check_block(kind, n, snaps[n], t, grads)):
+            rows[fam] += [(n + "." + what, e, b) for what, e, b in part]
+    return out, rows
+
+
+def _report_rows(tag, rows):
+    bad = [(fam,) + r for fam, rr in rows.items() for r in rr if not r[1] < r[2]]
+    for fam, rr in rows.items():
+        top = sorted(rr, key=lambda r: -r[1] / r[2])[:3]
+        print("   %s one-block f64 check, %s, closest to their bounds: " % (tag, fam) +
+              "; ".join("%s %.2e (bound %.2e)" % r for r in top))
+    return bad
+
+
 def _bench_args(dtype, frb="iresnet50", classes=85742, emulate_world=1):
     return argparse.Namespace(frb=frb, batch=256, classes=classes, dtype=dtype, emulate_world=emulate_world,
                               data="resident")
@@ -170,7 +227,9 @@ def test_full_size_step_bf16_vs_f32_and_graph_replay():
     # 6 %, tests/test_gpu_block_local.py -- measured 0.38: cap 0.45)
     tol = bf16_tolerances("ires50_b32", cap=0.45)
 
-    def run(dtype, steps=1, graph=False, streams=True):
+    local_rows = {}
+
+    def run(dtype, steps=1, graph=False, streams=True, local=None):
         torch.manual_seed(0)
         tr = bench.Trainer(_bench_args(dtype), 0, 0, 1)
         batch = tr.batches[0]
@@ -192,6 +251,10 @@ def test_full_size_step_bf16_vs_f32_and_graph_replay():
                 for _ in range(steps):
                     gr.replay()
                     losses.append((float(out[0]), float(out[1])))
+            elif local:
+                (lv, sl), rows = _tapped_step(tr.model, local, lambda: tr.step(batch))
+                losses.append((float(lv), float(sl)))
+                local_rows.update(rows)
             else:
                 for _ in range(steps + (2 if steps > 1 else 0)):
                     lv, sl = tr.step(batch)
@@ -212,7 +275,11 @@ def test_full_size_step_bf16_vs_f32_and_graph_replay():
         return res
 
     f32 = run("f32")
-    b16 = run("bf16")
+    # the bf16 step with six blocks tapped at the full batch (one per FRB stage, an FM bottleneck, an OSB block)
+    b16 = run("bf16", local=["frb.layer1.2", "frb.layer2.3", "frb.layer3.6", "frb.layer4.2", "frb.fm_ops.2.res_block.0",
+                             "osb.layer2.1"])
+    bad = _report_rows("batch 256", local_rows)
+    assert not bad, bad[:10]
     (lv32, sl32), (lv16, sl16) = f32["losses"][0], b16["losses"][0]
     print("full-size step: head loss f32 %.5f bf16 %.5f | seg loss %.5f / %.5f | gnorm %.4f / %.4f"
           % (lv32, lv16, sl32, sl16, f32["gnorm"], b16["gnorm"]))
@@ -248,6 +315,9 @@ def test_config4_full_size_step_ires100_2m_ids_shard():
     picks = [n for n in STAGE_PICKS if n != "frb.layer3.13.conv2.weight"] + ["frb.layer3.29.conv2.weight",
                                                                               "frb.layer2.12.conv1.weight"]
 
+    LOCAL4 = ["frb.layer1.2", "frb.layer2.12", "frb.layer3.29", "frb.layer4.2", "frb.fm_ops.1.res_block.1", "osb.layer3.1"]
+    local_rows = {}
+
     def run(dtype):
         torch.manual_seed(0)
         torch.cuda.reset_peak_memory_stats()
@@ -256,7 +326,11 @@ def test_config4_full_size_step_ires100_2m_ids_shard():
         if dtype == "bf16":
             ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
         try:
-            lv, sl = tr.step(tr.batches[0])
+            if dtype == "bf16":
+                (lv, sl), rows = _tapped_step(tr.model, LOCAL4, lambda: tr.step(tr.batches[0]))
+                local_rows.update(rows)
+            else:
+                lv, sl = tr.step(tr.batches[0])
             torch.cuda.synchronize()
             names = dict(tr.model.named_parameters())
             finite = all(bool(torch.isfinite(p.grad).all()) for p in names.values() if p.grad is not None)
@@ -272,6 +346,8 @@ def test_config4_full_size_step_ires100_2m_ids_shard():
         return res
 
     f32, b16 = run("f32"), run("bf16")
+    bad = _report_rows("config 4, batch 256", local_rows)
+    assert not bad, bad[:10]
     print("config 4 full size: head loss f32 %.5f bf16 %.5f | seg %.5f / %.5f | gnorm %.4f / %.4f | peak %.1f / %.1f GB"
           % (f32["loss"][0], b16["loss"][0], f32["loss"][1], b16["loss"][1], f32["gnorm"], b16["gnorm"],
              f32["peak_gb"], b16["peak_gb"]))
