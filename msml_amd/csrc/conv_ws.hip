@@ -298,6 +298,42 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     // ---- epilogue: affine / PReLU / statistics in registers, transpose through the consumed image
     unsigned short* otile = reinterpret_cast<unsigned short*>(As + cur * ABYTES);
+    if constexpr (M16 && !FUSE) {
+      // forward launches without a residual store straight from registers (conv_halo.hip): v_permlane16_swap leaves
+      // every lane with 8 contiguous channels of its pixel -- no LDS transpose, no second barrier per tile
+      if (p.residual == nullptr) {
+#pragma unroll
+        for (int jg = 0; jg < 4; jg++) {
+          const int m = i0 * 32 + jg * 16 + l16;
+          const bool valid = (jg < 2 * nmt) & pix_ok(m);
+          u32x2 pk[2];
+#pragma unroll
+          for (int g = 0; g < 2; g++) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              float z = acc4[jg][g][j] * sv[g][j] + bv[g][j];
+              if (act_here) z = z > 0.f ? z : z * av[g][j];
+              v[j] = z;
+              if (valid) {
+                s1[g][j] += z;
+                s2[g][j] += z * z;
+              }
+            }
+            pk[g][0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
+            pk[g][1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
+          }
+          u32x4 o16;
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            auto sw = __builtin_amdgcn_permlane16_swap(pk[0][e], pk[1][e], false, false);
+            o16[e] = sw[0]; o16[2 + e] = sw[1];
+          }
+          if (valid) *reinterpret_cast<u32x4*>(p.out + pix_off(m) + kg * 32 + (q16 & 1) * 16 + (q16 >> 1) * 8) = o16;
+        }
+        continue;
+      }
+    }
     if constexpr (M16) {
 #pragma unroll
       for (int jg = 0; jg < 4; jg++) {

@@ -51,8 +51,19 @@ def main():
         _lib.call("msml_conv_wgrad_group", arr(*[dys[i].data_ptr() for i in idx]), arr(*[xs[i].data_ptr() for i in idx]),
                   arr(*[d.data_ptr() for d in dws]), 4, C, C, C, C, C, 0, N, H, H, H, H, 3, 3, 1, 1, 1, 1, ws, ws.numel(),
                   _lib.BF16)                                                                           # four layers
+    # round 5: the halo2 family -- 256 -> 256 @ 28x28 stride 2 forward (four parity planes) and its backward-data conv with
+    # the fused BatchNorm sums (four output classes), 512 -> 512 @ 7x7 forward (mosaic of four images)
+    x28 = [torch.randn(N, 28, 28, C, device="cuda").bfloat16() for _ in range(4)]
+    c5 = 512
+    x7 = [torch.randn(N, 7, 7, c5, device="cuda").bfloat16() for _ in range(REPS)]
+    w5 = torch.randn(c5, c5, 3, 3, device="cuda") * 0.02
+    wp5 = ops.pack_weight(w5, False, c5, 0, _lib.BF16)
+    for r in range(REPS):
+        ops.conv2d(x28[r % 4], None, wp, None, C, 3, 3, 2, 1, 1, False, want_stats=True)
+        ops.conv_dgrad_bnbwd(dys[r], wpt, C, 3, 3, 2, 1, 1, 28, 28, x28[(r + 1) % 4], coef, alpha)
+        ops.conv2d(x7[r], None, wp5, None, c5, 3, 3, 1, 1, 1, False, want_stats=True)
     torch.cuda.synchronize()
-    print("launched %d x (fwd, bn+fwd, dgrad+bnb, wgrad x1, wgrad x4) at %d x %d x %d x %d" % (REPS, N, H, H, C))
+    print("launched %d x (fwd, bn+fwd, dgrad+bnb, wgrad x1, wgrad x4) at %d x %d x %d x %d + the halo2 launches" % (REPS, N, H, H, C))
 
 
 if __name__ == "__main__":

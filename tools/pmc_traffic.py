@@ -40,6 +40,9 @@ def per_kind(d, counter):
         m = re.search(r"k_conv_halo<\d+, \d+, (true|false), (true|false)", name)       # third / fourth template argument = FUSE / XF
         if m:
             kind = "dgrad" if m.group(1) == "true" else ("fwd_bn" if m.group(2) == "true" else "fwd")
+        m2 = re.search(r"k_conv_halo2<\d+, \d+, (\d), (\d), (true|false)", name)   # GEOM, MOS, FUSE
+        if m2:
+            kind = {"1": "h2_s2_fwd", "2": "h2_s2_dgrad", "0": "h2_mosaic"}[m2.group(1)]
         elif "k_wgrad_halo" in name:
             kind = "wgrad"
         elif "k_wgrad_reduce" in name:
@@ -75,6 +78,19 @@ def main():
         wk = mean(w["wgrad"][which::2]) + mean(w["reduce"][which::2])
         entry(label, "k_wgrad_halo<128> + k_wgrad_reduce_rows (%d layer%s per launch pair)" % (layers, "s" * (layers > 1)),
               fk, wk, layers * (2 * ACT + DW), "operands + split-K slabs written and re-read + the f32 gradient")
+    if f.get("h2_s2_fwd"):
+        a28 = N * 28 * 28 * C * 2
+        entry("conv N c256+0->256 28x28 k3x3 s2 n256 [k_conv_halo2<stride-2 forward, 4 parity planes, 14x14 px>]",
+              "k_conv_halo2<256, 1, stride-2 forward>", mean(f["h2_s2_fwd"]), mean(w["h2_s2_fwd"]), a28 + ACT + WB,
+              "stride-2 forward + statistics: the 28x28 input once (as four parity planes), the 14x14 output once")
+        entry("conv T+bnb c256+0->256 14x14 k3x3 s2 n256 [k_conv_halo2<stride-2 backward-data, 4 output classes, 14x14 px>]",
+              "k_conv_halo2<256, 1, stride-2 backward-data, FUSE>", mean(f["h2_s2_dgrad"]), mean(w["h2_s2_dgrad"]),
+              ACT + 2 * a28 + WB, "stride-2 backward-data + BatchNorm sums: dY (re-read by the four class slices), saved "
+              "28x28 input read, 28x28 dX written")
+        a7 = N * 7 * 7 * 512 * 2
+        entry("conv N c512+0->512 7x7 k3x3 s1 n256 [k_conv_halo2<mosaic of four 7x7 images x 128 ch>]",
+              "k_conv_halo2<128, 2, mosaic>", mean(f["h2_mosaic"]), mean(w["h2_mosaic"]), 2 * a7 + 512 * 512 * 9 * 2,
+              "7x7 forward + statistics: input once per 128-channel block of the output (x 4), output once, weights per tile")
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in out.items():
         if isinstance(v, dict):
