@@ -376,10 +376,29 @@ k_conv_halo(const ConvHaloArgs p) {
   static_assert(NT % C8 == 0 && (BM * C8) % NT == 0, "a thread keeps one 8-channel chunk in the copy-out loop");
   const int c8 = t % C8;
   constexpr bool fuse = FUSE;
-  u32x4 xr[ITERS];
+  // FUSE on the 16x16x32 tiling (round 5): the rounded dX leaves straight from registers (after v_permlane16_swap a lane
+  // holds channels cdir .. cdir + 7 of its pixel) and feeds the BatchNorm sums in that layout, with the saved BatchNorm
+  // input fetched per (pixel group, lane) -- no LDS transpose, no barrier between the main loop and the stores
+  // Measured NOT faster on these maps (round 5, tools/bench_bnbwd.py + step A/B on one box: 128 @ 28x28 102.1 -> 99.5 us, 256 @
+  // 14x14 65.8 -> 65.8 us, the step 29.24 / 29.21 -> 29.35 / 29.35 ms: the per-lane loads of the saved input touch 64 B per
+  // pixel and wave where the copy-out loop reads whole 512-B pixel rows) -- kept as a build switch, -DHALO_FDIR.
+#ifdef HALO_FDIR
+  constexpr bool FDIR = FUSE && M16;
+#else
+  constexpr bool FDIR = false;
+#endif
+  const int cdir = kg * 32 + (q16 & 1) * 16 + (q16 >> 1) * 8;
+  u32x4 xr[FDIR ? NG : ITERS];
   BnbCoef bk;
   float bq[3][8];
-  if (fuse) {
+  if constexpr (FDIR) {
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+      const int m = i0 * 32 + k * 16 + l16;
+      xr[k] = (k < 2 * nmt && pix_ok(m)) ? *reinterpret_cast<const u32x4*>(p.bnb.x + pix_off(m) + n0 + cdir) : u32x4{0, 0, 0, 0};
+    }
+    bk = bnb_load_coef(p.bnb, n0 + cdir);
+  } else if (fuse) {
 #pragma unroll
     for (int k = 0; k < ITERS; k++) {
       const int m = (t + k * NT) / C8;
@@ -407,7 +426,7 @@ k_conv_halo(const ConvHaloArgs p) {
   // Forward launches without a residual store straight from registers: v_permlane32_swap gives
   // the lane pair of a pixel 16 contiguous channels each (32 B), so a wave writes 64 B runs per
   // pixel with two 16-B stores per lane and tile -- no LDS transpose, no barrier.
-  const bool direct = X3 || (!FUSE && p.residual == nullptr);
+  const bool direct = X3 || FDIR || (!FUSE && p.residual == nullptr);
   if constexpr (M16) {
 #pragma unroll
     for (int jg = 0; jg < NG; jg++) {
@@ -445,8 +464,12 @@ k_conv_halo(const ConvHaloArgs p) {
           auto sw = __builtin_amdgcn_permlane16_swap(pk[0][e], pk[1][e], false, false);
           o16[e] = sw[0]; o16[2 + e] = sw[1];
         }
-        if (valid)
+        if (valid) {
           *reinterpret_cast<u32x4*>(p.out + pix_off(m) + n0 + kg * 32 + (q16 & 1) * 16 + (q16 >> 1) * 8) = o16;
+          if constexpr (FDIR)
+            bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16)),
+                      load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[jg])), bq);
+        }
       }
     }
   } else {
@@ -578,14 +601,17 @@ k_conv_halo(const ConvHaloArgs p) {
   }
   }
   if (fuse) {
-    constexpr int G = NT / C8;
+    constexpr int G = FDIR ? 16 * NWM : NT / C8;       // threads that share an 8-channel chunk
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
     MSML_LDS_REGION(red, G * 3 * BN * 4);
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
-      for (int j = 0; j < 8; j++) red[((t / C8) * 3 + q) * BN + (t % C8) * 8 + j] = bq[q][j];
+      for (int j = 0; j < 8; j++) {
+        if constexpr (FDIR) red[((mg * 16 + l16) * 3 + q) * BN + cdir + j] = bq[q][j];
+        else red[((t / C8) * 3 + q) * BN + (t % C8) * 8 + j] = bq[q][j];
+      }
     __syncthreads();
     for (int i = t; i < 3 * BN; i += NT) {
       const int q = i / BN, c = i % BN;

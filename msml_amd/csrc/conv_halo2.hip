@@ -284,10 +284,24 @@ k_conv_halo2(const ConvHalo2Args p) {
   constexpr int C8 = BN / 8, ITERS = (BM * C8 + NT - 1) / NT;
   static_assert(NT % C8 == 0, "a thread keeps one 8-channel chunk in the copy-out loop");
   const int c8 = t % C8;
-  u32x4 xr[ITERS];
+  // FDIR (mosaic tiles only): the rounded dX leaves straight from registers (after v_permlane16_swap a lane holds channels
+  // cdir .. cdir + 7 of its pixel) and feeds the BatchNorm sums in that layout, the saved BatchNorm input fetched per (pixel
+  // group, lane): no LDS transpose, no barrier between the main loop and the stores.  Measured (tools/bench_bnbwd.py): 512 ->
+  // 512 @ 7x7 69.2 -> 63.4 us; on the large maps the 64-B granularity of those loads costs more than the transpose saves (128 @
+  // 56x56 stride 2: 193 -> 205 us, 256 @ 28x28: 94 -> 100 us), so the 14 x 14 tilings keep the LDS-transposed copy-out.
+  constexpr bool FDIR = FUSE && MOS != 0;
+  const int cdir = kg * 32 + ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;
+  u32x4 xr[FDIR ? NGW : ITERS];
   BnbCoef bk;
   float bq[3][8];
-  if constexpr (FUSE) {
+  if constexpr (FDIR) {
+#pragma unroll
+    for (int k = 0; k < NGW; k++) {
+      const int m = (g0 + k) * 16 + (lane & 15);
+      xr[k] = (k < ng && pix_ok(m)) ? *reinterpret_cast<const u32x4*>(p.bnb.x + pix_off(m) + n0 + cdir) : u32x4{0, 0, 0, 0};
+    }
+    bk = bnb_load_coef(p.bnb, n0 + cdir);
+  } else if constexpr (FUSE) {
 #pragma unroll
     for (int k = 0; k < ITERS; k++) {
       const int idx = t + k * NT, m = idx / C8;
@@ -308,7 +322,7 @@ k_conv_halo2(const ConvHalo2Args p) {
     bv[g] = (!FUSE && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n0 + kb + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
     sv[g] = (!FUSE && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + n0 + kb + 16 * g) : f32x4{1.f, 1.f, 1.f, 1.f};
   }
-  const bool direct = !FUSE && p.residual == nullptr;
+  const bool direct = FDIR || (!FUSE && p.residual == nullptr);
 #pragma unroll
   for (int jg = 0; jg < NGW; jg++) {
     const int m = (g0 + jg) * 16 + l16;
@@ -340,7 +354,12 @@ k_conv_halo2(const ConvHalo2Args p) {
         auto sw = __builtin_amdgcn_permlane16_swap(pk[0][e], pk[1][e], false, false);
         o16[e] = sw[0]; o16[2 + e] = sw[1];
       }
-      if (valid) *reinterpret_cast<u32x4*>(p.out + pix_off(m) + n0 + kg * 32 + (q16 & 1) * 16 + (q16 >> 1) * 8) = o16;
+      if (valid) {
+        *reinterpret_cast<u32x4*>(p.out + pix_off(m) + n0 + cdir) = o16;
+        if constexpr (FDIR)
+          bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16)),
+                    load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[jg])), bq);
+      }
     }
   }
   if (!direct) {
@@ -359,7 +378,7 @@ k_conv_halo2(const ConvHalo2Args p) {
           store8<unsigned short>(reinterpret_cast<unsigned short*>(&v), a8);
         }
         *reinterpret_cast<u32x4*>(p.out + o) = v;
-        if constexpr (FUSE)
+        if constexpr (FUSE && !FDIR)
           bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&v)),
                     load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[k])), bq);
       }
@@ -367,14 +386,17 @@ k_conv_halo2(const ConvHalo2Args p) {
   }
   const long wg = (long)blockIdx.x + (long)gridDim.x * blockIdx.z;
   if constexpr (FUSE) {
-    constexpr int G = NT / C8;
+    constexpr int G = FDIR ? 16 * NWM : NT / C8;       // threads that share an 8-channel chunk
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
     MSML_LDS_REGION(red, G * 3 * BN * 4);
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
-      for (int j = 0; j < 8; j++) red[((t / C8) * 3 + q) * BN + (t % C8) * 8 + j] = bq[q][j];
+      for (int j = 0; j < 8; j++) {
+        if constexpr (FDIR) red[((mg * 16 + (lane & 15)) * 3 + q) * BN + cdir + j] = bq[q][j];
+        else red[((t / C8) * 3 + q) * BN + (t % C8) * 8 + j] = bq[q][j];
+      }
     __syncthreads();
     for (int i = t; i < 3 * BN; i += NT) {
       const int q = i / BN, c = i % BN;

@@ -161,7 +161,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
   BnbCoef bk;
   float bq[3][8];
+  // (FUSE on the 16x16x32 tiling: the sums are taken in the register layout of the direct store -- after the permlane swap
+  // a lane holds channels cdir .. cdir + 7 of its pixel -- so its coefficients are those of that chunk)
+  const int cdir = kg * 32 + (q16 & 1) * 16 + (q16 >> 1) * 8;
+#ifdef WS_NO_FDIR
   if (FUSE) bk = bnb_load_coef(p.bnb, c8 * 8);
+#else
+  if (FUSE) bk = bnb_load_coef(p.bnb, M16 ? cdir : c8 * 8);
+#endif
 #pragma unroll
   for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -196,7 +203,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // that closes an iteration orders those reads before this write)
     if (tile + (int)gridDim.x < p.ntiles) issue_a(tile + gridDim.x, cur ^ 1);
     u32x4 xr[ITERS];
-    if (FUSE) {                                        // saved BatchNorm input of this thread's chunks
+#ifdef WS_NO_FDIR
+    constexpr bool FDIR0 = false;
+#else
+    constexpr bool FDIR0 = M16 && FUSE;
+#endif
+    if (FDIR0) {                                       // saved BatchNorm input in the direct-store layout
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int m = i0 * 32 + k * 16 + l16;
+        xr[k] = (k < 2 * nmt && pix_ok(m)) ? *reinterpret_cast<const u32x4*>(p.bnb.x + pix_off(m) + cdir) : u32x4{0, 0, 0, 0};
+      }
+    } else if (FUSE) {                                 // saved BatchNorm input of this thread's chunks
 #pragma unroll
       for (int k = 0; k < ITERS; k++) {
         const int idx = t + k * NT, m = idx / C8;
@@ -334,6 +352,38 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         continue;
       }
     }
+#ifdef WS_NO_FDIR
+    constexpr bool FDIR = false;                       // (A/B build)
+#else
+    constexpr bool FDIR = M16 && FUSE;
+#endif
+    if constexpr (FDIR) {
+      // backward-data + BatchNorm sums straight from registers: the bf16-rounded dX chunk is stored and, with the saved
+      // BatchNorm input of the same pixel / channels, feeds the three sums (no LDS transpose, one barrier per tile)
+#pragma unroll
+      for (int jg = 0; jg < 4; jg++) {
+        const int m = i0 * 32 + jg * 16 + l16;
+        const bool valid = (jg < 2 * nmt) & pix_ok(m);
+        u32x2 pk[2];
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          pk[g][0] = (unsigned int)f2bf(acc4[jg][g][0]) | ((unsigned int)f2bf(acc4[jg][g][1]) << 16);
+          pk[g][1] = (unsigned int)f2bf(acc4[jg][g][2]) | ((unsigned int)f2bf(acc4[jg][g][3]) << 16);
+        }
+        u32x4 o16;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          auto sw = __builtin_amdgcn_permlane16_swap(pk[0][e], pk[1][e], false, false);
+          o16[e] = sw[0]; o16[2 + e] = sw[1];
+        }
+        if (valid) {
+          *reinterpret_cast<u32x4*>(p.out + pix_off(m) + cdir) = o16;
+          bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16)),
+                    load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[jg])), bq);
+        }
+      }
+      continue;
+    }
     if constexpr (M16) {
 #pragma unroll
       for (int jg = 0; jg < 4; jg++) {
@@ -426,7 +476,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
-      for (int j = 0; j < 8; j++) red[((t / C8) * 3 + q) * C + c8 * 8 + j] = bq[q][j];
+      for (int j = 0; j < 8; j++) {
+#ifndef WS_NO_FDIR
+        if constexpr (M16) red[((((wave >> 1) * 16 + l16)) * 3 + q) * C + cdir + j] = bq[q][j];   // 64 lanes share a chunk
+        else
+#endif
+          red[((t / C8) * 3 + q) * C + c8 * 8 + j] = bq[q][j];
+      }
     __syncthreads();
     for (int i = t; i < 3 * C; i += NT) {
       const int q = i / C, c = i % C;
@@ -534,7 +590,10 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
   if (bnb_rows) *bnb_rows = a.ntiles < ws_num_cus() ? a.ntiles : ws_num_cus();
   // 16x16x32 variant: measured neutral here (64 -> 64 @ 112x112 forward 426 -> 408 us, backward-data and the 56x56 maps
   // +-1 %: this kernel waits on its image loads and transposes, not on the MFMA clock) -- opt-in, MSML_WS_M16=1
-  static const bool m16 = getenv("MSML_WS_M16") && atoi(getenv("MSML_WS_M16")) != 0;
+  // Round 5: with the direct stores (no LDS transpose, one barrier per tile) the 16x16x32 variant is the faster one -- 64 -> 64 @
+  // 112x112 forward 431 -> 385 us, @ 56x56 100 -> 93 us, the step 29.38 -> 29.17 / 29.26 ms (one box, twice): default;
+  // MSML_WS_M16=0 restores the 32x32x16 kernels.
+  static const bool m16 = !(getenv("MSML_WS_M16") && atoi(getenv("MSML_WS_M16")) == 0);
   if (xin) { if (m16) launch_ws<false, true, true>(a, st); else launch_ws<false, true>(a, st); }   // (same tiling as the plain launch)
   else if (bnb) { if (m16) launch_ws<true, false, true>(a, st); else launch_ws<true>(a, st); }
   else { if (m16) launch_ws<false, false, true>(a, st); else launch_ws<false>(a, st); }
