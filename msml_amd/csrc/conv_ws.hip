@@ -193,22 +193,86 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
   }
 
+  // ---- direct epilogue of the 16x16x32 tiling (round 5): forward launches without a residual and backward-data launches
+  // with the fused BatchNorm sums store straight from registers -- v_permlane16_swap leaves every lane with 8 contiguous
+  // channels of its pixel (conv_halo.hip): no LDS transpose, one barrier per tile.  -DWS_STAGGER (tried, not faster): waves
+  // 4-7 (the SIMD partners of 0-3) keep their accumulators across the barrier and store tile t at the top of iteration
+  // t + 1, beside their partners' MFMAs (MI355X_MICROARCH.md, two waves per SIMD, item 9); bit-identical either way.
+  f32x16 acc[2];
+  f32x4 acc4[4][2];                                    // M16: [16-pixel group][channel half]
+  u32x4 xr[ITERS];
+#ifdef WS_NO_FDIR
+  constexpr bool FDIR = false;                         // (A/B build)
+#else
+  constexpr bool FDIR = M16 && FUSE;
+#endif
+  auto epi_dir = [&](int tl) {
+    const int n = tl / tpi, trem = tl - n * tpi, ty = trem / p.tpx;
+    const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
+    auto pix_ok = [&](int m) { return ((m & 15) < TW) & (x0 + (m & 15) < p.W) & (y0 + (m >> 4) < p.H); };
+    auto pix_off = [&](int m) { return ((long)(n * p.H + y0 + (m >> 4)) * p.W + x0 + (m & 15)) * C; };
+#pragma unroll
+    for (int jg = 0; jg < 4; jg++) {
+      const int m = i0 * 32 + jg * 16 + l16;
+      const bool valid = (jg < 2 * nmt) & pix_ok(m);
+      u32x2 pk[2];
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float z = acc4[jg][g][j];
+          if (!FUSE) {
+            z = z * sv[g][j] + bv[g][j];
+            if (act_here) z = z > 0.f ? z : z * av[g][j];
+            if (valid) {
+              s1[g][j] += z;
+              s2[g][j] += z * z;
+            }
+          }
+          v[j] = z;
+        }
+        pk[g][0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
+        pk[g][1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
+      }
+      u32x4 o16;
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        auto sw = __builtin_amdgcn_permlane16_swap(pk[0][e], pk[1][e], false, false);
+        o16[e] = sw[0]; o16[2 + e] = sw[1];
+      }
+      if (valid) {
+#ifndef WS_ABLATE_STORE
+        *reinterpret_cast<u32x4*>(p.out + pix_off(m) + cdir) = o16;
+#endif
+        if constexpr (FDIR)
+          bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16)),
+                    load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[jg])), bq);
+      }
+    }
+  };
+  const bool dir = M16 && (FDIR || (!FUSE && p.residual == nullptr));
+#ifdef WS_STAGGER
+  const bool late = dir && wave >= 4;
+#else
+  const bool late = false;     // measured (round 5, one box): staggered 398 / 89 us forward, 95.4 us fused backward-data against
+                               // 390 / 87 / 89.5 us unstaggered -- the late waves' image requests start later; build switch only
+#endif
+  int ptile = -1;
+
   for (int it = 0; tile < p.ntiles; it++, tile += gridDim.x) {
     const int cur = it & 1;
+    if (late && ptile >= 0) epi_dir(ptile);            // (before this tile's loads of xr and the zeroing of the accumulators)
     const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
     const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
     auto pix_ok = [&](int m) { return ((m & 15) < TW) & (x0 + (m & 15) < p.W) & (y0 + (m >> 4) < p.H); };
     auto pix_off = [&](int m) { return ((long)(n * p.H + y0 + (m >> 4)) * p.W + x0 + (m & 15)) * C; };
     // next tile's image (its buffer was the transpose tile of the previous iteration: the barrier
     // that closes an iteration orders those reads before this write)
+#ifndef WS_ABLATE_LOADS
     if (tile + (int)gridDim.x < p.ntiles) issue_a(tile + gridDim.x, cur ^ 1);
-    u32x4 xr[ITERS];
-#ifdef WS_NO_FDIR
-    constexpr bool FDIR0 = false;
-#else
-    constexpr bool FDIR0 = M16 && FUSE;
 #endif
-    if (FDIR0) {                                       // saved BatchNorm input in the direct-store layout
+    if (FDIR) {                                        // saved BatchNorm input in the direct-store layout
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int m = i0 * 32 + k * 16 + l16;
@@ -224,8 +288,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    f32x16 acc[2];
-    f32x4 acc4[4][2];                                  // M16: [16-pixel group][channel half]
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -261,7 +323,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           xform(tile + gridDim.x, cur ^ 1);
         }
+#ifdef WS_ABLATE_READS
+        if (step + 1 < 18) { a16[nb][0] = a16[cb][0]; a16[nb][1] = a16[cb][1]; a16[nb][2] = a16[cb][2]; a16[nb][3] = a16[cb][3];
+                             b16[nb][0] = b16[cb][0]; b16[nb][1] = b16[cb][1]; }   // (timing build: fragments read once per tile)
+#else
         if (step + 1 < 18) frags(step + 1, a16[nb], b16[nb]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -316,72 +383,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     // ---- epilogue: affine / PReLU / statistics in registers, transpose through the consumed image
     unsigned short* otile = reinterpret_cast<unsigned short*>(As + cur * ABYTES);
-    if constexpr (M16 && !FUSE) {
-      // forward launches without a residual store straight from registers (conv_halo.hip): v_permlane16_swap leaves
-      // every lane with 8 contiguous channels of its pixel -- no LDS transpose, no second barrier per tile
-      if (p.residual == nullptr) {
-#pragma unroll
-        for (int jg = 0; jg < 4; jg++) {
-          const int m = i0 * 32 + jg * 16 + l16;
-          const bool valid = (jg < 2 * nmt) & pix_ok(m);
-          u32x2 pk[2];
-#pragma unroll
-          for (int g = 0; g < 2; g++) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              float z = acc4[jg][g][j] * sv[g][j] + bv[g][j];
-              if (act_here) z = z > 0.f ? z : z * av[g][j];
-              v[j] = z;
-              if (valid) {
-                s1[g][j] += z;
-                s2[g][j] += z * z;
-              }
-            }
-            pk[g][0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
-            pk[g][1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
-          }
-          u32x4 o16;
-#pragma unroll
-          for (int e = 0; e < 2; e++) {
-            auto sw = __builtin_amdgcn_permlane16_swap(pk[0][e], pk[1][e], false, false);
-            o16[e] = sw[0]; o16[2 + e] = sw[1];
-          }
-          if (valid) *reinterpret_cast<u32x4*>(p.out + pix_off(m) + kg * 32 + (q16 & 1) * 16 + (q16 >> 1) * 8) = o16;
-        }
-        continue;
-      }
-    }
-#ifdef WS_NO_FDIR
-    constexpr bool FDIR = false;                       // (A/B build)
-#else
-    constexpr bool FDIR = M16 && FUSE;
-#endif
-    if constexpr (FDIR) {
-      // backward-data + BatchNorm sums straight from registers: the bf16-rounded dX chunk is stored and, with the saved
-      // BatchNorm input of the same pixel / channels, feeds the three sums (no LDS transpose, one barrier per tile)
-#pragma unroll
-      for (int jg = 0; jg < 4; jg++) {
-        const int m = i0 * 32 + jg * 16 + l16;
-        const bool valid = (jg < 2 * nmt) & pix_ok(m);
-        u32x2 pk[2];
-#pragma unroll
-        for (int g = 0; g < 2; g++) {
-          pk[g][0] = (unsigned int)f2bf(acc4[jg][g][0]) | ((unsigned int)f2bf(acc4[jg][g][1]) << 16);
-          pk[g][1] = (unsigned int)f2bf(acc4[jg][g][2]) | ((unsigned int)f2bf(acc4[jg][g][3]) << 16);
-        }
-        u32x4 o16;
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-          auto sw = __builtin_amdgcn_permlane16_swap(pk[0][e], pk[1][e], false, false);
-          o16[e] = sw[0]; o16[2 + e] = sw[1];
-        }
-        if (valid) {
-          *reinterpret_cast<u32x4*>(p.out + pix_off(m) + cdir) = o16;
-          bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16)),
-                    load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[jg])), bq);
-        }
-      }
+    // forward launches without a residual and fused-BatchNorm backward-data launches of the 16x16x32 tiling store
+    // straight from registers (epi_dir above); waves 4-7 do so at the top of the NEXT iteration (stagger)
+    if (dir) {
+      if (!late) epi_dir(tile);
+      ptile = tile;
       continue;
     }
     if constexpr (M16) {
@@ -467,6 +473,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     __syncthreads();     // transpose tile read out: its buffer may take the image after next
   }
+
+  if (late && ptile >= 0) epi_dir(ptile);
+  if (dir) __syncthreads();                            // (the end-of-kernel reductions below reuse LDS the last tile's MFMAs read)
 
   // ---- one partial row per workgroup (the weight region of LDS is free now)
   if (FUSE) {
