@@ -602,6 +602,11 @@ bool msml_conv_halo2_dispatch(const void* in0, int c0p, const void* wp, int kop,
                               int pad_w, int transposed, hipStream_t st, const float* scale, const float* alpha,
                               const void* residual, int res_first, const BnBwdFuse* bnb, int* bnb_rows);
 
+bool msml_conv_s2r_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
+                            float* stats, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
+                            int transposed, hipStream_t st, const float* scale, const float* alpha, const void* residual,
+                            const BnBwdFuse* bnb, int* bnb_rows);
+
 bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
@@ -641,6 +646,11 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   if (!in1 && out_dtype == MSML_BF16 &&
       msml_conv_halo2_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h, pad_w,
                                transposed, st, scale, alpha, residual, res_first, bnb, bnb_rows))
+    return true;
+  // 64 -> 64 channel stride-2 3x3 layers (weights in registers, persistent): conv_s2r.hip
+  if (!in1 && out_dtype == MSML_BF16 &&
+      msml_conv_s2r_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed,
+                             st, scale, alpha, residual, bnb, bnb_rows))
     return true;
   // split-bf16 inference: 3x3 / stride-1 layers of the 28x28 / 14x14 stages on the halo kernel (c0p is 3 x logical)
   if (x3 && !in1 &&

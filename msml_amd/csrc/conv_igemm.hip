@@ -523,6 +523,8 @@ extern "C" int msml_conv2d_bnbwd_acc(const void* in0, int c0p, const void* wp, i
 
 int msml_conv_halo2_tiling(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
                            int pad_h, int pad_w, int transposed);
+int msml_conv_s2r_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                          int pad_w, int transposed);
 bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                             int stride, int pad_h, int pad_w, bool want_stats);
 bool msml_conv_ws_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
@@ -690,6 +692,10 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
   if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
       msml_conv_halo_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
     return coutp % 256 == 0 ? "k_conv_halo<14x14 px x 256 ch, 8 waves>" : "k_conv_halo<14x14 px x 128 ch, 8 waves>";
+  if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
+      msml_conv_s2r_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed))
+    return transposed ? "k_conv_s2r<64 -> 64 stride-2 backward-data, weights in registers, persistent>"
+                      : "k_conv_s2r<64 -> 64 stride-2 forward, 4 parity planes, weights in registers, persistent>";
   if (fast && c1p == 0 && out_dtype == MSML_BF16) {
     const int t2 = msml_conv_halo2_tiling(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed);
     if (t2 == 3) return "k_conv_halo2<mosaic of six 4x4 images x 128 ch>";

@@ -1,0 +1,382 @@
+// 3x3 / stride-2 / pad-1 convolution for bf16 NHWC maps with 64 input and 64 output channels: conv2 of the first
+// IBasicBlock of layer1 (112x112 -> 56x56, backbones/frb/iresnet.py:56-67 with stride 2, :166-170) and of the OSB
+// encoder's layer1 (backbones/osb/unet.py:80-91), forward and backward-data.  These launches are byte-bound (forward: 411 MB
+// in, 103 MB out for 59 GFLOP) and ran on the im2col kernel at 2.5-2.8 TB/s.
+//
+// The weights live in REGISTERS for the life of a persistent workgroup: 8 waves = 4 output-channel groups of 16 x 2
+// halves of the tile's pixel rows, a wave's 16 x 576 weights are 18 fragments = 72 VGPRs, so LDS (160 KB) holds images
+// only and no weight fragment is ever read from it.
+//   FORWARD  (MODE 1): the input is walked as its four parity planes X(2i + py, 2j + px) (conv_halo2.hip); a tile's
+//            four plane images (14 x 14 outputs + halo = 16 x 16 pixels x 128 B each) have one LDS buffer per plane,
+//            and the NEXT tile's plane p is requested as soon as every wave is done with this tile's plane p: each
+//            image has a whole tile of MFMAs to land, the waits are counted (`s_waitcnt vmcnt(8)`: the two images requested
+//            after the wanted one; a tile past the end still issues its (out-of-range, zero-filling) requests).
+//   BACKWARD (MODE 2): a tile of dY (+ halo) in LDS serves the four output parity classes of dX one after the other
+//            (1 / 2 / 2 / 4 taps), next tile's image requested one tile ahead; strided 16-B stores straight from
+//            registers; with FUSE the BatchNorm backward sums (common.h) are taken in that register layout.
+// MFMA: D = W_frag x X_frag on v_mfma_f32_16x16x32_bf16, image fragments by ds_read_b128 from the XOR-swizzled image
+// (chunk key p & 7), zero padding from out-of-range DMA offsets.  Statistics / sums in accumulator mode only.
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "common.h"
+
+struct ConvS2rArgs {
+  const unsigned short* in;
+  unsigned int in_bytes;
+  int N;
+  int IH, IW;         // input map of the launch (MODE 1: full resolution; MODE 2: dY = the half-resolution grid)
+  int GH, GW;         // GEMM grid (half resolution): 14 x 14 tiles
+  int OH, OW;         // output map (MODE 1: GH x GW; MODE 2: 2 GH x 2 GW)
+  int tpy, tpx, ntiles;
+  const unsigned short* wp;      // [64][576] bf16, K order [tap][c]
+  unsigned short* out;
+  unsigned int out_bytes;
+  float* stats;       // MODE 1: accumulator double[MSML_ACC_ROWS][2][64] or nullptr
+  BnBwdFuse bnb;      // MODE 2 + FUSE (accumulator mode)
+};
+
+#define S2R_OOB 0x78000000u
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int MODE, bool FUSE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_s2r(const ConvS2rArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = 64, ABYTES = 256 * 128, NIMG = MODE == 1 ? 4 : 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                                     // [NIMG][256 px][128 B]
+  MSML_LDS_REGION(As, NIMG * ABYTES + 1024);           // (+ the pixels the padding rows read past an image)
+  float* ktab = reinterpret_cast<float*>(smem + NIMG * ABYTES + 1024);      // FUSE: [5][64] scale, shift, alpha, invstd, -mean invstd
+  if (FUSE) MSML_LDS_REGION(ktab, 5 * C * 4);
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kg = wave & 3, mg = wave >> 2;             // 16 output channels, pixel-row groups [7 mg, 7 mg + 7)
+  const int l16 = lane & 15, q16 = lane >> 4;
+  const int tpi = p.tpy * p.tpx;
+
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
+
+  // weights: fragment (tap, window w) = rows kg * 16 + l16, k = tap * 64 + w * 32 + q16 * 8 .. + 7
+  u32x4 wf[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+      wf[tap][w] = *reinterpret_cast<const u32x4*>(p.wp + (long)(kg * 16 + l16) * 576 + tap * 64 + w * 32 + q16 * 8);
+  if (FUSE) {
+    for (int c = t; c < C; c += 512) {
+      const float is = p.bnb.invstd[c];
+      ktab[c] = p.bnb.scale[c];
+      ktab[C + c] = p.bnb.shift[c];
+      ktab[2 * C + c] = p.bnb.alpha ? p.bnb.alpha[c] : 1.f;
+      ktab[3 * C + c] = is;
+      ktab[4 * C + c] = -p.bnb.mean[c] * is;
+    }
+  }
+
+  // image request of (tile, plane offset `poff` bytes) into LDS buffer `buf`; tile < 0 or >= ntiles: all lanes out of range
+  // (the request is still issued: the counted waits below rely on a fixed number of requests per step)
+  auto issue_img = [&](int tile, unsigned int poff, int buf) {
+    const bool live = tile < p.ntiles;
+    const int tl = live ? tile : 0;
+    const int n = tl / tpi, trem = tl - n * tpi, ty = trem / p.tpx;
+    const int y0 = ty * 14, x0 = (trem - ty * p.tpx) * 14;
+    char* a = As + buf * ABYTES;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int j = wave + i * 8;
+      const int hp = j * 8 + (lane >> 3);
+      const int logical = (lane & 7) ^ (hp & 7);
+      int by = y0 + (hp >> 4) - 1, bx = x0 + (hp & 15) - 1;
+      const bool v = live & ((unsigned)by < (unsigned)p.GH) & ((unsigned)bx < (unsigned)p.GW);
+      if (MODE == 1) { by *= 2; bx *= 2; }
+      const unsigned int off = v ? (unsigned int)((n * p.IH + by) * p.IW + bx) * (unsigned int)(C * 2) + poff + logical * 16u
+                                 : S2R_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(a + j * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[7];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int j = 0; j < 7; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // one tap of the walked map: LDS row offset lr, column offset ls (1 = the tap's pixel itself), weight tap index wt
+  auto tap_mfma = [&](const char* img, int lr, int ls, const u32x4 (&wfr)[2]) {
+    const int arow = l16 + ls, asw = arow & 7;
+    const char* Arow = img + (((lr << 4) + mg * 112) * 128) + arow * 128;
+    u32x4 a[2][7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) a[0][j] = *reinterpret_cast<const u32x4*>(Arow + ((q16 ^ asw) << 4) + j * 2048);
+#pragma unroll
+    for (int j = 0; j < 7; j++) a[1][j] = *reinterpret_cast<const u32x4*>(Arow + (((4 + q16) ^ asw) << 4) + j * 2048);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+#pragma unroll
+      for (int j = 0; j < 7; j++)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr[w]), __builtin_bit_cast(bf16x8, a[w][j]),
+                                                         acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- direct epilogue: a lane holds channels kg * 16 + 4 q16 + (0..3) of pixel l16 of each of its 7 groups.  Groups
+  // are stored in pairs: v_permlane16_swap trades the odd 16-lane rows of group j for the even rows of group j + 1, which
+  // leaves rows 0 / 2 with channels 0-7 / 8-15 of group j's pixel and rows 1 / 3 with those of group j + 1's: one 16-B
+  // store per lane and pair (the seventh group pairs with nothing: its rows 1 / 3 store out of range = dropped).
+  const int cch = kg * 16 + (q16 >> 1) * 8;            // this lane's 8-channel chunk after the swap
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};   // MODE 1: statistics of channels kg * 16 + 4 q16 + (0..3), f32 values
+  float bq[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) bq[0][j] = bq[1][j] = bq[2][j] = 0.f;
+  // element offset of the output pixel of GEMM row m of (tile origin n, y0, x0), class (cy, cx); negative = no pixel
+  auto out_pix = [&](int n, int y0, int x0, int m, int cy, int cx) -> long {
+    const int my = m >> 4, mx = m & 15;
+    int gy = y0 + my, gx = x0 + mx;
+    if (!((mx < 14) & (gx < p.GW) & (gy < p.GH))) return -1;
+    if (MODE == 2) { gy = 2 * gy + cy; gx = 2 * gx + cx; }
+    return ((long)(n * p.OH + gy) * p.OW + gx) * C;
+  };
+  u32x4 xr[4];
+  auto load_x = [&](int n, int y0, int x0, int cy, int cx) {     // FUSE: saved BatchNorm input in the store layout
+#pragma unroll
+    for (int pr = 0; pr < 4; pr++) {
+      const int m = (mg * 7 + 2 * pr + (q16 & 1)) * 16 + l16;
+      const long o = (2 * pr + (q16 & 1) < 7) ? out_pix(n, y0, x0, m, cy, cx) : -1;
+      xr[pr] = o >= 0 ? *reinterpret_cast<const u32x4*>(p.bnb.x + o + cch) : u32x4{0, 0, 0, 0};
+    }
+  };
+  auto epilogue = [&](int n, int y0, int x0, int cy, int cx) {
+    u32x2 pk[8];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      pk[j][0] = (unsigned int)f2bf(acc[j][0]) | ((unsigned int)f2bf(acc[j][1]) << 16);
+      pk[j][1] = (unsigned int)f2bf(acc[j][2]) | ((unsigned int)f2bf(acc[j][3]) << 16);
+      if (MODE == 1 && p.stats && out_pix(n, y0, x0, (mg * 7 + j) * 16 + l16, 0, 0) >= 0) {
+        s1 += acc[j];
+        s2 += acc[j] * acc[j];
+      }
+    }
+    pk[7] = u32x2{0, 0};
+    BnbCoef bk;
+    if (FUSE) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        bk.sc[j] = ktab[cch + j]; bk.sh[j] = ktab[C + cch + j]; bk.al[j] = ktab[2 * C + cch + j];
+        bk.is[j] = ktab[3 * C + cch + j]; bk.nm[j] = ktab[4 * C + cch + j];
+      }
+    }
+#pragma unroll
+    for (int pr = 0; pr < 4; pr++) {
+      u32x4 o16;
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        auto sw = __builtin_amdgcn_permlane16_swap(pk[2 * pr][e], pk[2 * pr + 1][e], false, false);
+        o16[e] = sw[0]; o16[2 + e] = sw[1];
+      }
+      const int grp = 2 * pr + (q16 & 1);
+      const int m = (mg * 7 + grp) * 16 + l16;
+      const long o = grp < 7 ? out_pix(n, y0, x0, m, cy, cx) : -1;
+      // (buffer store: an out-of-range offset drops it)
+      __builtin_amdgcn_raw_buffer_store_b128(o16, rs_out, o >= 0 ? (unsigned int)((o + cch) * 2) : S2R_OOB, 0, 0);
+      if (o >= 0) {
+        const Vec8 v = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16));
+        if (FUSE) bnb_accum(bk, p.bnb.alpha != nullptr, v, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[pr])), bq);
+      }
+    }
+  };
+
+  if (FUSE) __syncthreads();                           // coefficient table
+  if constexpr (MODE == 1) {
+    // ---------------- forward: planes 3 (4 taps), 2, 1 (2 taps each), 0 (1 tap); buffer = plane -----------------
+    // plane (py, px) adds (py IW + px) pixels to the plane-(0, 0) offsets
+    const unsigned int po[4] = {0u, (unsigned int)(C * 2), (unsigned int)(p.IW * C * 2), (unsigned int)((p.IW + 1) * C * 2)};
+    int tile = blockIdx.x;
+    issue_img(tile, po[3], 3);
+    issue_img(tile, po[2], 2);
+    issue_img(tile, po[1], 1);
+    for (; tile < p.ntiles; tile += gridDim.x) {
+      const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+      const int y0 = ty * 14, x0 = (trem - ty * p.tpx) * 14;
+      const int nxt = tile + gridDim.x;
+      zero_acc();
+      // Counted waits: `s_waitcnt vmcnt(N)` returns when all but the N youngest memory operations of the wave are done, so
+      // N = the image requests issued after the wanted one (always 8 here: two images of 4 requests; issue_img never
+      // skips a request).  The up-to-4 stores of the previous tile's epilogue sit between them in issue order: not counting
+      // them only makes a wait stronger (it then also covers the image requested before those stores, three steps old).
+      // step 0: plane 3.  Issued after its request: planes 2 and 1 of this tile (+ the previous tile's stores)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_img(tile, po[0], 0);                       // (plane 0's buffer: read last in the previous tile's last step)
+      {
+        const char* img = As + 3 * ABYTES;             // rows r in {0, 2} x columns s in {0, 2}: offsets lr, ls = {0, 1}
+        tap_mfma(img, 0, 0, wf[0]);
+        tap_mfma(img, 0, 1, wf[2]);
+        tap_mfma(img, 1, 0, wf[6]);
+        tap_mfma(img, 1, 1, wf[8]);
+      }
+      // step 1: plane 2 = (py 1, px 0): rows {0, 2}, column 1.  Issued after its request: plane 1, (stores), plane 0
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_img(nxt, po[3], 3);
+      {
+        const char* img = As + 2 * ABYTES;
+        tap_mfma(img, 0, 1, wf[1]);
+        tap_mfma(img, 1, 1, wf[7]);
+      }
+      // step 2: plane 1 = (py 0, px 1): row 1, columns {0, 2}.  Issued after its request: (stores), plane 0, next plane 3
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_img(nxt, po[2], 2);
+      {
+        const char* img = As + 1 * ABYTES;
+        tap_mfma(img, 1, 0, wf[3]);
+        tap_mfma(img, 1, 1, wf[5]);
+      }
+      // step 3: plane 0: the centre tap.  Issued after its request: the next tile's planes 3 and 2
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_img(nxt, po[1], 1);
+      tap_mfma(As, 1, 1, wf[4]);
+      epilogue(n, y0, x0, 0, 0);
+    }
+  } else {
+    // ---------------- backward-data: a dY tile serves the four output classes; next tile's image one tile ahead ---
+    int tile = blockIdx.x, it = 0;
+    issue_img(tile, 0, 0);
+    for (; tile < p.ntiles; tile += gridDim.x, it++) {
+      const int cur = it & 1;
+      const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+      const int y0 = ty * 14, x0 = (trem - ty * p.tpx) * 14;
+      __syncthreads();                                 // this tile's image landed everywhere (drains vmcnt); the other
+      issue_img(tile + gridDim.x, 0, cur ^ 1);         // buffer was read last in the previous iteration
+      const char* img = As + cur * ABYTES;
+      // class (cy, cx): rows cy ? {r 0 -> lr 2, r 2 -> lr 1} : {r 1 -> lr 1}, columns likewise; weight tap r * 3 + s
+      if (FUSE) load_x(n, y0, x0, 1, 1);
+      zero_acc();
+      tap_mfma(img, 2, 2, wf[0]);
+      tap_mfma(img, 2, 1, wf[2]);
+      tap_mfma(img, 1, 2, wf[6]);
+      tap_mfma(img, 1, 1, wf[8]);
+      epilogue(n, y0, x0, 1, 1);
+      if (FUSE) load_x(n, y0, x0, 1, 0);
+      zero_acc();
+      tap_mfma(img, 2, 1, wf[1]);
+      tap_mfma(img, 1, 1, wf[7]);
+      epilogue(n, y0, x0, 1, 0);
+      if (FUSE) load_x(n, y0, x0, 0, 1);
+      zero_acc();
+      tap_mfma(img, 1, 2, wf[3]);
+      tap_mfma(img, 1, 1, wf[5]);
+      epilogue(n, y0, x0, 0, 1);
+      if (FUSE) load_x(n, y0, x0, 0, 0);
+      zero_acc();
+      tap_mfma(img, 1, 1, wf[4]);
+      epilogue(n, y0, x0, 0, 0);
+    }
+  }
+
+  // ---- per-channel sums of this workgroup: the lanes that share a channel chunk (16 x the two pixel-row halves) meet in LDS
+  __syncthreads();
+  constexpr int NQ = MODE == 1 ? 2 : 3;
+  if (MODE == 1 ? (p.stats != nullptr) : FUSE) {
+    // MODE 1: [slot 32][2][64], slot = mg * 16 + l16 (the lanes that hold one channel quad); MODE 2: [slot 64][3][64],
+    // slot = mg * 32 + (q16 & 1) * 16 + l16 (the lanes that hold one 8-channel chunk after the swap)
+    constexpr int NS = MODE == 1 ? 32 : 64;
+    float* red = reinterpret_cast<float*>(smem);
+    MSML_LDS_REGION(red, NS * NQ * C * 4);
+    if (MODE == 1) {
+      const int slot = mg * 16 + l16;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        red[(slot * NQ + 0) * C + kg * 16 + 4 * q16 + j] = s1[j];
+        red[(slot * NQ + 1) * C + kg * 16 + 4 * q16 + j] = s2[j];
+      }
+    } else {
+      const int slot = mg * 32 + (q16 & 1) * 16 + l16;
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) red[(slot * NQ + q) * C + cch + j] = bq[q][j];
+    }
+    __syncthreads();
+    for (int i = t; i < NQ * C; i += 512) {
+      const int q = i / C, c = i % C;
+      float sum = 0.f;
+      for (int s = 0; s < NS; s++) sum += red[(s * NQ + q) * C + c];
+      if (MODE == 1) stats_emit(p.stats, 1, blockIdx.x, q, C, c, sum);
+      else bnb_emit(p.bnb.partial, 1, blockIdx.x, q, C, c, sum);
+    }
+  }
+#endif
+}
+
+static int s2r_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+  }
+  return n;
+}
+
+// 1 when k_conv_s2r takes the shape: 64 -> 64 channels, 3x3, stride 2, pad 1, even maps, enough real GEMM rows.
+int msml_conv_s2r_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
+                          int pad_w, int transposed) {
+  static const bool off = getenv("MSML_NO_S2R_CONV") != nullptr;
+  if (off || R != 3 || S != 3 || stride != 2 || pad_h != 1 || pad_w != 1 || c0p != 64 || coutp != 64 || kop < 64) return 0;
+  int gh, gw;
+  if (!transposed) { if ((H & 1) || (W & 1) || P != H / 2 || Q != W / 2) return 0; gh = P; gw = Q; }
+  else { if (P != 2 * H || Q != 2 * W) return 0; gh = H; gw = W; }
+  const long tiles = (long)N * cdiv(gh, 14) * cdiv(gw, 14);
+  if ((long)N * gh * gw * 10 < tiles * 224 * 7) return 0;
+  const long big = (long)N * (transposed ? P : H) * (transposed ? Q : W) * 64 * 2;
+  return big < 0x70000000L ? 1 : 0;
+}
+
+template <int MODE, bool FUSE>
+static void launch_s2r(ConvS2rArgs& a, hipStream_t st) {
+  const size_t img = (size_t)(MODE == 1 ? 4 : 2) * 256 * 128 + 1024;
+  size_t lds = img + (FUSE ? 5 * 64 * sizeof(float) : 0);
+  const size_t rlds = (size_t)64 * (MODE == 1 ? 2 : 3) * 64 * 4;
+  if (rlds > lds) lds = rlds;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_s2r<MODE, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  });
+  const int wgs = a.ntiles < s2r_num_cus() ? a.ntiles : s2r_num_cus();
+  k_conv_s2r<MODE, FUSE><<<dim3(wgs), dim3(512), lds, st>>>(a);
+}
+
+// Tried by msml_conv_fast_dispatch before the im2col kernel; false = shape / epilogue not covered here.
+bool msml_conv_s2r_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
+                            float* stats, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
+                            int transposed, hipStream_t st, const float* scale, const float* alpha, const void* residual,
+                            const BnBwdFuse* bnb, int* bnb_rows) {
+  if (!msml_conv_s2r_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed)) return false;
+  if (bias || scale || alpha || residual) return false;
+  if (stats && (!msml_tl_stats_acc || transposed)) return false;
+  if (bnb && (!bnb->acc || !transposed || stats)) return false;
+  ConvS2rArgs a;
+  a.in = (const unsigned short*)in0; a.in_bytes = (unsigned int)((long)N * H * W * 64 * 2);
+  a.N = N; a.IH = H; a.IW = W;
+  a.GH = transposed ? H : P; a.GW = transposed ? W : Q;
+  a.OH = P; a.OW = Q;
+  a.tpy = cdiv(a.GH, 14); a.tpx = cdiv(a.GW, 14); a.ntiles = N * a.tpy * a.tpx;
+  a.wp = (const unsigned short*)wp;
+  a.out = (unsigned short*)out; a.out_bytes = (unsigned int)((long)N * P * Q * 64 * 2);
+  a.stats = stats;
+  a.bnb = BnBwdFuse{};
+  if (bnb) a.bnb = *bnb;
+  if (bnb_rows) *bnb_rows = a.ntiles < s2r_num_cus() ? a.ntiles : s2r_num_cus();
+  if (!transposed) launch_s2r<1, false>(a, st);
+  else if (bnb) launch_s2r<2, true>(a, st);
+  else launch_s2r<2, false>(a, st);
+  return true;
+}

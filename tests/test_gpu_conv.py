@@ -1070,3 +1070,53 @@ def test_conv_halo2_stride2_and_mosaic(shape):
     xh = (xf - coef[2]) * coef[3]
     want = torch.stack((gg.sum(0), (gg * xh).sum(0), (gq * torch.clamp(z, max=0)).sum(0))).double()
     assert torch.allclose(acc.sum(0), want, rtol=2e-3, atol=2e-3 * want.abs().max().item())
+
+
+# conv_s2r.hip: 64 -> 64 channel stride-2 3x3 layers with the weights in registers (N, H): one tile per workgroup, more
+# tiles than workgroups (persistent loop, counted waits across tiles), ragged tiles (13 x 13 outputs), the OSB's 56 -> 28
+@pytest.mark.parametrize("shape", [(6, 56), (20, 112), (5, 28), (4, 26), (70, 56)])
+def test_conv_s2r_64_channel_stride2(shape):
+    """k_conv_s2r: forward + accumulator-mode statistics, backward-data, backward-data with the fused BatchNorm backward
+    sums, against f64 torch on the same bf16-rounded operands (backbones/frb/iresnet.py:56-67, layer1's stride-2 conv2)."""
+    n, h = shape
+    c = 64
+    g = torch.Generator().manual_seed(n * 131 + h)
+    x = torch.randn(n, c, h, h, generator=g).bfloat16().float()
+    w = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5).bfloat16().float()
+    ho = h // 2
+    name = _lib.value("msml_conv2d_kernel", c, 0, c, n, h, h, ho, ho, 3, 3, 2, 1, 1, 0, _lib.BF16, _lib.BF16, 1).decode()
+    assert "k_conv_s2r" in name, name
+    xd = x.double().requires_grad_(True)
+    ref = F.conv2d(xd, w.double(), None, 2, 1)
+    out, stats = run_conv(x, None, w, None, 2, 1, 1, _lib.BF16)
+    got = ops.to_nchw(out, c).cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref.float()).abs().max().item() <= 1.5e-2 * scale
+    assert stats.dtype == torch.float64
+    ssum = stats.sum(0).float().cpu()
+    assert torch.allclose(ssum[0], ref.float().sum((0, 2, 3)), rtol=0, atol=1.5e-2 * scale * ref[:, 0].numel() ** 0.5)
+    assert torch.allclose(ssum[1], (ref.float() ** 2).sum((0, 2, 3)), rtol=2e-2)
+    dy = torch.randn(ref.shape, generator=g).bfloat16().float()
+    ref.backward(dy.double())
+    wpt = ops.pack_weight(w.cuda(), True, c, 0, _lib.BF16)
+    dyd = ops.to_nhwc(dy.cuda(), _lib.BF16)
+    name = _lib.value("msml_conv2d_kernel", c, 0, c, n, ho, ho, h, h, 3, 3, 2, 1, 1, 1, _lib.BF16, _lib.BF16, 0).decode()
+    assert "k_conv_s2r" in name, name
+    dx, _ = ops.conv2d(dyd, None, wpt, None, c, 3, 3, 2, 1, 1, True, p=h, q=h)
+    gx = ops.to_nchw(dx, c).cpu().double()
+    assert (gx - xd.grad).abs().max().item() <= 1.5e-2 * xd.grad.abs().max().item()
+    bnx = torch.randn(n, h, h, c, generator=g).bfloat16().cuda()
+    coef = (torch.rand(4, c, generator=g) + 0.5).cuda()
+    for alpha in (None, torch.full((c,), 0.25, device="cuda")):
+        r2 = ops.conv_dgrad_bnbwd(dyd, wpt, c, 3, 3, 2, 1, 1, h, h, bnx, coef, alpha)
+        assert r2 is not None
+        dx2, acc = r2
+        assert torch.equal(dx2, dx)
+        gq = dx2.float().reshape(-1, c)
+        xf = bnx.float().reshape(-1, c)
+        z = xf * coef[0] + coef[1]
+        neg = (z <= 0) if alpha is not None else torch.zeros_like(z, dtype=torch.bool)
+        gg = torch.where(neg, gq * 0.25, gq)
+        xh = (xf - coef[2]) * coef[3]
+        want = torch.stack((gg.sum(0), (gg * xh).sum(0), torch.where(neg, gq * z, torch.zeros_like(z)).sum(0))).double()
+        assert torch.allclose(acc.sum(0), want, rtol=2e-3, atol=2e-3 * want.abs().max().item())
