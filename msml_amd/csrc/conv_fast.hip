@@ -633,6 +633,11 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
     if (bnb_rows) *bnb_rows = 1;
     return true;
   }
+  // (64 -> 64 stride-1 forward / plain backward-data: the register-weights kernel first, conv_s2r.hip)
+  if (stride == 1 && !in1 && !bnb && out_dtype == MSML_BF16 &&
+      msml_conv_s2r_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed,
+                             st, scale, alpha, residual, bnb, bnb_rows))
+    return true;
   if (!in1 && out_dtype == MSML_BF16 &&
       msml_conv_ws_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h,
                             pad_w, transposed, st, scale, alpha, residual, res_first, bnb, bnb_rows))

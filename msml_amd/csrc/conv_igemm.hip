@@ -688,7 +688,7 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
     return "k_conv_line<full lines in LDS, weights resident, persistent>";
   if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
       msml_conv_ws_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
-    return "k_conv_ws<64 -> 64 channels, weights resident, persistent>";
+    return "k_conv_ws<64 -> 64 channels, weights resident, persistent>";    // (or k_conv_s2r<stride 1> without fused sums / residual)
   if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
       msml_conv_halo_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
     return coutp % 256 == 0 ? "k_conv_halo<14x14 px x 256 ch, 8 waves>" : "k_conv_halo<14x14 px x 128 ch, 8 waves>";

@@ -35,6 +35,7 @@ struct ConvS2rArgs {
   unsigned int out_bytes;
   float* stats;       // MODE 1: accumulator double[MSML_ACC_ROWS][2][64] or nullptr
   BnBwdFuse bnb;      // MODE 2 + FUSE (accumulator mode)
+  int flip;           // MODE 0 backward-data
 };
 
 #define S2R_OOB 0x78000000u
@@ -133,30 +134,40 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   float bq[3][8];
 #pragma unroll
   for (int j = 0; j < 8; j++) bq[0][j] = bq[1][j] = bq[2][j] = 0.f;
-  // element offset of the output pixel of GEMM row m of (tile origin n, y0, x0), class (cy, cx); negative = no pixel
-  auto out_pix = [&](int n, int y0, int x0, int m, int cy, int cx) -> long {
-    const int my = m >> 4, mx = m & 15;
-    int gy = y0 + my, gx = x0 + mx;
-    if (!((mx < 14) & (gx < p.GW) & (gy < p.GH))) return -1;
-    if (MODE == 2) { gy = 2 * gy + cy; gx = 2 * gx + cx; }
-    return ((long)(n * p.OH + gy) * p.OW + gx) * C;
-  };
-  u32x4 xr[4];
-  auto load_x = [&](int n, int y0, int x0, int cy, int cx) {     // FUSE: saved BatchNorm input in the store layout
-#pragma unroll
-    for (int pr = 0; pr < 4; pr++) {
-      const int m = (mg * 7 + 2 * pr + (q16 & 1)) * 16 + l16;
-      const long o = (2 * pr + (q16 & 1) < 7) ? out_pix(n, y0, x0, m, cy, cx) : -1;
-      xr[pr] = o >= 0 ? *reinterpret_cast<const u32x4*>(p.bnb.x + o + cch) : u32x4{0, 0, 0, 0};
+  // Output addressing of a tile (n, y0, x0) and class (cy, cx): GEMM row group g = mg * 7 + j is image row y0 + g, the lane's
+  // pixel column x0 + l16 (columns 14, 15 of the pitch are padding); 32-bit element offsets (tensors < 2^31 bytes), the
+  // tile-constant part in scalars.  After the pair swap a lane stores group 2 pr + (q16 & 1).
+  int t_rows = 0;                                      // image rows of this tile that exist
+  bool t_col = false;                                  // this lane's pixel column exists
+  unsigned int t_base = 0, t_rowstep = 0;              // element offset of (group 0, this lane's pixel), elements per group
+  auto set_tile = [&](int n, int y0, int x0, int cy, int cx) {
+    t_rows = p.GH - y0;
+    t_col = (l16 < 14) & (x0 + l16 < p.GW);
+    if (MODE == 2) {
+      t_base = (unsigned int)((n * p.OH + 2 * y0 + cy) * p.OW + 2 * (x0 + l16) + cx) * C;
+      t_rowstep = (unsigned int)(2 * p.OW * C);
+    } else {
+      t_base = (unsigned int)((n * p.OH + y0) * p.OW + x0 + l16) * C;
+      t_rowstep = (unsigned int)(p.OW * C);
     }
   };
-  auto epilogue = [&](int n, int y0, int x0, int cy, int cx) {
+  auto grp_ok = [&](int g) { return t_col & (g < t_rows) & (g < 14); };
+  u32x4 xr[4];
+  auto load_x = [&]() {                                // FUSE: saved BatchNorm input in the store layout (after set_tile)
+#pragma unroll
+    for (int pr = 0; pr < 4; pr++) {
+      const int g = mg * 7 + 2 * pr + (q16 & 1);
+      const bool ok = (2 * pr + (q16 & 1) < 7) & grp_ok(g);
+      xr[pr] = ok ? *reinterpret_cast<const u32x4*>(p.bnb.x + t_base + g * t_rowstep + cch) : u32x4{0, 0, 0, 0};
+    }
+  };
+  auto epilogue = [&]() {
     u32x2 pk[8];
 #pragma unroll
     for (int j = 0; j < 7; j++) {
       pk[j][0] = (unsigned int)f2bf(acc[j][0]) | ((unsigned int)f2bf(acc[j][1]) << 16);
       pk[j][1] = (unsigned int)f2bf(acc[j][2]) | ((unsigned int)f2bf(acc[j][3]) << 16);
-      if (MODE == 1 && p.stats && out_pix(n, y0, x0, (mg * 7 + j) * 16 + l16, 0, 0) >= 0) {
+      if (MODE != 2 && !FUSE && p.stats && grp_ok(mg * 7 + j)) {
         s1 += acc[j];
         s2 += acc[j] * acc[j];
       }
@@ -178,15 +189,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         auto sw = __builtin_amdgcn_permlane16_swap(pk[2 * pr][e], pk[2 * pr + 1][e], false, false);
         o16[e] = sw[0]; o16[2 + e] = sw[1];
       }
-      const int grp = 2 * pr + (q16 & 1);
-      const int m = (mg * 7 + grp) * 16 + l16;
-      const long o = grp < 7 ? out_pix(n, y0, x0, m, cy, cx) : -1;
+      const int g = mg * 7 + 2 * pr + (q16 & 1);
+      const bool ok = (2 * pr + (q16 & 1) < 7) & grp_ok(g);
       // (buffer store: an out-of-range offset drops it)
-      __builtin_amdgcn_raw_buffer_store_b128(o16, rs_out, o >= 0 ? (unsigned int)((o + cch) * 2) : S2R_OOB, 0, 0);
-      if (o >= 0) {
-        const Vec8 v = load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16));
-        if (FUSE) bnb_accum(bk, p.bnb.alpha != nullptr, v, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[pr])), bq);
-      }
+      __builtin_amdgcn_raw_buffer_store_b128(o16, rs_out, ok ? (t_base + g * t_rowstep + cch) * 2u : S2R_OOB, 0, 0);
+      if (FUSE && ok)
+        bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16)),
+                  load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[pr])), bq);
     }
   };
 
@@ -242,7 +251,31 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       __builtin_amdgcn_s_barrier();
       issue_img(nxt, po[1], 1);
       tap_mfma(As, 1, 1, wf[4]);
-      epilogue(n, y0, x0, 0, 0);
+      set_tile(n, y0, x0, 0, 0);
+      epilogue();
+    }
+  } else if constexpr (MODE == 0) {
+    // ---------------- stride 1 (the contract of conv_ws.hip): nine taps of one image, next tile's image one tile ahead
+    int tile = blockIdx.x, it = 0;
+    issue_img(tile, 0, 0);
+    for (; tile < p.ntiles; tile += gridDim.x, it++) {
+      const int cur = it & 1;
+      const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+      const int y0 = ty * 14, x0 = (trem - ty * p.tpx) * 14;
+      __syncthreads();
+      issue_img(tile + gridDim.x, 0, cur ^ 1);
+      const char* img = As + cur * ABYTES;
+      set_tile(n, y0, x0, 0, 0);
+      if (FUSE) load_x();
+      zero_acc();
+      if (p.flip) {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) tap_mfma(img, 2 - tap / 3, 2 - tap % 3, wf[tap]);
+      } else {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) tap_mfma(img, tap / 3, tap % 3, wf[tap]);
+      }
+      epilogue();
     }
   } else {
     // ---------------- backward-data: a dY tile serves the four output classes; next tile's image one tile ahead ---
@@ -256,40 +289,45 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       issue_img(tile + gridDim.x, 0, cur ^ 1);         // buffer was read last in the previous iteration
       const char* img = As + cur * ABYTES;
       // class (cy, cx): rows cy ? {r 0 -> lr 2, r 2 -> lr 1} : {r 1 -> lr 1}, columns likewise; weight tap r * 3 + s
-      if (FUSE) load_x(n, y0, x0, 1, 1);
+      set_tile(n, y0, x0, 1, 1);
+      if (FUSE) load_x();
       zero_acc();
       tap_mfma(img, 2, 2, wf[0]);
       tap_mfma(img, 2, 1, wf[2]);
       tap_mfma(img, 1, 2, wf[6]);
       tap_mfma(img, 1, 1, wf[8]);
-      epilogue(n, y0, x0, 1, 1);
-      if (FUSE) load_x(n, y0, x0, 1, 0);
+      epilogue();
+      set_tile(n, y0, x0, 1, 0);
+      if (FUSE) load_x();
       zero_acc();
       tap_mfma(img, 2, 1, wf[1]);
       tap_mfma(img, 1, 1, wf[7]);
-      epilogue(n, y0, x0, 1, 0);
-      if (FUSE) load_x(n, y0, x0, 0, 1);
+      epilogue();
+      set_tile(n, y0, x0, 0, 1);
+      if (FUSE) load_x();
       zero_acc();
       tap_mfma(img, 1, 2, wf[3]);
       tap_mfma(img, 1, 1, wf[5]);
-      epilogue(n, y0, x0, 0, 1);
-      if (FUSE) load_x(n, y0, x0, 0, 0);
+      epilogue();
+      set_tile(n, y0, x0, 0, 0);
+      if (FUSE) load_x();
       zero_acc();
       tap_mfma(img, 1, 1, wf[4]);
-      epilogue(n, y0, x0, 0, 0);
+      epilogue();
     }
   }
 
   // ---- per-channel sums of this workgroup: the lanes that share a channel chunk (16 x the two pixel-row halves) meet in LDS
   __syncthreads();
-  constexpr int NQ = MODE == 1 ? 2 : 3;
-  if (MODE == 1 ? (p.stats != nullptr) : FUSE) {
+  constexpr bool STATS = MODE != 2 && !FUSE;
+  constexpr int NQ = STATS ? 2 : 3;
+  if (STATS ? (p.stats != nullptr) : FUSE) {
     // MODE 1: [slot 32][2][64], slot = mg * 16 + l16 (the lanes that hold one channel quad); MODE 2: [slot 64][3][64],
     // slot = mg * 32 + (q16 & 1) * 16 + l16 (the lanes that hold one 8-channel chunk after the swap)
-    constexpr int NS = MODE == 1 ? 32 : 64;
+    constexpr int NS = STATS ? 32 : 64;
     float* red = reinterpret_cast<float*>(smem);
     MSML_LDS_REGION(red, NS * NQ * C * 4);
-    if (MODE == 1) {
+    if (STATS) {
       const int slot = mg * 16 + l16;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -308,7 +346,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       const int q = i / C, c = i % C;
       float sum = 0.f;
       for (int s = 0; s < NS; s++) sum += red[(s * NQ + q) * C + c];
-      if (MODE == 1) stats_emit(p.stats, 1, blockIdx.x, q, C, c, sum);
+      if (STATS) stats_emit(p.stats, 1, blockIdx.x, q, C, c, sum);
       else bnb_emit(p.bnb.partial, 1, blockIdx.x, q, C, c, sum);
     }
   }
@@ -329,9 +367,16 @@ static int s2r_num_cus() {
 int msml_conv_s2r_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
                           int pad_w, int transposed) {
   static const bool off = getenv("MSML_NO_S2R_CONV") != nullptr;
-  if (off || R != 3 || S != 3 || stride != 2 || pad_h != 1 || pad_w != 1 || c0p != 64 || coutp != 64 || kop < 64) return 0;
+  if (off || R != 3 || S != 3 || pad_h != 1 || pad_w != 1 || c0p != 64 || coutp != 64 || kop < 64) return 0;
+  // stride 1 (the layers of conv_ws.hip): forward + statistics and plain backward-data measured faster here (round 5, one box:
+  // 64 -> 64 @ 112x112 389 -> 350 us, @ 56x56 87 -> 81 us; backward-data 350 -> 312 / 83 -> 71 us), the fused-BatchNorm
+  // backward-data slower (92.6 -> 100.7 us: 16-channel waves touch 32 B per pixel) -- the dispatcher keeps that one on
+  // k_conv_ws.  MSML_NO_S2R_STRIDE1=1: stride-2 layers only.
+  static const bool s1 = getenv("MSML_NO_S2R_STRIDE1") == nullptr;
+  if (stride != 2 && !(stride == 1 && s1)) return 0;
   int gh, gw;
-  if (!transposed) { if ((H & 1) || (W & 1) || P != H / 2 || Q != W / 2) return 0; gh = P; gw = Q; }
+  if (stride == 1) { if (P != H || Q != W) return 0; gh = H; gw = W; }
+  else if (!transposed) { if ((H & 1) || (W & 1) || P != H / 2 || Q != W / 2) return 0; gh = P; gw = Q; }
   else { if (P != 2 * H || Q != 2 * W) return 0; gh = H; gw = W; }
   const long tiles = (long)N * cdiv(gh, 14) * cdiv(gw, 14);
   if ((long)N * gh * gw * 10 < tiles * 224 * 7) return 0;
@@ -361,12 +406,14 @@ bool msml_conv_s2r_dispatch(const void* in0, int c0p, const void* wp, int kop, c
                             const BnBwdFuse* bnb, int* bnb_rows) {
   if (!msml_conv_s2r_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed)) return false;
   if (bias || scale || alpha || residual) return false;
-  if (stats && (!msml_tl_stats_acc || transposed)) return false;
+  if (stride == 1 && bnb) return false;                 // (see msml_conv_s2r_applies)
+  if (stats && (!msml_tl_stats_acc || (transposed && stride == 2))) return false;
   if (bnb && (!bnb->acc || !transposed || stats)) return false;
   ConvS2rArgs a;
   a.in = (const unsigned short*)in0; a.in_bytes = (unsigned int)((long)N * H * W * 64 * 2);
   a.N = N; a.IH = H; a.IW = W;
-  a.GH = transposed ? H : P; a.GW = transposed ? W : Q;
+  a.GH = (transposed || stride == 1) ? H : P; a.GW = (transposed || stride == 1) ? W : Q;
+  a.flip = transposed;
   a.OH = P; a.OW = Q;
   a.tpy = cdiv(a.GH, 14); a.tpx = cdiv(a.GW, 14); a.ntiles = N * a.tpy * a.tpx;
   a.wp = (const unsigned short*)wp;
@@ -375,7 +422,8 @@ bool msml_conv_s2r_dispatch(const void* in0, int c0p, const void* wp, int kop, c
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
   if (bnb_rows) *bnb_rows = a.ntiles < s2r_num_cus() ? a.ntiles : s2r_num_cus();
-  if (!transposed) launch_s2r<1, false>(a, st);
+  if (stride == 1) { if (bnb) launch_s2r<0, true>(a, st); else launch_s2r<0, false>(a, st); }
+  else if (!transposed) launch_s2r<1, false>(a, st);
   else if (bnb) launch_s2r<2, true>(a, st);
   else launch_s2r<2, false>(a, st);
   return true;
