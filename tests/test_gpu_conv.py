@@ -823,7 +823,9 @@ def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     assert torch.equal(rm_b, rm_a) and torch.equal(rv_b, rv_a)
     # (64 channels: the two-launch side's conv runs on k_conv_s2r, the fused one on k_conv_ws -- identical outputs, but the
     # f32 per-workgroup partial sums of the statistics are cut differently before they meet in f64)
-    assert torch.allclose(st_b.sum(0), st_a.sum(0), rtol=1e-12 if cin != 64 else 1e-6, atol=0)
+    sa, sb = st_a.sum(0), st_b.sum(0)
+    assert torch.allclose(sb, sa, rtol=1e-12, atol=0) if cin != 64 else \
+        torch.allclose(sb, sa, rtol=1e-6, atol=1e-6 * sa.abs().max().item())
 
 
 @pytest.mark.parametrize("with_alpha", [False, True])
