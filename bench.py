@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # MI355X_MICROARCH.md (dense)
-ROUND = "r04"                                     # PMC summaries of OTHER rounds are never quoted (kernels change)
+ROUND = "r05"                                     # PMC summaries of OTHER rounds are never quoted (kernels change)
 # forward GFLOP per image (hooks on the imported reference); F_train = 3 x F_fwd (section 3)
 F_FWD_GF = {"iresnet18": 8.446, "iresnet34": 12.146, "iresnet50": 15.845, "iresnet100": 27.406}
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
@@ -41,8 +41,11 @@ JSON_OUT = None                                   # the process's real stdout (m
 # device copy, and `value_normalised` rescales the headline to a reference box: every kernel family's share of the step's
 # kernel time (from the same run's `kernels` table) is scaled by the ratio of ITS yardstick to the reference constants below.
 # The constants are arbitrary but fixed (the first box of round 5): only ratios between runs mean anything.
-REF_MFMA_TFLOPS = 1400.0
-REF_COPY_TBS = 5.20
+REF_MFMA_LDS_TFLOPS = 1640.0
+REF_COPY_TBS = 4.50
+# how much of a probe's box-to-box difference the step's MFMA families show: their kernels wait on LDS / L2 / HBM as well as on
+# the matrix clock (fitted on this round's boxes; 1.0 would be a purely clock-bound step)
+MFMA_EXP = 0.5
 MFMA_FAMILIES = ("conv_igemm", "conv_wgrad", "gemm_splitk", "conv_x3", "conv_fused")
 
 
@@ -95,13 +98,14 @@ def calibrate():
 
 def normalise(value, calib, kernels):
     """value x (what this box costs relative to the reference box): the MFMA families' share of the kernel time scales with
-    REF_MFMA / probe, everything else (BatchNorm / element-wise / optimizer: HBM-bound) with REF_COPY / probe."""
+    (REF_MFMA_LDS / LDS-fed probe) ^ MFMA_EXP, everything else (BatchNorm / element-wise / optimizer: HBM-bound) with
+    REF_COPY / copy probe."""
     share = 0.76                                       # (round-4 family table; used when the run has no kernel events)
     if kernels:
         tot = sum(v["ms_per_step"] for v in kernels.values())
         if tot > 0:
             share = sum(v["ms_per_step"] for k, v in kernels.items() if k in MFMA_FAMILIES) / tot
-    slow = share * REF_MFMA_TFLOPS / calib["mfma_tflops"] + (1.0 - share) * REF_COPY_TBS / calib["copy_tbs"]
+    slow = share * (REF_MFMA_LDS_TFLOPS / calib["mfma_lds_tflops"]) ** MFMA_EXP + (1.0 - share) * REF_COPY_TBS / calib["copy_tbs"]
     return value * slow, share
 
 
@@ -854,11 +858,13 @@ def main():
         vn, share = normalise(value, calib, rec.get("kernels"))
         sc = [v for v in sclk if v is not None]
         calib.update({"sclk_mhz_avg": round(sum(sc) / len(sc), 1) if sc else None,
-                      "ref_mfma_tflops": REF_MFMA_TFLOPS, "ref_copy_tbs": REF_COPY_TBS, "mfma_share_of_kernel_time": round(share, 4),
+                      "ref_mfma_lds_tflops": REF_MFMA_LDS_TFLOPS, "ref_copy_tbs": REF_COPY_TBS, "mfma_exponent": MFMA_EXP,
+                      "mfma_share_of_kernel_time": round(share, 4),
                       "method": "msml_probe_mfma: 512 WGs x 4 waves x 20000 x 16 register-resident v_mfma_f32_16x16x32_bf16 on random "
                                 "operands, median of 15 launches after 12; copy: torch copy_ of 512 MiB (read + write), median of 9; "
-                                "both on the training stream right before the timed region; value_normalised = value x (share x "
-                                "ref_mfma / mfma + (1 - share) x ref_copy / copy), share = MFMA families' part of the kernel-event time"})
+                                "msml_probe_mfma_lds: 256 WGs x 8 waves, 9 ds_read_b128 per 14 MFMAs; all on the training stream right before the "
+                                "timed region; value_normalised = value x (share x (ref_mfma_lds / mfma_lds) ^ mfma_exponent + (1 - share) x "
+                                "ref_copy / copy), share = MFMA families' part of the kernel-event time"})
         rec["calibration"] = calib
         rec["value_normalised"] = round(vn, 2)
     if world == 1 and not args.no_extra_modes and args.mode == "train" and args.dtype == "bf16":
