@@ -30,7 +30,7 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(s["achieved"] - d["value"] * 47.535 / 1e3) < 0.5 and abs(s["frac"] - s["achieved"] / 2500.0) < 1e-3
     # round 5: box calibration measured in the same run, the normalised headline, both dominant labels on the line
     c = d["calibration"]
-    for k in ("mfma_tflops", "mfma_lds_tflops", "copy_tbs", "ref_mfma_lds_tflops", "ref_copy_tbs", "mfma_share_of_kernel_time",
+    for k in ("mfma_tflops", "mfma_lds_tflops", "copy_tbs", "ref_mfma_lds_tflops", "mfma_exponent", "mfma_share_of_kernel_time",
               "method"):
         assert k in c, k
     assert 300.0 < c["mfma_lds_tflops"] < 2500.0 and 1.0 < c["copy_tbs"] < 8.0 and 0.5 < c["mfma_share_of_kernel_time"] < 0.9
@@ -53,7 +53,7 @@ def test_normalised_headline_spreads_less_than_the_raw_one_across_boxes():
     nrm = [bench.normalise(d["value"], d["calibration"], d["kernels"])[0] for d in ds]
     spread = lambda v: (max(v) - min(v)) / (sum(v) / len(v))      # noqa: E731
     assert spread(nrm) < spread(raw), (raw, nrm)
-    assert spread(nrm) < 0.025, (raw, nrm)
+    assert spread(nrm) < 0.02, (raw, nrm)              # (+-1 %)
 
 
 def test_pmc_summary_of_the_round_is_keyed_by_bench_labels():
