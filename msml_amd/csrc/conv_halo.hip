@@ -256,7 +256,14 @@ k_conv_halo(const ConvHaloArgs p) {
     }
 #endif
     // (the image chunks requested one stage ago have landed for this wave: the wait above)
+    // (round 5: waves 4-7, the SIMD partners of 0-3, transform one tap later -- one wave's VALU beside the other's MFMAs;
+    // bit-identical, 128 @ 28x28 bn + conv 103.6 -> 101.8 us, the step 29.41 / 29.50 -> 29.36 / 29.39 ms on one box.
+    // -DHALO_XF_NO_STAGGER: all eight waves at tap 1)
+#ifdef HALO_XF_NO_STAGGER
     if ((XF || XB) && tr == 0 && ts == 1 && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
+#else
+    if ((XF || XB) && tr == 0 && ts == (wave < 4 ? 1 : 2) && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef HALO_ABLATE_COMPUTE
     const int r = p.flip ? 2 - tr : tr, s = p.flip ? 2 - ts : ts;
