@@ -340,6 +340,10 @@ bool msml_wgrad_fast_launch_group(const void* const* u, int up, const void* cons
 
 int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
                            int stride, int pad_h, int pad_w);
+int msml_wgrad_halo_s2_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                              int pad_h, int pad_w);
+bool msml_wgrad_halo_s2_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W, int P, int Q,
+                               int splits, hipStream_t st);
 bool msml_wgrad_halo_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W,
                             int splits, hipStream_t st, const BnIn* xin = nullptr);
 int msml_wgrad_halo_group_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S,
@@ -467,6 +471,14 @@ extern "C" int msml_conv_wgrad(const void* u, int up, const void* v, int vp, flo
     if (ls > 0 && msml_wgrad_line_launch(u, v, vp, a.ws, N, H, R, ls, st)) {
       MSML_LAUNCH_OK("conv_wgrad(line)");
       wgrad_reduce_launch(a.ws, dw, ls, up, taps, vp, A, Breal, Btot, boff, accumulate, st);
+      MSML_LAUNCH_OK("conv_wgrad_reduce");
+      return MSML_OK;
+    }
+    const int hs2 = msml_wgrad_halo_s2_splits(up, vp, A, Breal, N, H, W, P, Q, R, S, stride, pad_h, pad_w);
+    if (hs2 > 0 && (long)hs2 * up * taps * vp * (long)sizeof(float) <= (long)ws_bytes &&
+        msml_wgrad_halo_s2_launch(u, up, v, vp, a.ws, N, H, W, P, Q, hs2, st)) {
+      MSML_LAUNCH_OK("conv_wgrad(halo, stride 2)");
+      wgrad_reduce_launch(a.ws, dw, hs2, up, taps, vp, A, Breal, Btot, boff, accumulate, st);
       MSML_LAUNCH_OK("conv_wgrad_reduce");
       return MSML_OK;
     }

@@ -34,7 +34,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 struct WgradHaloArgs {
   const unsigned short* u[WH_MAXGROUP]; int up; unsigned int u_bytes;     // dY [N][H][W][up], one per grouped layer
   const unsigned short* v[WH_MAXGROUP]; int vp; unsigned int v_bytes;     // X  [N][H][W][vp]
-  int N, H, W, spy, spx;      // strips per image column / row (7 rows x 14 columns each)
+  int N, H, W, spy, spx;      // dY map; strips per image column / row (7 rows x 14 columns each)
+  int XH, XW;                 // S2: the conv input map (2 H x 2 W); otherwise = H, W
   int nstrips, chunk;         // total strips, strips per split
   int zper;                   // splits per layer: grid.z = layers x zper, z = layer * zper + split
   int remap;                  // 1: XCD-aware workgroup order (all dW tiles of one z on one XCD's L2)
@@ -47,11 +48,17 @@ struct WgradHaloArgs {
 // XF: the conv input X is a BatchNorm(+PReLU) of the stored tensor v; the strips are normalised in LDS
 // P7: 7 x 7 maps, a strip = two images side by side (issue()); compile-time, the 128-row instantiation has no register
 // to spare (a run-time switch spilled three dwords: 940 -> 595 TFLOP/s on the 14 x 14 layers)
-template <int CO, bool XF = false, bool P7 = false>
+// S2 (round 5): stride-2 convs (conv2 of the first block of a stage, backbones/frb/iresnet.py:56-67 with stride 2): the X
+// strip is held as its four PARITY PLANES X(2i + py, 2j + px), each 8 rows x 16 pixels x 2 channel groups around the dY
+// strip (halo origin -1); tap (r, s) reads plane ((r != 1), (s != 1)) at row offset (r != 0), column offset (s != 0) -- a
+// per-tap constant like the stride-1 shifts, the MFMA loop is unchanged.  64 KB of X per strip: 64-row tiles only (LDS).
+template <int CO, bool XF = false, bool P7 = false, bool S2 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wgrad_halo(const WgradHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int GU = CO / 32, NI = CO / 64, UBLK = 7 * GU, NBLK = UBLK + 20, NISS = (NBLK + 7) / 8;
-  constexpr int UB = UBLK * 1024, VB = 10 * 2 * 1024, STAGE = UB + VB;    // dY strip, X strip + halo (+ 1 row)
+  static_assert(!S2 || (CO == 64 && !XF && !P7), "the stride-2 strips come with 64-row tiles, no input transform");
+  constexpr int NXB = S2 ? 4 * 8 * 2 : 20;             // X blocks of 1 KB per strip
+  constexpr int GU = CO / 32, NI = CO / 64, UBLK = 7 * GU, NBLK = UBLK + NXB, NISS = (NBLK + 7) / 8;
+  constexpr int UB = UBLK * 1024, VB = NXB * 1024, STAGE = UB + VB;      // dY strip, X strip + halo (+ 1 row)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   MSML_LDS_REGION(smem, 2 * STAGE + (XF ? 3 * 64 * 4 : 0));
   const int t = threadIdx.x, lane = t & 63;
@@ -120,8 +127,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int y0 = sy * 7, x0 = (rem - sy * p.spx) * 14;
 #pragma unroll
     for (int i = 0; i < NISS; i++) {
-      const int blk = wave + 8 * i;                    // 7 GU dY blocks, then 20 X blocks
+      const int blk = wave + 8 * i;                    // 7 GU dY blocks, then 20 X blocks (S2: 4 planes x 8 rows x 2 groups)
       if (blk >= NBLK) break;
+      if (S2 && blk >= UBLK) {
+        const int bb = blk - UBLK, plane = bb >> 4, hr = (bb >> 1) & 7, g = bb & 1;
+        const int y = 2 * (y0 + hr - 1) + (plane >> 1), x = 2 * (x0 + lp - 1) + (plane & 1);
+        const bool ok = ((unsigned)y < (unsigned)p.XH) & ((unsigned)x < (unsigned)p.XW);
+        const unsigned int off = ok ? (unsigned int)((n * p.XH + y) * p.XW + x) * (unsigned int)(p.vp * 2) +
+                                          (unsigned int)(b0 + g * 32 + lc * 8) * 2u
+                                    : WH_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lptr_t)(vb + bb * 1024), 16, off, 0, 0, 0);
+        continue;
+      }
       if (blk < UBLK) {
         const int j = blk / GU, g = blk % GU;
         const int y = y0 + j, x = x0 + lp;
@@ -190,8 +207,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
   for (int k = 0; k < 5; k++) {
     const int tp = tap0 + k, r = tp / 3, sft = tp - r * 3;
-    vlok[k] = r * 2048 + (sft == 0 ? vlo[0] : (sft == 1 ? vlo[1] : vlo[2]));
-    vhik[k] = r * 2048 + (sft == 0 ? vhi[0] : (sft == 1 ? vhi[1] : vhi[2]));
+    if (S2) {
+      const int plane = (r != 1) * 2 + (sft != 1), lr = r != 0, ls = sft != 0;
+      vlok[k] = plane * 16384 + lr * 2048 + (ls ? vlo[1] : vlo[0]);
+      vhik[k] = plane * 16384 + lr * 2048 + (ls ? vhi[1] : vhi[0]);
+    } else {
+      vlok[k] = r * 2048 + (sft == 0 ? vlo[0] : (sft == 1 ? vlo[1] : vlo[2]));
+      vhik[k] = r * 2048 + (sft == 0 ? vhi[0] : (sft == 1 ? vhi[1] : vhi[2]));
+    }
   }
   typedef __attribute__((address_space(3))) s16x4* tr_ptr;
   auto tr2 = [&](const char* lo, const char* hi) -> s16x8 {
@@ -320,16 +343,59 @@ int msml_wgrad_halo_splits(int up, int vp, int A, int Breal, int N, int H, int W
   return (int)splits;
 }
 
-template <int CO, bool XF, bool P7 = false>
+template <int CO, bool XF, bool P7 = false, bool S2 = false>
 static void wh_launch(const WgradHaloArgs& a, dim3 grid, hipStream_t st) {
-  // two stages of (7 dY row blocks per 32 Cout + 10 X rows x 2 channel groups) KB (+ coefficient table)
-  const size_t lds = 2 * (7 * (CO / 32) + 10 * 2) * 1024 + (XF ? 3 * 64 * sizeof(float) : 0);
+  // two stages of (7 dY row blocks per 32 Cout + 10 X rows x 2 channel groups [S2: 4 planes x 8 rows x 2]) KB (+ coefficient table)
+  const size_t lds = 2 * (7 * (CO / 32) + (S2 ? 64 : 10 * 2)) * 1024 + (XF ? 3 * 64 * sizeof(float) : 0);
   static std::once_flag attr_once;                     // (per template instantiation; launches come from
   std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<CO, XF, P7>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_halo<CO, XF, P7, S2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  k_wgrad_halo<CO, XF, P7><<<grid, dim3(512), lds, st>>>(a);
+  k_wgrad_halo<CO, XF, P7, S2><<<grid, dim3(512), lds, st>>>(a);
+}
+
+// Stride-2 3x3 / pad-1 weight gradient on the strip kernel (S2): splits (0 = shape not covered).  (H, W) = the conv input,
+// (P, Q) = dY.
+int msml_wgrad_halo_s2_splits(int up, int vp, int A, int Breal, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                              int pad_h, int pad_w) {
+  // Measured (round 5, tools/bench_conv.py --only wgrad, batch 256): NOT faster than the im2col kernel -- 64 @ 112 152 vs 153 us,
+  // 128 @ 56 136 vs 124, 256 @ 28 110 vs 121: the four X planes are 64 KB of LDS fill per strip against 34 KB at stride 1, and
+  // only 64-row tiles fit.  Opt-in (read per call, so that a test can switch it on): MSML_HALO_WGRAD_S2=1.
+  if (getenv("MSML_NO_HALO_WGRAD") != nullptr || getenv("MSML_HALO_WGRAD_S2") == nullptr) return 0;
+  if (R != 3 || S != 3 || stride != 2 || pad_h != 1 || pad_w != 1 || (H & 1) || (W & 1) || P != H / 2 || Q != W / 2) return 0;
+  if (up % 64 != 0 || vp % 64 != 0 || A != up || Breal != vp) return 0;
+  const long strips = (long)N * cdiv(P, 7) * cdiv(Q, 14);
+  if ((long)N * P * Q * 10 < strips * 112 * 7) return 0;           // < 70 % real k-values (7x7 / 4x4 maps: im2col kernel)
+  if ((long)N * P * Q * up * 2 >= 0x70000000L || (long)N * H * W * vp * 2 >= 0x70000000L) return 0;
+  const int tiles = (up / 64) * (vp / 64);
+  long splits = wh_cus() / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > strips) splits = strips;
+  if (splits > 512) splits = 512;
+  return (int)splits;
+}
+
+bool msml_wgrad_halo_s2_launch(const void* u, int up, const void* v, int vp, float* ws, int N, int H, int W, int P, int Q,
+                               int splits, hipStream_t st) {
+  WgradHaloArgs a;
+  for (int i = 0; i < WH_MAXGROUP; i++) {
+    a.u[i] = (const unsigned short*)u;
+    a.v[i] = (const unsigned short*)v;
+  }
+  a.up = up; a.u_bytes = (unsigned int)((long)N * P * Q * up * 2);
+  a.vp = vp; a.v_bytes = (unsigned int)((long)N * H * W * vp * 2);
+  a.N = N; a.H = P; a.W = Q; a.XH = H; a.XW = W; a.spy = cdiv(P, 7); a.spx = cdiv(Q, 14);
+  a.pair7 = 0;
+  a.nstrips = N * a.spy * a.spx;
+  a.chunk = cdiv(a.nstrips, splits);
+  a.zper = splits;
+  a.ws = ws;
+  a.xin = BnIn{nullptr, nullptr, nullptr};
+  const int tiles = (up / 64) * (vp / 64);
+  a.remap = (getenv("MSML_WGRAD_HALO_NO_REMAP") == nullptr && tiles >= 4 && splits % 8 == 0) ? 1 : 0;
+  wh_launch<64, false, false, true>(a, dim3(up / 64, vp / 64, splits), st);
+  return true;
 }
 
 // splits per layer when `group` layers of this shape share one launch (0: not covered)
@@ -353,7 +419,7 @@ bool msml_wgrad_halo_launch_group(const void* const* u, int up, const void* cons
   }
   a.up = up; a.u_bytes = (unsigned int)((long)N * H * W * up * 2);
   a.vp = vp; a.v_bytes = (unsigned int)((long)N * H * W * vp * 2);
-  a.N = N; a.H = H; a.W = W; a.spy = cdiv(H, 7); a.spx = cdiv(W, 14);
+  a.N = N; a.H = H; a.W = W; a.XH = H; a.XW = W; a.spy = cdiv(H, 7); a.spx = cdiv(W, 14);
   a.pair7 = (H == 7 && W == 7) ? 1 : 0;
   a.nstrips = a.pair7 ? (N + 1) / 2 : N * a.spy * a.spx;
   a.chunk = cdiv(a.nstrips, splits);

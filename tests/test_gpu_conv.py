@@ -1124,3 +1124,24 @@ def test_conv_s2r_64_channel_stride2(shape):
         xh = (xf - coef[2]) * coef[3]
         want = torch.stack((gg.sum(0), (gg * xh).sum(0), torch.where(neg, gq * z, torch.zeros_like(z)).sum(0))).double()
         assert torch.allclose(acc.sum(0), want, rtol=2e-3, atol=2e-3 * want.abs().max().item())
+
+
+# stride-2 weight gradients on the strip kernel (k_wgrad_halo<64, S2>: the X strip as four parity planes): (N, Cin, Cout, H)
+# with H the conv INPUT size; more strips than splits, ragged strips (26 -> 13), the 256-channel layer (16 dW tiles)
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("shape", [(6, 64, 64, 56), (3, 64, 64, 112), (9, 128, 128, 28), (4, 64, 128, 26), (5, 256, 256, 28)])
+def test_conv_wgrad_stride2_on_the_strip_kernel(shape, accumulate, monkeypatch):
+    monkeypatch.setenv("MSML_HALO_WGRAD_S2", "1")         # (opt-in: measured not faster than the im2col kernel)
+    n, cin, cout, h = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, h, generator=g).bfloat16().float()
+    ho = h // 2
+    dy = torch.randn(n, cout, ho, ho, generator=g).bfloat16().float()
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.double, requires_grad=True)
+    F.conv2d(x.double(), w, None, 2, 1).backward(dy.double())
+    ref = w.grad.float()
+    dw = torch.full((cout, cin, 3, 3), 2.0, device="cuda")
+    ops.conv_wgrad(ops.to_nhwc(dy.cuda(), _lib.BF16), ops.to_nhwc(x.cuda(), _lib.BF16), dw, cout, cin, cin, 0,
+                   3, 3, 2, 1, 1, accumulate=accumulate)
+    want = ref + (2.0 if accumulate else 0.0)
+    assert (dw.cpu() - want).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
