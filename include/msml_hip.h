@@ -375,6 +375,14 @@ int msml_conv2d_x3(const void* in0, int c0p, const void* in1, int c1p, const voi
                    const float* scale, const float* shift, const float* alpha, const void* residual,
                    int res_first, void* out, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                    int stride, int pad_h, int pad_w, int transposed, void* stream);
+/* msml_conv2d_x3_border: the 3x3 / stride-1 / pad-1 forward case of msml_conv2d_x3 with a shift per BORDER CLASS of the
+ *   output pixel: shift9 = float[9][coutp], row cy * 3 + cx, cy (cx) = 0 on the first row (column) of the map, 2 on the
+ *   last, 1 inside; H, W >= 2.  Lets the caller fold an eval-mode BatchNorm IN FRONT of the conv into it -- bn1 -> conv1
+ *   of IBasicBlock (reference backbones/frb/iresnet.py:58-60): conv(W, s x + t) = conv(W s, x) + the sum of W t over
+ *   the taps that fall INSIDE the map (the zero padding follows the BatchNorm), which is a constant per class. */
+int msml_conv2d_x3_border(const void* in0, int c0p, const void* wp, int kop, const float* scale,
+                          const float* shift9, const float* alpha, const void* residual, int res_first,
+                          void* out, int coutp, int N, int H, int W, void* stream);
 int msml_x3_bn_act_fwd(const void* x, const float* scale, const float* shift, const float* alpha,
                        const void* residual, int res_first, void* y, long M, int C, void* stream);
 int msml_x3_fm_fuse_fwd(const void* x, const void* yf, void* z, long M, int C, int act, int arith,

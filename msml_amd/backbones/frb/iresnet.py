@@ -45,8 +45,10 @@ class IBasicBlock(nn.Module):
     def forward(self, x):
         if self.training and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and ops.BLOCK_FUNCTION:
             return blocks.iblock(self, x)          # one autograd node, fused backward (blocks.py)
-        out = Fh.bn_act(x, None, self.bn1)
-        out = conv_bn(self.conv1, self.bn2, out, prelu=self.prelu)
+        out = Fh.bn_conv_bn_eval_x3(x, self.bn1, self.conv1, self.bn2, self.prelu) if isinstance(x, Fh.SplitT) else None
+        if out is None:
+            out = Fh.bn_act(x, None, self.bn1)
+            out = conv_bn(self.conv1, self.bn2, out, prelu=self.prelu)
         identity = x
         if self.downsample is not None:
             identity = conv_bn(self.downsample[0], self.downsample[1], x)

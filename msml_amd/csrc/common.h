@@ -16,6 +16,13 @@
 #define MSML_ACC_ROWS 8
 #endif
 extern thread_local int msml_tl_stats_acc;
+// Border-class bias (msml_conv2d_x3_border, conv_igemm.hip): `bias` of a 3x3 / stride-1 / pad-1 forward launch points at
+// float[9][coutp], row (cy * 3 + cx) with cy / cx = 0 on the first row / column of the map, 2 on the last, 1 inside.
+// Travels from the C entry point to the launch sites like msml_tl_stats_acc.
+extern thread_local int msml_tl_bias9;
+__device__ __forceinline__ int border_class(int y, int x, int H, int W) {
+  return ((y == 0) ? 0 : (y == H - 1 ? 2 : 1)) * 3 + ((x == 0) ? 0 : (x == W - 1 ? 2 : 1));
+}
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -42,6 +42,7 @@ struct ConvFastArgs {
   const float* alpha;
   const unsigned short* residual;
   int res_first;
+  int bias9;                      // X3: `bias` is float[9][coutp] by border class (common.h); applied in the copy-out loop
   float* stats;
   int stats_acc;      // accumulator mode (common.h): stats is double[MSML_ACC_ROWS][2][coutp]
   BnBwdFuse bnb;      // bnb.partial != nullptr: fused BatchNorm backward-reduce (common.h)
@@ -384,9 +385,9 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
     const int lcol = brow0 + j * 32 + r32;
     const int col = n0 + lcol;
     const bool cok = col < p.coutp;
-    const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+    const float bv = (p.bias && cok && !(X3 && p.bias9)) ? p.bias[col] : 0.f;
     const float sv = (p.scale && cok) ? p.scale[col] : 1.f;
-    const bool act_here = p.alpha && !(p.residual && p.res_first);
+    const bool act_here = p.alpha && !(p.residual && p.res_first) && !(X3 && p.bias9);
     const float av = (act_here && cok) ? p.alpha[col] : 1.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -459,7 +460,19 @@ __global__ void __launch_bounds__(WGM * WGN * 64, FUSE ? 2 : 1) k_conv_fast(cons
         const long m = m0 + row;
         if (m < Mc && col < p.coutp) {
           Vec8 a = load8<float>(otf + row * OPF + c8 * 8);
-          const long o = out_pixel(m) * (3L * p.coutp) + col;
+          const long opix = out_pixel(m);
+          const long o = opix * (3L * p.coutp) + col;
+          if (p.bias9) {                               // border-class shift (+ the PReLU that follows it)
+            const int ox = (int)(opix % p.Q), oy = (int)((opix / p.Q) % p.P);
+            const Vec8 b9 = load8<float>(p.bias + border_class(oy, ox, p.P, p.Q) * p.coutp + col);
+            const bool act9 = p.alpha && !(p.residual && p.res_first);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              float z = a.v[q] + b9.v[q];
+              if (act9) z = z > 0.f ? z : z * p.alpha[col + q];
+              a.v[q] = z;
+            }
+          }
           if (p.residual) {
             const Vec8 rh = load8<unsigned short>(p.residual + o), rl = load8<unsigned short>(p.residual + o + p.coutp);
 #pragma unroll
@@ -607,6 +620,10 @@ bool msml_conv_s2r_dispatch(const void* in0, int c0p, const void* wp, int kop, c
                             int transposed, hipStream_t st, const float* scale, const float* alpha, const void* residual,
                             const BnBwdFuse* bnb, int* bnb_rows);
 
+bool msml_conv_s2r_x3_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp, int N,
+                               int H, int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int transposed,
+                               hipStream_t st, const float* scale, const float* alpha, const void* residual, int res_first);
+
 bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p, const void* wp, int kop,
                              const float* bias, void* out, int coutp, float* stats, int N, int H,
                              int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
@@ -657,6 +674,11 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
       msml_conv_s2r_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed,
                              st, scale, alpha, residual, bnb, bnb_rows))
     return true;
+  // split-bf16 inference: the 64 -> 64 channel 3x3 / stride-1 layers with both weight planes in registers (conv_s2r.hip)
+  if (x3 && !in1 &&
+      msml_conv_s2r_x3_dispatch(in0, c0p, wp, kop, bias, out, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed, st,
+                                scale, alpha, residual, res_first))
+    return true;
   // split-bf16 inference: 3x3 / stride-1 layers of the 28x28 / 14x14 stages on the halo kernel (c0p is 3 x logical)
   if (x3 && !in1 &&
       msml_conv_halo_dispatch(in0, c0p, wp, kop, bias, out, coutp, stats, N, H, W, P, Q, R, S, stride, pad_h,
@@ -685,6 +707,7 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   a.wp = (const unsigned short*)wp; a.out = out; a.coutp = coutp; a.bias = bias; a.stats = stats;
   a.stats_acc = stats ? msml_tl_stats_acc : 0;
   a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual; a.res_first = res_first;
+  a.bias9 = (x3 && bias) ? msml_tl_bias9 : 0;
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
   a.M = (long)N * P * Q;
@@ -771,7 +794,7 @@ bool msml_conv_fast_splitk(const void* in0, int c0p, const void* wp, int kop, fl
   a.N = N; a.H = 1; a.W = 1; a.P = 1; a.Q = 1; a.R = 1; a.S = 1;
   a.stride = 1; a.stride_shift = 0; a.pad_h = 0; a.pad_w = 0; a.transposed = 0;
   a.wp = (const unsigned short*)wp; a.out = ws; a.coutp = coutp; a.bias = nullptr; a.stats = nullptr; a.stats_acc = 0;
-  a.scale = nullptr; a.alpha = nullptr; a.residual = nullptr; a.res_first = 0;
+  a.scale = nullptr; a.alpha = nullptr; a.residual = nullptr; a.res_first = 0; a.bias9 = 0;
   a.bnb = BnBwdFuse{};
   a.M = N;
   a.parity = 0;

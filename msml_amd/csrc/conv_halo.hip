@@ -41,6 +41,7 @@ struct ConvHaloArgs {
   const float* alpha;
   const unsigned short* residual;
   int res_first;
+  int bias9;                      // X3: `bias` is float[9][coutp] by border class (common.h)
   float* stats;
   int stats_rows;
   int stats_acc;      // accumulator mode (common.h): stats is double[MSML_ACC_ROWS][2][coutp]
@@ -501,9 +502,13 @@ k_conv_halo(const ConvHaloArgs p) {
           r4[3] = __uint_as_float(rh[1] & 0xffff0000u) + __uint_as_float(rl[1] & 0xffff0000u);
         }
         unsigned short hh[4], ll[4];
+        f32x4 bg = bv[g];
+        if (p.bias9 && valid)
+          bg = *reinterpret_cast<const f32x4*>(p.bias + border_class(y0 + (m >> 4), x0 + (m & 15), p.H, p.W) * p.coutp + n0 + kb +
+                                               8 * g);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          float z = acc[i][g * 4 + j] * sv[g][j] + bv[g][j];
+          float z = acc[i][g * 4 + j] * sv[g][j] + bg[j];
           if (act_here) z = z > 0.f ? z : z * av[g][j];
           if (p.residual) {
             z += r4[j];
@@ -725,6 +730,8 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   a.out = (unsigned short*)out; a.coutp = coutp;
   a.bias = bias; a.scale = scale; a.alpha = alpha; a.residual = (const unsigned short*)residual;
   a.res_first = res_first; a.stats = stats;
+  a.bias9 = (x3 && bias) ? msml_tl_bias9 : 0;
+  if (msml_tl_bias9 && !x3) return false;
   a.stats_rows = cdiv((long)N * P * Q, msml_conv_tile_m(coutp));
   a.stats_acc = stats ? msml_tl_stats_acc : 0;
   a.bnb = BnBwdFuse{};

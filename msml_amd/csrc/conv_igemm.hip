@@ -329,6 +329,7 @@ bool msml_deconv4_dispatch(const void* in0, const void* in1, const void* wp, int
                            int H, hipStream_t st);
 
 thread_local int msml_tl_stats_acc = 0;
+thread_local int msml_tl_bias9 = 0;
 
 extern "C" int msml_conv_tile_m(int coutp) { return coutp <= 64 ? 256 : 128; }
 extern "C" int msml_conv_tile_n(int coutp) { return coutp <= 32 ? 32 : (coutp <= 64 ? 64 : 128); }
@@ -470,6 +471,30 @@ extern "C" int msml_conv2d_x3(const void* in0, int c0p, const void* in1, int c1p
                                      (hipStream_t)stream, scale, alpha, residual, res_first, nullptr, nullptr),
              MSML_ERR_UNSUPPORTED, "conv2d_x3: shape not supported by the fast kernel");
   MSML_LAUNCH_OK("conv2d_x3");
+  return MSML_OK;
+}
+
+
+// The same conv with a BORDER-CLASS shift: shift9 = float[9][coutp], row (cy * 3 + cx), cy / cx = 0 on the first row /
+// column of the output map, 2 on the last, 1 inside (3x3 / stride-1 / pad-1 forward only).  This is what folding an
+// eval-mode BatchNorm IN FRONT of the conv into the conv needs (bn1 -> conv1 of IBasicBlock, backbones/frb/iresnet.py:58-60):
+// conv(W, s x + t) = conv(W s, x) + sum over the taps INSIDE the map of W t -- the zero padding is applied after the
+// BatchNorm, so the constant part depends on which taps of a border pixel fall outside.
+extern "C" int msml_conv2d_x3_border(const void* in0, int c0p, const void* wp, int kop, const float* scale,
+                                     const float* shift9, const float* alpha, const void* residual, int res_first, void* out,
+                                     int coutp, int N, int H, int W, void* stream) {
+  MSML_CHECK(in0 && wp && out && shift9, MSML_ERR_SHAPE, "conv2d_x3_border: null pointer");
+  MSML_CHECK(c0p > 0 && c0p % 32 == 0 && coutp > 0 && coutp % 32 == 0 && H >= 2 && W >= 2, MSML_ERR_SHAPE,
+             "conv2d_x3_border: c0p=%d coutp=%d H=%d W=%d", c0p, coutp, H, W);
+  const int bn = msml_conv_tile_n(coutp);
+  MSML_CHECK(kop >= cdiv(coutp, bn) * bn, MSML_ERR_SHAPE, "conv2d_x3_border: packed weight rows");
+  msml_tl_bias9 = 1;
+  const bool ok = msml_conv_fast_dispatch(in0, 3 * c0p, nullptr, 0, wp, kop, shift9, out, coutp, nullptr, N, H, W, H, W, 3, 3, 1,
+                                          1, 1, 0, MSML_BF16, MSML_BF16X3, bn, (hipStream_t)stream, scale, alpha, residual,
+                                          res_first, nullptr, nullptr);
+  msml_tl_bias9 = 0;
+  MSML_CHECK(ok, MSML_ERR_UNSUPPORTED, "conv2d_x3_border: shape not supported by the fast kernel");
+  MSML_LAUNCH_OK("conv2d_x3_border");
   return MSML_OK;
 }
 

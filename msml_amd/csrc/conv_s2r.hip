@@ -353,6 +353,213 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
 }
 
+// ---- split-bf16 inference (x3.hip, config 5: eval/qeval_mxnet.py:326-390 through the fp16=True default precision) -------
+// 64 -> 64 channel 3x3 / stride-1 layers on tensors stored as [hi | lo | hi] (3 x 64 channels per pixel).  The general
+// kernel walks them as ONE implicit GEMM over 192 input channels with the operand [wh | wh | wl]: the hi plane is fetched
+// and read from LDS twice.  Here a tile's hi and lo planes are two LDS images (256 B of the 384 a pixel holds), wh AND wl
+// of the wave's 16 output channels stay in registers (2 x 72 VGPRs), and every hi fragment read from LDS feeds two MFMAs
+// (wh, wl), every lo fragment one (wh): 3 MFMAs per 2 fragment reads where the bf16 kernel above has 1 per read.
+// Epilogue in f32 from the accumulators (pair swap on the f32 values): scale / shift (eval-mode BatchNorm or bias), PReLU,
+// residual (hi + lo) before or after the PReLU, then the three output planes -- the arithmetic of k_conv_fast's X3 epilogue.
+struct ConvS2rX3Args {
+  const unsigned short* in;      // [N][H][W][192]
+  unsigned int in_bytes;
+  int N, GH, GW;
+  int tpy, tpx, ntiles;
+  const unsigned short* wp;      // [64][9 * 192], K order [tap][wh(64) | wh(64) | wl(64)]
+  unsigned short* out;           // [N][H][W][192]
+  unsigned int out_bytes;
+  const float* scale;            // per output channel or nullptr (1)
+  const float* bias;             // per output channel or nullptr (0); bias9: float[9][64] by border class (common.h)
+  const float* alpha;            // PReLU slopes or nullptr
+  const unsigned short* residual;  // split tensor of the output's shape or nullptr
+  int res_first;                 // residual is added BEFORE the PReLU
+  int bias9;
+};
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_s2r_x3(const ConvS2rX3Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = 64, PIX = 3 * C, ABYTES = 256 * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                                     // [2 buffers][hi, lo][256 px][128 B]
+  MSML_LDS_REGION(As, 4 * ABYTES + 1024);
+  float* ktab = reinterpret_cast<float*>(smem + 4 * ABYTES + 1024);     // [2][64] scale, alpha, then [1 or 9][64] shift
+  MSML_LDS_REGION(ktab, 11 * C * 4);
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kg = wave & 3, mg = wave >> 2;
+  const int l16 = lane & 15, q16 = lane >> 4;
+  const int tpi = p.tpy * p.tpx;
+
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
+
+  u32x4 wh[9][2], wl[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const unsigned short* wr = p.wp + (long)(kg * 16 + l16) * (9 * PIX) + tap * PIX + w * 32 + q16 * 8;
+      wh[tap][w] = *reinterpret_cast<const u32x4*>(wr);
+      wl[tap][w] = *reinterpret_cast<const u32x4*>(wr + 2 * C);
+    }
+  for (int c = t; c < C; c += 512) {
+    ktab[c] = p.scale ? p.scale[c] : 1.f;
+    ktab[C + c] = p.alpha ? p.alpha[c] : 1.f;
+  }
+  for (int c = t; c < (p.bias9 ? 9 : 1) * C; c += 512) ktab[2 * C + c] = p.bias ? p.bias[c] : 0.f;
+
+  // both planes of a tile (+ halo) into buffer `buf`: 8 requests per lane (a tile past the end: all out of range)
+  auto issue_img = [&](int tile, int buf) {
+    const bool live = tile < p.ntiles;
+    const int tl = live ? tile : 0;
+    const int n = tl / tpi, trem = tl - n * tpi, ty = trem / p.tpx;
+    const int y0 = ty * 14, x0 = (trem - ty * p.tpx) * 14;
+    char* a = As + buf * 2 * ABYTES;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int j = wave + i * 8;
+      const int hp = j * 8 + (lane >> 3);
+      const int logical = (lane & 7) ^ (hp & 7);
+      const int by = y0 + (hp >> 4) - 1, bx = x0 + (hp & 15) - 1;
+      const bool v = live & ((unsigned)by < (unsigned)p.GH) & ((unsigned)bx < (unsigned)p.GW);
+      const unsigned int off = v ? (unsigned int)((n * p.GH + by) * p.GW + bx) * (unsigned int)(PIX * 2) + logical * 16u : S2R_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(a + j * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(a + ABYTES + j * 1024), 16, v ? off + C * 2u : S2R_OOB, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[7];
+  auto tap_mfma = [&](const char* img, int lr, int ls, const u32x4 (&whr)[2], const u32x4 (&wlr)[2]) {
+    const int arow = l16 + ls, asw = arow & 7;
+    const char* Arow = img + (((lr << 4) + mg * 112) * 128) + arow * 128;
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      // (one set of 7 fragments live at a time: 2 x 72 weight registers leave no room for a second one; the partner wave
+      // of the SIMD covers the LDS latency)
+      u32x4 a[7];
+#pragma unroll
+      for (int j = 0; j < 7; j++) a[j] = *reinterpret_cast<const u32x4*>(Arow + (((4 * w + q16) ^ asw) << 4) + j * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 7; j++)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whr[w]), __builtin_bit_cast(bf16x8, a[j]),
+                                                         acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 7; j++)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wlr[w]), __builtin_bit_cast(bf16x8, a[j]),
+                                                         acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 7; j++) a[j] = *reinterpret_cast<const u32x4*>(Arow + ABYTES + (((4 * w + q16) ^ asw) << 4) + j * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 7; j++)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whr[w]), __builtin_bit_cast(bf16x8, a[j]),
+                                                         acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int cch = kg * 16 + (q16 >> 1) * 8;            // the lane's 8-channel chunk after the pair swap (see k_conv_s2r)
+  const bool act_here = p.alpha && !(p.residual && p.res_first);
+  const bool act_after = p.alpha && p.residual && p.res_first;
+
+  __syncthreads();                                     // coefficient table
+  int tile = blockIdx.x, it = 0;
+  issue_img(tile, 0);
+  for (; tile < p.ntiles; tile += gridDim.x, it++) {
+    const int cur = it & 1;
+    const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+    const int y0 = ty * 14, x0 = (trem - ty * p.tpx) * 14;
+    __syncthreads();                                   // this tile's planes landed (drains vmcnt); the other buffer is free
+    issue_img(tile + gridDim.x, cur ^ 1);
+    const char* img = As + cur * 2 * ABYTES;
+#pragma unroll
+    for (int j = 0; j < 7; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) tap_mfma(img, tap / 3, tap % 3, wh[tap], wl[tap]);
+
+    // epilogue: group pairs (2 pr, 2 pr + 1) swapped on the f32 values; the lane then holds channels cch .. cch + 7 of pixel
+    // l16 of group 2 pr + (q16 & 1)
+    const int rows = p.GH - y0;
+    const bool col_ok = (l16 < 14) & (x0 + l16 < p.GW);
+    const unsigned int base = (unsigned int)((n * p.GH + y0) * p.GW + x0 + l16) * PIX, rowstep = (unsigned int)(p.GW * PIX);
+    // (coefficients and residual chunks are fetched per pair: with 2 x 72 weight registers the epilogue has ~50 to work in)
+    auto res_ok = [&](int pr) {
+      const int g = mg * 7 + 2 * pr + (q16 & 1);
+      return (2 * pr + (q16 & 1) < 7) & col_ok & (g < rows) & (g < 14);
+    };
+    auto res_ptr = [&](int pr) { return p.residual + base + (mg * 7 + 2 * pr + (q16 & 1)) * rowstep + cch; };
+    u32x4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};
+    if (p.residual && res_ok(0)) {
+      rh = *reinterpret_cast<const u32x4*>(res_ptr(0));
+      rl = *reinterpret_cast<const u32x4*>(res_ptr(0) + C);
+    }
+#pragma unroll
+    for (int pr = 0; pr < 4; pr++) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        // (through float temporaries: __builtin_bit_cast applied to the vector-element expression itself reads element 0)
+        const float f0 = acc[2 * pr][e], f1 = pr < 3 ? acc[pr < 3 ? 2 * pr + 1 : 0][e] : 0.f;
+        const unsigned int a0 = __float_as_uint(f0), a1 = __float_as_uint(f1);
+        auto sw = __builtin_amdgcn_permlane16_swap(a0, a1, false, false);
+        v[e] = __builtin_bit_cast(float, (unsigned int)sw[0]);
+        v[4 + e] = __builtin_bit_cast(float, (unsigned int)sw[1]);
+      }
+      const int g = mg * 7 + 2 * pr + (q16 & 1);
+      const bool ok = (2 * pr + (q16 & 1) < 7) & col_ok & (g < rows) & (g < 14);
+      Vec8 z;
+      {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(ktab + cch), s1 = *reinterpret_cast<const f32x4*>(ktab + cch + 4);
+        const float* hb = ktab + 2 * C + cch + (p.bias9 ? border_class(y0 + g, x0 + l16, p.GH, p.GW) * C : 0);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(hb), h1 = *reinterpret_cast<const f32x4*>(hb + 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++) z.v[i] = v[i] * (i < 4 ? s0[i & 3] : s1[i & 3]) + (i < 4 ? h0[i & 3] : h1[i & 3]);
+      }
+      const f32x4 al0 = *reinterpret_cast<const f32x4*>(ktab + C + cch), al1 = *reinterpret_cast<const f32x4*>(ktab + C + cch + 4);
+      if (act_here) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) z.v[i] = z.v[i] > 0.f ? z.v[i] : z.v[i] * (i < 4 ? al0[i & 3] : al1[i & 3]);
+      }
+      if (p.residual) {
+        float a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          a[2 * i] = __builtin_bit_cast(float, rh[i] << 16);
+          a[2 * i + 1] = __builtin_bit_cast(float, rh[i] & 0xffff0000u);
+          b[2 * i] = __builtin_bit_cast(float, rl[i] << 16);
+          b[2 * i + 1] = __builtin_bit_cast(float, rl[i] & 0xffff0000u);
+        }
+        if (pr < 3 && res_ok(pr + 1)) {                  // next pair's chunks fly during this pair's arithmetic
+          rh = *reinterpret_cast<const u32x4*>(res_ptr(pr + 1));
+          rl = *reinterpret_cast<const u32x4*>(res_ptr(pr + 1) + C);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          float y = z.v[i] + (a[i] + b[i]);
+          if (act_after) y = y > 0.f ? y : y * (i < 4 ? al0[i & 3] : al1[i & 3]);
+          z.v[i] = y;
+        }
+      }
+      u32x4 oh, ol;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned short h0 = f2bf(z.v[2 * i]), h1 = f2bf(z.v[2 * i + 1]);
+        oh[i] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+        ol[i] = (unsigned int)f2bf(z.v[2 * i] - bf2f(h0)) | ((unsigned int)f2bf(z.v[2 * i + 1] - bf2f(h1)) << 16);
+      }
+      const unsigned int ob = ok ? (base + g * rowstep + cch) * 2u : S2R_OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(oh, rs_out, ob, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ol, rs_out, ok ? ob + C * 2u : S2R_OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(oh, rs_out, ok ? ob + C * 4u : S2R_OOB, 0, 0);
+    }
+  }
+#endif
+}
+
 static int s2r_num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -426,5 +633,34 @@ bool msml_conv_s2r_dispatch(const void* in0, int c0p, const void* wp, int kop, c
   else if (!transposed) launch_s2r<1, false>(a, st);
   else if (bnb) launch_s2r<2, true>(a, st);
   else launch_s2r<2, false>(a, st);
+  return true;
+}
+
+// Split-bf16 inference (msml_conv2d_x3): 64 -> 64 channel 3x3 / stride-1 / pad-1 forward layers; c0p = 3 x 64 as the fast
+// dispatcher sees it.  MSML_NO_S2R_X3=1 (read per call: the tests compare with the general kernel) leaves them on k_conv_fast.
+bool msml_conv_s2r_x3_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp, int N,
+                               int H, int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w, int transposed,
+                               hipStream_t st, const float* scale, const float* alpha, const void* residual, int res_first) {
+  if (getenv("MSML_NO_S2R_CONV") != nullptr || getenv("MSML_NO_S2R_X3") != nullptr) return false;
+  if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || transposed || c0p != 192 || coutp != 64 || kop < 64) return false;
+  if (P != H || Q != W) return false;
+  const long tiles = (long)N * cdiv(H, 14) * cdiv(W, 14);
+  if ((long)N * H * W * 10 < tiles * 224 * 7) return false;            // < 70 % real GEMM rows
+  if ((long)N * H * W * 192 * 2 >= 0x70000000L) return false;
+  ConvS2rX3Args a;
+  a.in = (const unsigned short*)in0; a.in_bytes = (unsigned int)((long)N * H * W * 192 * 2);
+  a.N = N; a.GH = H; a.GW = W;
+  a.tpy = cdiv(H, 14); a.tpx = cdiv(W, 14); a.ntiles = N * a.tpy * a.tpx;
+  a.wp = (const unsigned short*)wp;
+  a.out = (unsigned short*)out; a.out_bytes = a.in_bytes;
+  a.scale = scale; a.bias = bias; a.alpha = alpha; a.residual = (const unsigned short*)residual; a.res_first = res_first;
+  a.bias9 = bias ? msml_tl_bias9 : 0;
+  const size_t lds = (size_t)4 * 256 * 128 + 1024 + 11 * 64 * sizeof(float);
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_s2r_x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  const int wgs = a.ntiles < s2r_num_cus() ? a.ntiles : s2r_num_cus();
+  k_conv_s2r_x3<<<dim3(wgs), dim3(512), lds, st>>>(a);
   return true;
 }

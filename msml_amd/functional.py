@@ -5,6 +5,7 @@ state dicts and optimizers see exactly what they see with the reference modules.
 Backward functions run on PyTorch's autograd thread; the library is reentrant and every call
 passes torch's current stream explicitly.
 """
+import os
 import torch
 
 from . import _lib, ops
@@ -924,7 +925,11 @@ def conv_x3(x0, x1, conv_m, scale, shift, alpha, residual, res_first, c1=0, weig
     q = ops.conv_out_size(wd, s, stride, pw, deconv)
     out = _x3_empty(n, p, q, coutp, x0.device)
     pix = n * h * wd if deconv else n * p * q
-    with ops.PROFILE.rec("conv_x3", 2.0 * pix * cin * cout * r * s):
+    name = "conv_x3"
+    if ops.PROFILE.on and os.environ.get("MSML_PROFILE_X3_SHAPES"):
+        name = "conv_x3 c%d+%d->%d %dx%d k%dx%d s%d%s n%d" % (c0p, x1.shape[3] if x1 is not None else 0, coutp, h, wd, r, s,
+                                                             stride, "T" if deconv else "", n)
+    with ops.PROFILE.rec(name, 2.0 * pix * cin * cout * r * s):
         call("msml_conv2d_x3", x0.t, c0p, x1.t if x1 is not None else None, x1.shape[3] if x1 is not None else 0,
              wp, wp.shape[0], scale, shift, alpha, residual.t if residual is not None else None, int(res_first),
              out.t, coutp, n, h, wd, p, q, r, s, stride, ph, pw, int(deconv))
@@ -947,6 +952,54 @@ def conv_bn_eval_x3(x0, x1, conv_m, bn_m, prelu, residual, c1, res_first):
                    res_first, c1)
 
 
+# IBasicBlock's bn1 sits IN FRONT of conv1 (backbones/frb/iresnet.py:58-60): in eval mode it is an affine map per input
+# channel, so conv1(bn1(x)) = conv(W s1, x) + sum over the taps inside the map of W t1 -- a constant per BORDER CLASS of the
+# output pixel (the zero padding follows the BatchNorm).  The split-bf16 path folds it into conv1's operand and a [9][Cout]
+# shift table (msml_conv2d_x3_border) instead of a pass over the block input.  MSML_X3_NO_BN1_FOLD=1 restores the pass.
+X3_FOLD_BN1 = os.environ.get("MSML_X3_NO_BN1_FOLD") is None
+
+
+def _bn_stamp(bn_m):
+    return (bn_m.weight._version, bn_m.bias._version, bn_m.running_mean._version, bn_m.running_var._version,
+            bn_m.weight.data_ptr())
+
+
+def bn_conv_bn_eval_x3(x, bn_in, conv_m, bn_m, prelu):
+    """bn_in -> conv3x3 (stride 1, pad 1, no bias) -> bn_m -> PReLU on a split tensor in ONE launch; None when the conv
+    is not of that kind (the caller then runs bn_act + conv_bn)."""
+    n, h, w, cp = x.shape
+    cout, cin = conv_m.out_channels, conv_m.in_channels
+    if (not X3_FOLD_BN1 or conv_m.kernel_size != (3, 3) or conv_m.stride != (1, 1) or conv_m.padding != (1, 1)
+            or conv_m.bias is not None or h < 2 or w < 2):
+        return None
+    coutp = cpad(cout)
+    cw = conv_m.weight
+    stamp = (_bn_stamp(bn_in), _bn_stamp(bn_m), cw._version, cw.data_ptr(), ops.WEIGHT_EPOCH, cp)
+    hit = conv_m.__dict__.get("_msml_x3_fold")
+    if hit is None or hit[0] != stamp:
+        c_in = _eval_bn_coef(bn_in, cp).double()
+        c_out = _eval_bn_coef(bn_m, coutp).double()
+        wd = cw.detach().double()
+        wf = (wd * c_in[0, :cin].view(1, cin, 1, 1)).float()
+        wp = ops.pack_weight(_x3_expand(wf, 1, [(cin, cp)]), False, 3 * cp, 0, BF16)
+        tap = (wd * c_in[1, :cin].view(1, cin, 1, 1)).sum(1)                  # [cout][3][3]: W t1 per tap
+        rows = ((1, 2), (0, 1, 2), (0, 1))                                    # taps inside the map: first / inner / last
+        b9 = torch.zeros(9, coutp, dtype=torch.float64, device=cw.device)
+        for cy in range(3):
+            for cx in range(3):
+                b9[cy * 3 + cx, :cout] = tap[:, rows[cy], :][:, :, rows[cx]].sum((1, 2))
+        shift9 = (b9 * c_out[0].view(1, coutp) + c_out[1].view(1, coutp)).float().contiguous()
+        hit = (stamp, wp, shift9)
+        conv_m.__dict__["_msml_x3_fold"] = hit
+    _, wp, shift9 = hit
+    scale = _eval_bn_coef(bn_m, coutp)[0]
+    out = _x3_empty(n, h, w, coutp, x.device)
+    with ops.PROFILE.rec("conv_x3", 2.0 * n * h * w * cin * cout * 9):
+        call("msml_conv2d_x3_border", x.t, cp, wp, wp.shape[0], scale, shift9, prelu.weight if prelu is not None else None,
+             None, 0, out.t, coutp, n, h, w)
+    return out
+
+
 def conv_plain_x3(conv_m, x0, x1, c1):
     """Conv / deconv (+ bias) without BatchNorm (OSB decoder, FM same_conv)."""
     shift = _pad_vec(conv_m.bias, cpad(conv_m.out_channels)) if conv_m.bias is not None else None
@@ -957,8 +1010,12 @@ def bn_act_x3(x, bn_m, prelu=None, residual=None, res_first=False):
     n, h, w, cp = x.shape
     coef = _eval_bn_coef(bn_m, cp)
     y = _x3_empty(n, h, w, cp, x.device)
-    call("msml_x3_bn_act_fwd", x.t, coef[0], coef[1], prelu.weight if prelu is not None else None,
-         residual.t if residual is not None else None, int(res_first), y.t, n * h * w, cp)
+    name = "bn_act_fwd"
+    if ops.PROFILE.on and os.environ.get("MSML_PROFILE_X3_SHAPES"):
+        name = "bn_act_x3 c%d %dx%d n%d%s%s" % (cp, h, w, n, " +prelu" if prelu is not None else "", " +res" if residual is not None else "")
+    with ops.PROFILE.rec(name, 0.0, n * h * w * cp * 2 * (7 if residual is not None else 5)):
+        call("msml_x3_bn_act_fwd", x.t, coef[0], coef[1], prelu.weight if prelu is not None else None,
+             residual.t if residual is not None else None, int(res_first), y.t, n * h * w, cp)
     return y
 
 

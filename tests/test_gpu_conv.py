@@ -1145,3 +1145,100 @@ def test_conv_wgrad_stride2_on_the_strip_kernel(shape, accumulate, monkeypatch):
                    3, 3, 2, 1, 1, accumulate=accumulate)
     want = ref + (2.0 if accumulate else 0.0)
     assert (dw.cpu() - want).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+
+
+# conv_s2r.hip, k_conv_s2r_x3: split-bf16 (config 5) 64 -> 64 channel 3x3 / stride-1 layers with both weight planes in
+# registers (N, H, W): one tile per workgroup, the persistent loop (more tiles than workgroups), ragged tiles, a non-square map
+@pytest.mark.parametrize("epi", ["plain", "bn_prelu", "bn_res_prelu", "bn_prelu_res", "bias"])
+@pytest.mark.parametrize("shape", [(3, 56, 56), (2, 112, 112), (5, 28, 28), (4, 27, 40), (40, 56, 56)])
+def test_conv_x3_64_channel_register_kernel(shape, epi, monkeypatch):
+    """Split-bf16 conv + affine / PReLU / residual epilogue (functional.conv_x3 -> msml_conv2d_x3) on the register-weights
+    kernel: against f64 torch on the values the split tensors hold (f32-class: 3e-5 of the output scale, where one bf16
+    product is 4e-3), and against the general kernel (k_conv_fast X3), which differs only in the order of its f32 sums."""
+    import torch.nn as nn
+    from msml_amd import functional as Fh
+    n, h, w = shape
+    c = 64
+    g = torch.Generator().manual_seed(n * 977 + h * 31 + w + len(epi))
+    x = torch.randn(n, h, w, c, generator=g).cuda()
+    conv = nn.Conv2d(c, c, 3, 1, 1, bias=(epi == "bias")).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(c, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5)
+        if conv.bias is not None:
+            conv.bias.copy_(torch.randn(c, generator=g))
+    scale = (torch.rand(c, generator=g) + 0.5).cuda() if epi.startswith("bn") else None
+    shift = torch.randn(c, generator=g).cuda() if epi.startswith("bn") else (conv.bias.detach() if epi == "bias" else None)
+    alpha = (torch.rand(c, generator=g) * 0.5).cuda() if "prelu" in epi else None
+    res = torch.randn(n, h, w, c, generator=g).cuda() if "res" in epi else None
+    res_first = epi == "bn_res_prelu"
+    xs = Fh.x3_from_f32(x)
+    rs = Fh.x3_from_f32(res) if res is not None else None
+
+    def run():
+        return Fh.x3_to_f32(Fh.conv_x3(xs, None, conv, scale, shift, alpha, rs, res_first))
+
+    got = run()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("MSML_NO_S2R_X3", "1")
+    gen = run()
+    torch.cuda.synchronize()
+    monkeypatch.delenv("MSML_NO_S2R_X3")
+    xv = Fh.x3_to_f32(xs).double().permute(0, 3, 1, 2)
+    wh = conv.weight.detach().to(torch.bfloat16).float()
+    wv = (wh + (conv.weight.detach() - wh).to(torch.bfloat16).float()).double()      # what [wh | wh | wl] holds
+    y = F.conv2d(xv, wv, None, 1, 1)
+    cs = (1, c, 1, 1)
+    if scale is not None:
+        y = y * scale.double().view(cs)
+    if shift is not None:
+        y = y + shift.double().view(cs)
+    rv = Fh.x3_to_f32(rs).double().permute(0, 3, 1, 2) if rs is not None else None
+    if rv is not None and res_first:
+        y = y + rv
+    if alpha is not None:
+        y = torch.where(y > 0, y, y * alpha.double().view(cs))
+    if rv is not None and not res_first:
+        y = y + rv
+    ref = y.permute(0, 2, 3, 1)
+    tol = 3e-5 * ref.abs().max().item()
+    assert (gen.double() - ref).abs().max().item() <= tol          # (the general kernel meets the same bar)
+    assert (got.double() - ref).abs().max().item() <= tol
+    assert (got - gen).abs().max().item() <= tol
+
+
+# msml_conv2d_x3_border on its three kernels: (N, Cin, Cout, H, W) -- k_conv_s2r_x3 (64 -> 64), k_conv_halo X3 (one 14 x 14 tile
+# per image and four per image, ragged 13 x 20), k_conv_fast X3 (channel-changing conv1 of a stage's first block, 7 x 7 maps)
+@pytest.mark.parametrize("shape", [(3, 64, 64, 56, 56), (4, 64, 64, 27, 40), (5, 128, 128, 28, 28), (6, 256, 256, 14, 14),
+                                   (3, 256, 256, 13, 20), (4, 64, 128, 28, 28), (7, 512, 512, 7, 7), (2, 128, 256, 14, 14)])
+def test_conv_x3_with_the_leading_batchnorm_folded_in(shape):
+    """functional.bn_conv_bn_eval_x3 (bn1 -> conv1 -> bn2 -> PReLU of IBasicBlock, backbones/frb/iresnet.py:58-62, eval mode,
+    split-bf16): the leading BatchNorm folded into the conv operand + a shift per border class, against f64 torch on the
+    values the split input holds, and against the unfolded pair of launches."""
+    import torch.nn as nn
+    from msml_amd import functional as Fh
+    n, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=False).cuda()
+    bn1, bn2 = nn.BatchNorm2d(cin).cuda().eval(), nn.BatchNorm2d(cout).cuda().eval()
+    prelu = nn.PReLU(cout).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+        for bn in (bn1, bn2):
+            c = bn.num_features
+            bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g) * 0.5)
+            bn.running_mean.copy_(torch.randn(c, generator=g) * 0.3)
+            bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        prelu.weight.copy_(torch.rand(cout, generator=g) * 0.5)
+    xs = Fh.x3_from_f32(x)
+    out = Fh.bn_conv_bn_eval_x3(xs, bn1, conv, bn2, prelu)
+    assert out is not None
+    got = Fh.x3_to_f32(out)
+    two = Fh.x3_to_f32(Fh.conv_bn_eval_x3(Fh.bn_act_x3(xs, bn1), None, conv, bn2, prelu, None, 0, False))
+    with torch.no_grad():
+        xv = Fh.x3_to_f32(xs).double().permute(0, 3, 1, 2)
+        ref = prelu.double()(bn2.double()(conv.double()(bn1.double()(xv)))).permute(0, 2, 3, 1)
+    tol = 4e-5 * ref.abs().max().item()
+    assert (two.double() - ref).abs().max().item() <= tol          # (the unfolded pair meets the same bar)
+    assert (got.double() - ref).abs().max().item() <= tol
