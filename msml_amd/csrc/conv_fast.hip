@@ -613,7 +613,7 @@ bool msml_conv_pw_dispatch(const void* in0, int c0p, const void* wp, int kop, in
 bool msml_conv_halo2_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
                               float* stats, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
                               int pad_w, int transposed, hipStream_t st, const float* scale, const float* alpha,
-                              const void* residual, int res_first, const BnBwdFuse* bnb, int* bnb_rows);
+                              const void* residual, int res_first, const BnBwdFuse* bnb, int* bnb_rows, int x3 = 0);
 
 bool msml_conv_s2r_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
                             float* stats, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h, int pad_w,
@@ -678,6 +678,11 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   if (x3 && !in1 &&
       msml_conv_s2r_x3_dispatch(in0, c0p, wp, kop, bias, out, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed, st,
                                 scale, alpha, residual, res_first))
+    return true;
+  // split-bf16 inference: stride-2 layers and 7x7 / 4x4 maps (conv_halo2.hip)
+  if (x3 && !in1 &&
+      msml_conv_halo2_dispatch(in0, c0p, wp, kop, bias, out, coutp, nullptr, N, H, W, P, Q, R, S, stride, pad_h, pad_w,
+                               transposed, st, scale, alpha, residual, res_first, nullptr, nullptr, 1))
     return true;
   // split-bf16 inference: 3x3 / stride-1 layers of the 28x28 / 14x14 stages on the halo kernel (c0p is 3 x logical)
   if (x3 && !in1 &&

@@ -44,15 +44,21 @@ struct ConvHalo2Args {
   const unsigned short* residual;   // (!FUSE) added to the result before the store (the FM `conv_tee` join)
   float* stats;       // accumulator-mode statistics double[MSML_ACC_ROWS][2][coutp] or nullptr
   BnBwdFuse bnb;
+  // X3 (split-bf16 inference, x3.hip): C = 3 x the logical input channels ([hi | lo | hi] planes walked as plain channels),
+  // `out` / `residual` hold 3 x coutp channels per pixel; out = [prelu](acc * scale + bias [+ residual]) [+ residual]
+  const float* alpha;
+  int res_first;
+  int bias9;          // `bias` is float[9][coutp] by border class of the output pixel (common.h; stride-1 launches)
 };
 
 #define H2_OOB 0x78000000u
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN, int NWM, int GEOM, int MOS, bool FUSE>
+template <int BN, int NWM, int GEOM, int MOS, bool FUSE, bool X3 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo2(const ConvHalo2Args p) {
+  static_assert(!X3 || (!FUSE && GEOM != 2), "split-bf16: forward launches only");
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PL2 = 4, PITCH = 16, KG = BN / 32, NW = KG * NWM, NT = NW * 64;
   // mosaic geometry: images of IMG x IMG pixels every PER = IMG + 1 pixels, MC x MR of them per tile
@@ -322,6 +328,80 @@ k_conv_halo2(const ConvHalo2Args p) {
     bv[g] = (!FUSE && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n0 + kb + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
     sv[g] = (!FUSE && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + n0 + kb + 16 * g) : f32x4{1.f, 1.f, 1.f, 1.f};
   }
+  if constexpr (X3) {
+    // split-bf16 output: the pair swap runs on the f32 accumulators (the lane then holds channels cdir .. cdir + 7 of its
+    // pixel), affine + PReLU + residual (hi + lo planes) in f32, the result leaves as three planes (k_conv_fast's X3 epilogue)
+    const bool act_here = p.alpha && !(p.residual && p.res_first), act_after = p.alpha && p.residual && p.res_first;
+    const int cc = n0 + cdir;
+    float sc[8], bi[8], al[8];
+    {
+      const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 s0 = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cc) : one;
+      const f32x4 s1_ = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cc + 4) : one;
+      const f32x4 c0 = (p.bias && !p.bias9) ? *reinterpret_cast<const f32x4*>(p.bias + cc) : zero;
+      const f32x4 c1 = (p.bias && !p.bias9) ? *reinterpret_cast<const f32x4*>(p.bias + cc + 4) : zero;
+      const f32x4 a0 = p.alpha ? *reinterpret_cast<const f32x4*>(p.alpha + cc) : one;
+      const f32x4 a1 = p.alpha ? *reinterpret_cast<const f32x4*>(p.alpha + cc + 4) : one;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        sc[c] = s0[c]; sc[4 + c] = s1_[c];
+        bi[c] = c0[c]; bi[4 + c] = c1[c];
+        al[c] = a0[c]; al[4 + c] = a1[c];
+      }
+    }
+#pragma unroll
+    for (int jg = 0; jg < NGW; jg++) {
+      const int m = (g0 + jg) * 16 + l16;
+      const bool valid = (jg < ng) & pix_ok(m);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float f0 = acc4[jg][0][e], f1 = acc4[jg][1][e];      // (float temporaries: see conv_s2r.hip)
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(f0), __float_as_uint(f1), false, false);
+        v[e] = __uint_as_float(sw[0]);
+        v[4 + e] = __uint_as_float(sw[1]);
+      }
+      const long po = pix_off(m) * 3 + cc;
+      f32x4 b0 = {bi[0], bi[1], bi[2], bi[3]}, b1 = {bi[4], bi[5], bi[6], bi[7]};
+      if (p.bias9 && valid) {
+        const int my = m >> 4, mx = m & 15;
+        const int gy = MOS ? my % PER : y0 + my, gx = MOS ? mx % PER : x0 + mx;
+        const float* bp = p.bias + border_class(gy, gx, p.GH, p.GW) * p.coutp + cc;
+        b0 = *reinterpret_cast<const f32x4*>(bp);
+        b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+      }
+      u32x4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};
+      if (p.residual && valid) {
+        rh = *reinterpret_cast<const u32x4*>(p.residual + po);
+        rl = *reinterpret_cast<const u32x4*>(p.residual + po + p.coutp);
+      }
+      u32x4 oh, ol;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float z[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const int c = 2 * i + k;
+          float y = v[c] * sc[c] + (c < 4 ? b0[c & 3] : b1[c & 3]);
+          if (act_here) y = y > 0.f ? y : y * al[c];
+          if (p.residual) {
+            y += __uint_as_float(k ? (rh[i] & 0xffff0000u) : (rh[i] << 16)) + __uint_as_float(k ? (rl[i] & 0xffff0000u) : (rl[i] << 16));
+            if (act_after) y = y > 0.f ? y : y * al[c];
+          }
+          z[k] = y;
+        }
+        const unsigned short h0 = f2bf(z[0]), h1 = f2bf(z[1]);
+        oh[i] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+        ol[i] = (unsigned int)f2bf(z[0] - bf2f(h0)) | ((unsigned int)f2bf(z[1] - bf2f(h1)) << 16);
+      }
+      if (valid) {
+        *reinterpret_cast<u32x4*>(p.out + po) = oh;
+        *reinterpret_cast<u32x4*>(p.out + po + p.coutp) = ol;
+        *reinterpret_cast<u32x4*>(p.out + po + 2 * p.coutp) = oh;
+      }
+    }
+    return;
+  }
   const bool direct = FDIR || (!FUSE && p.residual == nullptr);
 #pragma unroll
   for (int jg = 0; jg < NGW; jg++) {
@@ -433,7 +513,7 @@ k_conv_halo2(const ConvHalo2Args p) {
 #endif
 }
 
-template <int BN, int NWM, int GEOM, int MOS, bool FUSE>
+template <int BN, int NWM, int GEOM, int MOS, bool FUSE, bool X3 = false>
 static void launch_halo2(ConvHalo2Args& a, hipStream_t st) {
   constexpr int NGRP = MOS ? 2 * (MOS + 1) - 1 : 14, HPX = MOS ? (NGRP + 2) * 16 + 8 : 16 * 16, BM = NGRP * 16;
   size_t lds = 2 * (size_t)HPX * 128 + 8 * 8192;        // two halo images + eight private weight rings
@@ -445,18 +525,18 @@ static void launch_halo2(ConvHalo2Args& a, hipStream_t st) {
   if (rlds > lds) lds = rlds;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo2<BN, NWM, GEOM, MOS, FUSE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo2<BN, NWM, GEOM, MOS, FUSE, X3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   const int tiles = MOS ? cdiv(a.N, MOS == 4 ? 6 : 4) : a.N * a.tpy * a.tpx;
   dim3 grid(tiles, a.coutp / BN, GEOM == 2 ? 4 : 1);
-  k_conv_halo2<BN, NWM, GEOM, MOS, FUSE><<<grid, dim3(512), lds, st>>>(a);
+  k_conv_halo2<BN, NWM, GEOM, MOS, FUSE, X3><<<grid, dim3(512), lds, st>>>(a);
 }
 
 // geom: 0 stride 1, 1 stride-2 forward, 2 stride-2 backward-data.  Returns the tiling (0 none, 1 plain 14 x 14 tiles,
 // 2 mosaic of four 7 x 7 images, 3 mosaic of six 4 x 4 images) this family takes the shape with.
 int msml_conv_halo2_tiling(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
-                           int pad_h, int pad_w, int transposed) {
+                           int pad_h, int pad_w, int transposed, int x3) {
   static const bool off = getenv("MSML_NO_HALO2_CONV") != nullptr;
   if (off) return 0;
   if (R != 3 || S != 3 || pad_h != 1 || pad_w != 1) return 0;
@@ -473,10 +553,13 @@ int msml_conv_halo2_tiling(int c0p, int kop, int coutp, int N, int H, int W, int
   // mosaics run 128-channel tiles: below ~160 workgroups (256 -> 256 @ 7x7: 128, 128 -> 128 @ 7x7: 64, the forward of
   // 256 @ 14 -> 7: 128) the im2col kernel's 64-row tiles fill the chip better (tools/bench_small.py: 37.4 -> 34.9 us,
   // 17.6 -> 19.7 us, 36.1 -> 37.7 us); a backward-data launch has four slices per tile
+  // (split-bf16 inference: the kernel choice must not depend on N -- an image's embedding is bit-identical whatever batch
+  // it is extracted in, tests/test_verification.py -- so the mosaics take every batch there; 512-channel layers only)
   const long cblk = coutp / 128, slices = (stride == 2 && transposed) ? 4 : 1;
-  if (gh == 7 && gw == 7)
-    return (no_mos || (stride == 2 && no_s2) || cdiv(N, 4) * cblk * slices < 160) ? 0 : 2;
-  if (gh == 4 && gw == 4 && stride == 1) return (no_mos || cdiv(N, 6) * cblk < 160) ? 0 : 3;
+  const bool fill7 = x3 ? coutp >= 512 : cdiv(N, 4) * cblk * slices >= 160;
+  const bool fill4 = x3 ? coutp >= 512 : cdiv(N, 6) * cblk >= 160;
+  if (gh == 7 && gw == 7) return (no_mos || (stride == 2 && no_s2) || !fill7) ? 0 : 2;
+  if (gh == 4 && gw == 4 && stride == 1) return (no_mos || !fill4) ? 0 : 3;
   if (stride == 1 || no_s2) return 0;                   // stride-1 maps with real tiles: conv_halo.hip
   const long tiles = (long)N * cdiv(gh, 14) * cdiv(gw, 14);
   if ((long)N * gh * gw * 10 < tiles * 224 * 7) return 0;           // < 70 % real GEMM rows: im2col kernel wins
@@ -487,10 +570,15 @@ int msml_conv_halo2_tiling(int c0p, int kop, int coutp, int N, int H, int W, int
 bool msml_conv_halo2_dispatch(const void* in0, int c0p, const void* wp, int kop, const float* bias, void* out, int coutp,
                               float* stats, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
                               int pad_w, int transposed, hipStream_t st, const float* scale, const float* alpha,
-                              const void* residual, int res_first, const BnBwdFuse* bnb, int* bnb_rows) {
-  const int tiling = msml_conv_halo2_tiling(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed);
+                              const void* residual, int res_first, const BnBwdFuse* bnb, int* bnb_rows, int x3) {
+  const int tiling = msml_conv_halo2_tiling(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed, x3);
   if (!tiling) return false;
-  if (alpha || res_first) return false;
+  // split-bf16 inference (c0p = 3 x the logical channels): forward launches, no statistics; MSML_NO_HALO2_X3=1 (read per
+  // call) leaves them on the im2col kernel
+  if (x3 && (transposed || bnb || stats || getenv("MSML_NO_HALO2_X3") != nullptr)) return false;
+  if (x3 && (long)N * P * Q * coutp * 6 >= 0x7fffffffL * 2) return false;
+  if (msml_tl_bias9 && !(x3 && stride == 1)) return false;
+  if (!x3 && (alpha || res_first)) return false;
   if (bnb && (bias || scale)) return false;
   if (stats && !msml_tl_stats_acc) return false;
   if (bnb && (!bnb->acc || residual || stats)) return false;
@@ -510,12 +598,21 @@ bool msml_conv_halo2_dispatch(const void* in0, int c0p, const void* wp, int kop,
   a.stats = stats;
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
+  a.alpha = alpha; a.res_first = res_first; a.bias9 = (x3 && bias) ? msml_tl_bias9 : 0;
   const bool mos = tiling >= 2;
   const bool wide = coutp % 256 == 0 && !mos;           // mosaic: N / 4 tiles -- 128-channel tiles fill the chip sooner
   if (bnb_rows) *bnb_rows = (mos ? cdiv(N, tiling == 3 ? 6 : 4) : N * a.tpy * a.tpx) * (geom == 2 ? 4 : 1);
 #define H2_CASE(GEOM, MOS)                                                              \
   if (bnb) { if (wide) launch_halo2<256, 1, GEOM, MOS, true>(a, st); else launch_halo2<128, 2, GEOM, MOS, true>(a, st); } \
   else { if (wide) launch_halo2<256, 1, GEOM, MOS, false>(a, st); else launch_halo2<128, 2, GEOM, MOS, false>(a, st); }
+  if (x3) {
+    if (tiling == 3) launch_halo2<128, 2, 0, 4, false, true>(a, st);
+    else if (mos && geom == 0) launch_halo2<128, 2, 0, 7, false, true>(a, st);
+    else if (mos) launch_halo2<128, 2, 1, 7, false, true>(a, st);
+    else if (wide) launch_halo2<256, 1, 1, 0, false, true>(a, st);
+    else launch_halo2<128, 2, 1, 0, false, true>(a, st);
+    return true;
+  }
   if (tiling == 3) {
     if (bnb) launch_halo2<128, 2, 0, 4, true>(a, st); else launch_halo2<128, 2, 0, 4, false>(a, st);
   } else if (mos) {

@@ -547,7 +547,7 @@ extern "C" int msml_conv2d_bnbwd_acc(const void* in0, int c0p, const void* wp, i
 }
 
 int msml_conv_halo2_tiling(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
-                           int pad_h, int pad_w, int transposed);
+                           int pad_h, int pad_w, int transposed, int x3);
 int msml_conv_s2r_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
                           int pad_w, int transposed);
 bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
@@ -722,7 +722,7 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
     return transposed ? "k_conv_s2r<64 -> 64 stride-2 backward-data, weights in registers, persistent>"
                       : "k_conv_s2r<64 -> 64 stride-2 forward, 4 parity planes, weights in registers, persistent>";
   if (fast && c1p == 0 && out_dtype == MSML_BF16) {
-    const int t2 = msml_conv_halo2_tiling(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed);
+    const int t2 = msml_conv_halo2_tiling(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, transposed, 0);
     if (t2 == 3) return "k_conv_halo2<mosaic of six 4x4 images x 128 ch>";
     if (t2 == 2) return stride == 1 ? "k_conv_halo2<mosaic of four 7x7 images x 128 ch>"
                                     : (transposed ? "k_conv_halo2<stride-2 backward-data, 4 classes, 7x7 mosaic x 128 ch>"

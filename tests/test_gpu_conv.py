@@ -1242,3 +1242,71 @@ def test_conv_x3_with_the_leading_batchnorm_folded_in(shape):
     tol = 4e-5 * ref.abs().max().item()
     assert (two.double() - ref).abs().max().item() <= tol          # (the unfolded pair meets the same bar)
     assert (got.double() - ref).abs().max().item() <= tol
+
+
+# k_conv_halo2 with the split-bf16 epilogue (config 5): (N, C, H, stride) -- stride-2 layers on 14 x 14 tiles (128- and 256-wide
+# channel blocks, ragged 26 -> 13), 14 -> 7 and 7 x 7 maps as four-image mosaics, 4 x 4 maps as six-image mosaics (a mosaic
+# needs ~160 workgroups, hence the batch)
+@pytest.mark.parametrize("epi", ["bn_prelu", "bn_res", "bn_res_prelu"])
+@pytest.mark.parametrize("shape", [(6, 128, 56, 2), (5, 256, 28, 2), (4, 128, 26, 2), (161, 512, 14, 2), (164, 512, 7, 1),
+                                   (243, 512, 4, 1)])
+def test_conv_x3_stride2_and_mosaics_on_the_halo_tile(shape, epi, monkeypatch):
+    import torch.nn as nn
+    from msml_amd import functional as Fh
+    n, c, h, stride = shape
+    ho = h // stride
+    g = torch.Generator().manual_seed(sum(shape) + len(epi))
+    x = torch.randn(n, h, h, c, generator=g).cuda()
+    conv = nn.Conv2d(c, c, 3, stride, 1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(c, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5)
+    scale = (torch.rand(c, generator=g) + 0.5).cuda()
+    shift = torch.randn(c, generator=g).cuda()
+    alpha = (torch.rand(c, generator=g) * 0.5).cuda() if "prelu" in epi else None
+    res = torch.randn(n, ho, ho, c, generator=g).cuda() if "res" in epi else None
+    res_first = epi == "bn_res_prelu"
+    xs = Fh.x3_from_f32(x)
+    rs = Fh.x3_from_f32(res) if res is not None else None
+
+    def run():
+        return Fh.x3_to_f32(Fh.conv_x3(xs, None, conv, scale, shift, alpha, rs, res_first))
+
+    got = run()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("MSML_NO_HALO2_X3", "1")
+    gen = run()
+    torch.cuda.synchronize()
+    monkeypatch.delenv("MSML_NO_HALO2_X3")
+    xv = Fh.x3_to_f32(xs).double().permute(0, 3, 1, 2)
+    wh = conv.weight.detach().to(torch.bfloat16).float()
+    wv = (wh + (conv.weight.detach() - wh).to(torch.bfloat16).float()).double()
+    cs = (1, c, 1, 1)
+    y = F.conv2d(xv, wv, None, stride, 1) * scale.double().view(cs) + shift.double().view(cs)
+    rv = Fh.x3_to_f32(rs).double().permute(0, 3, 1, 2) if rs is not None else None
+    if rv is not None and res_first:
+        y = y + rv
+    if alpha is not None:
+        y = torch.where(y > 0, y, y * alpha.double().view(cs))
+    if rv is not None and not res_first:
+        y = y + rv
+    ref = y.permute(0, 2, 3, 1)
+    tol = 4e-5 * ref.abs().max().item()
+    assert (gen.double() - ref).abs().max().item() <= tol
+    assert (got.double() - ref).abs().max().item() <= tol
+    assert (got - gen).abs().max().item() <= tol
+    if stride == 1:                                       # the leading-BatchNorm fold on the mosaic (border classes per image)
+        bn1, bn2 = nn.BatchNorm2d(c).cuda().eval(), nn.BatchNorm2d(c).cuda().eval()
+        prelu = nn.PReLU(c).cuda()
+        with torch.no_grad():
+            for bn in (bn1, bn2):
+                bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+                bn.bias.copy_(torch.randn(c, generator=g) * 0.5)
+                bn.running_mean.copy_(torch.randn(c, generator=g) * 0.3)
+                bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+            prelu.weight.copy_(torch.rand(c, generator=g) * 0.5)
+            ref2 = prelu.double()(bn2.double()(conv.double()(bn1.double()(xv)))).permute(0, 2, 3, 1)
+            conv.float()
+            bn1.float(); bn2.float(); prelu.float()
+        out = Fh.bn_conv_bn_eval_x3(xs, bn1, conv, bn2, prelu)
+        assert out is not None
+        assert (Fh.x3_to_f32(out).double() - ref2).abs().max().item() <= 4e-5 * ref2.abs().max().item()
