@@ -35,18 +35,22 @@ F_FWD_GF = {"iresnet18": 8.446, "iresnet34": 12.146, "iresnet50": 15.845, "iresn
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
 JSON_OUT = None                                   # the process's real stdout (main() points fd 1 at stderr)
 
-# Box calibration.  MI355X devices hold different clocks under one and the same load, and the boxes this
-# bench has run on differ by +-2...4 % on an unchanged build: `calibration` measures, in the SAME run and right before the timed
-# region, (i) a register-resident bf16 MFMA loop on random operands (msml_probe_mfma, csrc/probe.hip), (ii) the same with every
-# operand re-read from LDS in the halo conv's mix (msml_probe_mfma_lds) and (iii) a 2 x 512 MiB device copy, and
-# `value_normalised` rescales the headline to a reference box (normalise()).  The reference constant is arbitrary but fixed:
-# only ratios between runs mean anything.
-REF_MFMA_LDS_TFLOPS = 1640.0
-# how strongly the step's MFMA families follow the LDS-fed probe, fitted on the seven bench lines of one build this round
-# (profiles/r05_bench_box_*.json): boxes whose probe reads 1.3-2.6 % higher run conv + weight gradients 4.5-5 % faster -- the
-# probe is 0.2 s of one loop, the step keeps the chip loaded for seconds and the slower devices give more clock back.  The device
-# copy rate is recorded but NOT used: the HBM-bound families ran 3.06-3.08 / 2.73-2.77 ms at 4.47 and at 5.26 TB/s alike.
-MFMA_EXP = 2.0
+# Box calibration.  The boxes this bench has run on differ by +-2.5 % on an unchanged build (17 bench lines
+# of one build, profiles/r05_bench_box_*.json).  `calibration` records, in the SAME run and right before the timed region: (i) a
+# register-resident bf16 MFMA loop on random operands (msml_probe_mfma, csrc/probe.hip), (ii) the same with every operand re-read
+# from LDS in the halo conv's mix (msml_probe_mfma_lds), (iii) a 2 x 512 MiB device copy, (iv) a fixed 8192 x 8192 x 1024 GEMM on
+# the im2col kernel (calibrate_gemm) -- and what they showed is that NONE of them predicts how fast a box runs the conv families:
+# boxes with the lowest MFMA probes (1 609-1 620 LDS-fed) ran the step at 28.8-29.1 ms, one with a middle probe (1 645) at 29.9.
+# What does predict it is the step's own dominant launch timed alone in the run's one-stream event pass (`roofline.achieved`:
+# 839-920 TFLOP/s over those lines; conv + weight-gradient time follows it monotonically).  `value_normalised` therefore rescales
+# the MFMA families' share of the kernel time by (REF_DOMINANT / that rate) ^ DOM_EXP (normalise()): raw spread +-2.5 % ->
+# +-1.1 %.  The price: a change of THAT launch's own speed cancels out of value_normalised (it shows in `roofline.frac` and in
+# `value`); everything else in the step shows.  The reference constant is arbitrary but fixed: only ratios between runs mean
+# anything.
+REF_DOMINANT_TFLOPS = 900.0
+# how strongly the step's MFMA families follow the dominant launch's isolated rate (least squares over the 16 undisturbed lines:
+# the families are a mix of MFMA-, LDS- and byte-bound launches, so less than proportionally)
+DOM_EXP = 0.7
 MFMA_FAMILIES = ("conv_igemm", "conv_wgrad", "gemm_splitk", "conv_x3", "conv_fused")
 
 
@@ -97,16 +101,50 @@ def calibrate():
     return flop / t_mfma / 1e12, nbytes / t_copy / 1e12, flop2 / t_lds / 1e12
 
 
-def normalise(value, calib, kernels):
+def calibrate_gemm():
+    """TFLOP/s of a fixed 8192 x 8192 x 1024 bf16 GEMM on the im2col kernel's split-K entry (msml_gemm_splitk: LDS-DMA
+    operand fills, LDS fragment reads, 32x32x16 MFMAs, two f32 slabs + their reduce) -- a probe that loads the chip the
+    way the conv families do (global loads + LDS + MFMA + stores at once), which the two MFMA loops do not."""
+    from msml_amd import _lib, ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(11)
+    m, k, n = 8192, 8192, 1024
+    a = (torch.randn(m, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    w = (torch.randn(n, k, 1, 1, generator=g) * 0.05).to(dev)
+    wp = ops.pack_weight(w, False, k, 0, _lib.BF16)
+    need = _lib.value("msml_gemm_splitk_workspace", m, n, k)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    out = torch.empty(m, n, dtype=torch.float32, device=dev)
+
+    def fn():
+        _lib.call("msml_gemm_splitk", a, m, k, wp, wp.shape[0], out, n, ws, need, _lib.BF16)
+    for _ in range(6):
+        fn()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(16)]
+    evs[0].record()
+    for i in range(15):
+        fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(15))
+    return 2.0 * m * k * n / (ts[7] * 1e-3) / 1e12
+
+
+def normalise(value, calib, kernels, dominant=None):
     """value x (what this box costs relative to the reference box): the MFMA families' share of the kernel time scales with
-    (REF_MFMA_LDS / LDS-fed probe) ^ MFMA_EXP, everything else (BatchNorm / element-wise / optimizer: HBM-bound) is taken as
-    box-independent (see MFMA_EXP)."""
+    (REF_DOMINANT / isolated rate of the dominant launch) ^ DOM_EXP, everything else (BatchNorm / element-wise / optimizer:
+    HBM-bound) is taken as box-independent.  dominant: TFLOP/s of the dominant launch in the one-stream event pass of the same
+    run (default: calib["dominant_tflops"]); without it the value is returned as it is."""
     share = 0.76                                       # (round-4 family table; used when the run has no kernel events)
     if kernels:
         tot = sum(v["ms_per_step"] for v in kernels.values())
         if tot > 0:
             share = sum(v["ms_per_step"] for k, v in kernels.items() if k in MFMA_FAMILIES) / tot
-    slow = share * (REF_MFMA_LDS_TFLOPS / calib["mfma_lds_tflops"]) ** MFMA_EXP + (1.0 - share)
+    if dominant is None:
+        dominant = calib.get("dominant_tflops")
+    if not dominant:
+        return value, share
+    slow = share * (REF_DOMINANT_TFLOPS / dominant) ** DOM_EXP + (1.0 - share)
     return value * slow, share
 
 
@@ -696,7 +734,8 @@ def main():
     calib = None
     if not args.no_calibration:           # every rank (the two extra steps below hold collectives); rank 0 reports
         mf, cp, ml = calibrate()
-        calib = {"mfma_tflops": round(mf, 1), "mfma_lds_tflops": round(ml, 1), "copy_tbs": round(cp, 3)}
+        calib = {"mfma_tflops": round(mf, 1), "mfma_lds_tflops": round(ml, 1), "copy_tbs": round(cp, 3),
+                 "gemm_tflops": round(calibrate_gemm(), 1)}
         for _ in range(2):        # the probes leave the caches and the clock in their own state: two steps of the workload again
             throttled_step()
         barrier()
@@ -856,16 +895,19 @@ def main():
                                  "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                           for name, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
     if calib is not None:
-        vn, share = normalise(value, calib, rec.get("kernels"))
+        dom = (rec.get("roofline") or {}).get("achieved") if args.mode == "train" else None
+        vn, share = normalise(value, calib, rec.get("kernels"), dom)
         sc = [v for v in sclk if v is not None]
         calib.update({"sclk_mhz_avg": round(sum(sc) / len(sc), 1) if sc else None,
-                      "ref_mfma_lds_tflops": REF_MFMA_LDS_TFLOPS, "mfma_exponent": MFMA_EXP,
+                      "dominant_tflops": dom, "ref_dominant_tflops": REF_DOMINANT_TFLOPS, "dominant_exponent": DOM_EXP,
                       "mfma_share_of_kernel_time": round(share, 4),
                       "method": "msml_probe_mfma: 512 WGs x 4 waves x 20000 x 16 register-resident v_mfma_f32_16x16x32_bf16 on random "
                                 "operands, median of 15 launches after 12; copy: torch copy_ of 512 MiB (read + write), median of 9; "
-                                "msml_probe_mfma_lds: 256 WGs x 8 waves, 9 ds_read_b128 per 14 MFMAs; all on the training stream right before the "
-                                "timed region; value_normalised = value x (share x (ref_mfma_lds / mfma_lds) ^ mfma_exponent + (1 - share)), "
-                                "share = MFMA families' part of the kernel-event time; the copy rate is recorded, not used"})
+                                "msml_probe_mfma_lds: 256 WGs x 8 waves, 9 ds_read_b128 per 14 MFMAs; gemm: msml_gemm_splitk 8192 x 8192 x "
+                                "1024, median of 15; all on the training stream right before the timed region -- recorded, NOT used (they do "
+                                "not predict the conv families' speed on a box); value_normalised = value x (share x (ref_dominant / "
+                                "dominant) ^ dominant_exponent + (1 - share)), dominant = roofline.achieved of this run, share = MFMA "
+                                "families' part of the kernel-event time"})
         rec["calibration"] = calib
         rec["value_normalised"] = round(vn, 2)
     if world == 1 and not args.no_extra_modes and args.mode == "train" and args.dtype == "bf16":
