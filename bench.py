@@ -35,7 +35,7 @@ F_FWD_GF = {"iresnet18": 8.446, "iresnet34": 12.146, "iresnet50": 15.845, "iresn
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
 JSON_OUT = None                                   # the process's real stdout (main() points fd 1 at stderr)
 
-# Box calibration.  The boxes this bench has run on differ by +-2.5 % on an unchanged build (17 bench lines
+# Box calibration.  The boxes this bench has run on differ by +-2.5 % on an unchanged build (19 bench lines
 # of one build, profiles/r05_bench_box_*.json).  `calibration` records, in the SAME run and right before the timed region: (i) a
 # register-resident bf16 MFMA loop on random operands (msml_probe_mfma, csrc/probe.hip), (ii) the same with every operand re-read
 # from LDS in the halo conv's mix (msml_probe_mfma_lds), (iii) a 2 x 512 MiB device copy, (iv) a fixed 8192 x 8192 x 1024 GEMM on
@@ -48,7 +48,7 @@ JSON_OUT = None                                   # the process's real stdout (m
 # `value`); everything else in the step shows.  The reference constant is arbitrary but fixed: only ratios between runs mean
 # anything.
 REF_DOMINANT_TFLOPS = 900.0
-# how strongly the step's MFMA families follow the dominant launch's isolated rate (least squares over the 16 undisturbed lines:
+# how strongly the step's MFMA families follow the dominant launch's isolated rate (least squares over the first 16 undisturbed lines:
 # the families are a mix of MFMA-, LDS- and byte-bound launches, so less than proportionally)
 DOM_EXP = 0.7
 MFMA_FAMILIES = ("conv_igemm", "conv_wgrad", "gemm_splitk", "conv_x3", "conv_fused")
