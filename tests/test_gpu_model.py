@@ -72,6 +72,23 @@ def test_eval_fp16_default_meets_the_parity_bar(frb, fname, bs):
     assert err < 2e-4            # measured ~1e-5: keep an order of magnitude of margin visible
 
 
+def test_eval_fp16_bn1_fold_against_the_separate_pass(monkeypatch):
+    """Split-bf16 inference folds IBasicBlock's eval-mode bn1 into conv1 (functional.bn_conv_bn_eval_x3: operand scaled per
+    input channel + a shift per border class of the output pixel, backbones/frb/iresnet.py:58-60).  Against the path that
+    keeps bn1 as a pass of its own (X3_FOLD_BN1 off): same embeddings to split-bf16 rounding, same mask indices, and both
+    inside the golden's bar."""
+    m = hip_msml("iresnet50", fp16=True).eval()
+    x, _ = eval_inputs(2)
+    with torch.no_grad():
+        assert Fh.X3_FOLD_BN1
+        f1, s1 = m(x.cuda())
+        monkeypatch.setattr(Fh, "X3_FOLD_BN1", False)
+        f0, s0 = m(x.cuda())
+    assert rel_err(f1.float().cpu().numpy(), f0.float().cpu().numpy()) < 1e-4
+    assert torch.equal(Fh.mask_index(s1), Fh.mask_index(s0))
+    assert rel_err(s1.float().cpu().numpy(), s0.float().cpu().numpy()) < 1e-4
+
+
 @pytest.mark.parametrize("fp16", [False, True])
 def test_eval_ires34_vs_oracle(fp16):
     """iresnet34 ([3, 4, 6, 3], the third FRB the reference's MSML constructs: backbones/msml.py:106-108) has no
