@@ -743,6 +743,16 @@ bool msml_conv_fast_dispatch(const void* in0, int c0p, const void* in1, int c1p,
   static const long small_wgs = getenv("MSML_CONV_SMALL_M_WGS") ? atol(getenv("MSML_CONV_SMALL_M_WGS")) : 200;
   const bool small_m = small_ok && !x3 && out_dtype == MSML_BF16 && def_wgs <= small_wgs && a.M >= 2048 &&
                        (!stats || a.stats_acc) && (!bnb || bnb->acc);
+  // split-bf16 inference on the small maps (7x7 / 4x4: the deep OSB levels and their GCMs, the 256- / 128-channel 7x7
+  // layers): 64-row tiles whatever the batch -- the kernel choice of this mode must not depend on N (conv_halo2.hip) -- a
+  // 512 -> 32 @ 4x4 line conv is 16 workgroups of 256 rows x a K of 10 752 otherwise
+  static const bool x3_small = getenv("MSML_NO_X3_SMALL_M") == nullptr;
+  if (x3 && x3_small && !a.parity && P * Q <= 64 && !transposed) {
+    if (bn == 128) launch_fast<unsigned short, 64, 128, 2, 2, 2, false, true>(a, st);
+    else if (bn == 64) launch_fast<unsigned short, 64, 64, 2, 2, 2, false, true>(a, st);
+    else launch_fast<unsigned short, 64, 32, 2, 1, 2, false, true>(a, st);
+    return true;
+  }
   if (small_m) {
     if (bnb) {
       if (bias || residual || scale || alpha) return false;

@@ -1310,3 +1310,38 @@ def test_conv_x3_stride2_and_mosaics_on_the_halo_tile(shape, epi, monkeypatch):
         out = Fh.bn_conv_bn_eval_x3(xs, bn1, conv, bn2, prelu)
         assert out is not None
         assert (Fh.x3_to_f32(out).double() - ref2).abs().max().item() <= 4e-5 * ref2.abs().max().item()
+
+
+# split-bf16 convs on the small maps (64-row tiles of the general kernel whatever the batch): (N, Cin, Cout, H, (R, S), bias) --
+# the deepest GCM line convs (512 -> 18 @ 4x4), 256- / 128-channel 3x3 layers @ 7x7, a bottleneck 1x1
+@pytest.mark.parametrize("shape", [(37, 256, 256, 7, (3, 3), False), (50, 512, 18, 4, (7, 1), True), (50, 512, 18, 4, (1, 7), True),
+                                   (21, 128, 128, 7, (3, 3), False), (64, 512, 128, 7, (1, 1), False), (3, 256, 18, 7, (7, 1), True)])
+def test_conv_x3_small_maps(shape):
+    import torch.nn as nn
+    from msml_amd import functional as Fh
+    n, cin, cout, h, (r, s_), bias = shape
+    g = torch.Generator().manual_seed(sum(shape[:4]) + r)
+    x = torch.randn(n, h, h, cin, generator=g).cuda()
+    conv = nn.Conv2d(cin, cout, (r, s_), 1, (r // 2, s_ // 2), bias=bias).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, cin, r, s_, generator=g) * (2.0 / (cin * r * s_)) ** 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(cout, generator=g))
+    xs = Fh.x3_from_f32(x)
+    if bias:
+        got = Fh.x3_to_f32(Fh.conv_plain_x3(conv, xs, None, 0))[..., :cout]
+        extra = lambda y: y + conv.bias.detach().double().view(1, cout, 1, 1)      # noqa: E731
+    else:
+        scale = (torch.rand(cout, generator=g) + 0.5).cuda()
+        shift = torch.randn(cout, generator=g).cuda()
+        alpha = (torch.rand(cout, generator=g) * 0.5).cuda()
+        got = Fh.x3_to_f32(Fh.conv_x3(xs, None, conv, scale, shift, alpha, None, False))[..., :cout]
+
+        def extra(y):
+            y = y * scale.double().view(1, cout, 1, 1) + shift.double().view(1, cout, 1, 1)
+            return torch.where(y > 0, y, y * alpha.double().view(1, cout, 1, 1))
+    xv = Fh.x3_to_f32(xs).double().permute(0, 3, 1, 2)
+    wh = conv.weight.detach().to(torch.bfloat16).float()
+    wv = (wh + (conv.weight.detach() - wh).to(torch.bfloat16).float()).double()
+    ref = extra(F.conv2d(xv, wv, None, 1, (r // 2, s_ // 2))).permute(0, 2, 3, 1)
+    assert (got.double() - ref).abs().max().item() <= 4e-5 * ref.abs().max().item()
