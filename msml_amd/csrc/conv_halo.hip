@@ -473,7 +473,11 @@ k_conv_halo(const ConvHaloArgs p) {
           o16[e] = sw[0]; o16[2 + e] = sw[1];
         }
         if (valid) {
+#ifdef HALO_NT_STORE
+          __builtin_nontemporal_store(o16, reinterpret_cast<u32x4*>(p.out + pix_off(m) + n0 + kg * 32 + (q16 & 1) * 16 + (q16 >> 1) * 8));
+#else
           *reinterpret_cast<u32x4*>(p.out + pix_off(m) + n0 + kg * 32 + (q16 & 1) * 16 + (q16 >> 1) * 8) = o16;
+#endif
           if constexpr (FDIR)
             bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16)),
                       load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[jg])), bq);
