@@ -677,6 +677,272 @@ k_conv_halo(const ConvHaloArgs p) {
 #endif
 }
 
+// ---- persistent variant of the 128-channel tile (round 5) ------------------------------------------------------
+// A 128 -> 128 @ 28x28 launch is FOUR rounds of 14 x 14 tiles: every tile pays its exposed 64 KB image load, its epilogue
+// burst, its statistics atomics and a workgroup launch -- ~12 us that the one-round 256-channel launch pays once (525
+// against 930 TFLOP/s for the same FLOP).  Here a workgroup walks its tiles (blockIdx.x, + gridDim.x, ...) through ONE
+// software pipeline: the (tile, slab) sequence keeps alternating the two image buffers and the weight rings across the
+// tile boundary -- tile t + 1's first image is requested during tile t's last slab, its first weight stage before tile
+// t's epilogue -- the epilogue stores straight from registers beside the next tile's first stages, and the BatchNorm
+// statistics / fused backward sums stay in registers until the workgroup's last tile (one set of atomics per workgroup).
+// Same tiling, fragment maps and per-tile arithmetic as k_conv_halo<128, 2, FUSE, ..., M16>: outputs are bit-identical,
+// the sums differ in the order the tiles are added.  Plain forward (+ accumulator-mode statistics) and backward-data with
+// the fused BatchNorm sums (accumulator mode; register layout of -DHALO_FDIR); coutp == 128.
+template <bool FUSE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int PL2 = 4, PITCH = 16, BN = 128, KG = 4, NW = 8, NT = 512;
+  constexpr int TW = 14, TH = 14, HPX = 16 << PL2, ABYTES = HPX * 128, NAJ = HPX / 8, NAI = NAJ / NW;
+  constexpr int NG = 8, NGH = 4;                       // 16-pixel groups of one wave (at most), per pipeline phase
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                                     // [2][HPX][128 B]
+  char* Bs = smem + 2 * ABYTES;                        // [NW][2][32][128 B]
+  MSML_LDS_REGION(As, 2 * ABYTES);
+  MSML_LDS_REGION(Bs, NW * 8192);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  auto skey = [](int p_) { return p_ & 7; };
+  const int kg = wave % KG, mg = wave / KG;
+  const int i0 = mg * 4, nmt = mg == 0 ? 4 : 3, ng = 2 * nmt;
+  const int tpi = p.tpy * p.tpx;
+  const int l16 = lane & 15, q16 = lane >> 4;
+
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.w_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)out_bytes, 0x00020000);
+
+  auto calc_aoff = [&](int tile, unsigned int (&ao)[NAI]) {
+    const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+    const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
+#pragma unroll
+    for (int i = 0; i < NAI; i++) {
+      const int j = wave + i * NW;
+      const int hp = j * 8 + (lane >> 3);
+      const int logical = (lane & 7) ^ skey(hp);
+      const int iy = y0 + (hp >> PL2) - 1, ix = x0 + (hp & (PITCH - 1)) - 1;
+      const bool v = (tile < ntiles) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      ao[i] = v ? (unsigned int)((n * p.H + iy) * p.W + ix) * (unsigned int)(p.C * 2) + logical * 16u : HALO_OOB;
+    }
+  };
+  auto issue_a = [&](const unsigned int (&ao)[NAI], int cs, int buf) {
+    char* a = As + buf * ABYTES;
+#pragma unroll
+    for (int i = 0; i < NAI; i++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(a + (wave + i * NW) * 1024), 16,
+                                               ao[i] == HALO_OOB ? HALO_OOB : ao[i] + cs * 128u, 0, 0, 0);
+  };
+  unsigned int boffg[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = i * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ skey(row);
+    boffg[i] = (unsigned int)((kg * 32 + row) * p.Ktot) * 2u + logical * 16u;
+  }
+  auto issue_b = [&](int cs, int tap, int buf) {
+    char* b = Bs + wave * 8192 + buf * 4096;
+    const unsigned int col = (unsigned int)(tap * p.C + cs * 64) * 2u;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(b + i * 1024), 16, boffg[i] + col, 0, 0, 0);
+  };
+  int bfr16[2][2];
+#pragma unroll
+  for (int g = 0; g < 2; g++)
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const int row = 16 * g + l16;
+      bfr16[g][w] = wave * 8192 + row * 128 + (((4 * w + q16) ^ skey(row)) << 4);
+    }
+
+  // per-workgroup sums, in registers over all its tiles
+  const int cdir = kg * 32 + (q16 & 1) * 16 + (q16 >> 1) * 8;   // the lane's 8 channels after the pair swap
+  const int kb = kg * 32 + 4 * q16;                    // ... before it: kb + 16 g + j
+  f32x4 s1[2], s2[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++) s1[g] = s2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bq[3][8];
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) bq[q][j] = 0.f;
+  BnbCoef bk;
+  if (FUSE) bk = bnb_load_coef(p.bnb, cdir);
+
+  const int nslab = p.C >> 6, nstage = nslab * 9;
+  int tile = blockIdx.x;
+  unsigned int aoff[NAI], aoffn[NAI];
+  calc_aoff(tile, aoff);
+  issue_a(aoff, 0, 0);
+  issue_b(0, 0, 0);
+  __syncthreads();                                     // (drains vmcnt first)
+  int gs = 0, gq = 0;                                  // running slab / stage counters: image buffer gs & 1, weight slot gq & 1
+  bool first = true;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
+    const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
+    auto pix_ok = [&](int m) { return ((m & 15) < TW) & (x0 + (m & 15) < p.W) & (y0 + (m >> 4) < p.H); };
+    auto pix_off = [&](int m) { return (unsigned int)((n * p.H + y0 + (m >> 4)) * p.W + x0 + (m & 15)) * (unsigned int)BN; };
+    calc_aoff(tile + gridDim.x, aoffn);                // (a tile past the end: every request out of range)
+    f32x4 acc4[NG][2];
+#pragma unroll
+    for (int i = 0; i < NG; i++)
+#pragma unroll
+      for (int g = 0; g < 2; g++) acc4[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cs = 0, tr = 0, ts = 0;
+    for (int q = 0; q < nstage; q++, gq++) {
+      int ncs = cs, ntr = tr, nts = ts + 1;
+      if (nts == 3) { nts = 0; ntr++; }
+      if (ntr == 3) { ntr = 0; ncs++; }
+      // this wave's weights of stage q have landed.  Stage 0 of a later tile: they were requested BEFORE the previous
+      // tile's epilogue, whose NG stores (always issued, out of range when masked) are the only younger operations.
+      // (Also requesting stage 1's weights before the epilogue, so that stage 1 does not wait for the stores to be
+      // acknowledged either -- counted waits of 12 -- measured no faster alone and slower in the step; not kept.)
+#ifdef HALO_ABLATE_EPILOGUE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+      if (q == 0 && !first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      if (q + 1 < nstage) issue_b(ncs, ntr * 3 + nts, (gq + 1) & 1);
+      else issue_b(0, 0, (gq + 1) & 1);                // the next tile's first stage (past the end: a harmless re-read)
+      if ((tr | ts) == 0) {                            // first tap of a slab: the next slab's image, this tile's or the next one's
+        if (cs + 1 < nslab) issue_a(aoff, cs + 1, (gs + 1) & 1);
+        else issue_a(aoffn, 0, (gs + 1) & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int r = p.flip ? 2 - tr : tr, s = p.flip ? 2 - ts : ts;
+      const int arow = l16 + s, asw = skey(arow);
+      const char* Arow = As + (gs & 1) * ABYTES + (((r << PL2) + i0 * 32) * 128) + arow * 128;
+      const char* B = Bs + (gq & 1) * 4096;
+      u32x4 a16[2][NGH], b16[2][2];
+#pragma unroll
+      for (int j = 0; j < NGH; j++)
+        if (j < ng) a16[0][j] = *reinterpret_cast<const u32x4*>(Arow + ((q16 ^ asw) << 4) + j * 2048);
+#pragma unroll
+      for (int g = 0; g < 2; g++) b16[0][g] = *reinterpret_cast<const u32x4*>(B + bfr16[g][0]);
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++) {
+        const int cb = ph & 1, nb = cb ^ 1, w = ph >> 1, hf = ph & 1;
+        if (ph + 1 < 4) {
+          const int nw = (ph + 1) >> 1, nhf = (ph + 1) & 1;
+          const int ao = ((4 * nw + q16) ^ asw) << 4;
+#pragma unroll
+          for (int j = 0; j < NGH; j++)
+            if (nhf * NGH + j < ng) a16[nb][j] = *reinterpret_cast<const u32x4*>(Arow + ao + (nhf * NGH + j) * 2048);
+          if (nhf == 0) {
+#pragma unroll
+            for (int g = 0; g < 2; g++) b16[nw & 1][g] = *reinterpret_cast<const u32x4*>(B + bfr16[g][nw]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NGH; j++)
+          if (hf * NGH + j < ng) {
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+              acc4[hf * NGH + j][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, b16[w & 1][g]), __builtin_bit_cast(bf16x8, a16[cb][j]),
+                  acc4[hf * NGH + j][g], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ncs != cs) {                                 // slab switch (also the tile's end): the next image has landed
+        __syncthreads();                               // everywhere, and nobody reads the buffer the one after overwrites
+        gs++;
+      }
+      cs = ncs; tr = ntr; ts = nts;
+    }
+    first = false;
+#ifdef HALO_ABLATE_EPILOGUE
+    if (p.N >= 0) {
+#pragma unroll
+      for (int i = 0; i < NAI; i++) aoff[i] = aoffn[i];
+      continue;
+    }
+#endif
+    // ---- epilogue from registers: pair swap -> 8 contiguous channels per lane, one 16-B store per pixel group ----
+    u32x4 xr[NG];
+    if (FUSE) {
+#pragma unroll
+      for (int k = 0; k < NG; k++) {
+        const int m = i0 * 32 + k * 16 + l16;
+        xr[k] = (k < ng && pix_ok(m)) ? *reinterpret_cast<const u32x4*>(p.bnb.x + pix_off(m) + cdir) : u32x4{0, 0, 0, 0};
+      }
+    }
+#pragma unroll
+    for (int jg = 0; jg < NG; jg++) {
+      const int m = i0 * 32 + jg * 16 + l16;
+      const bool valid = (jg < ng) & pix_ok(m);
+      u32x2 pk[2];
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        const f32x4 z = acc4[jg][g];
+        if (!FUSE && valid) {
+          s1[g] += z;
+          s2[g] += z * z;
+        }
+        pk[g][0] = (unsigned int)f2bf(z[0]) | ((unsigned int)f2bf(z[1]) << 16);
+        pk[g][1] = (unsigned int)f2bf(z[2]) | ((unsigned int)f2bf(z[3]) << 16);
+      }
+      u32x4 o16;
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        auto sw = __builtin_amdgcn_permlane16_swap(pk[0][e], pk[1][e], false, false);
+        o16[e] = sw[0]; o16[2 + e] = sw[1];
+      }
+      // (buffer store: a masked lane stores out of range = dropped; the count of stores per tile is fixed, see the wait)
+      __builtin_amdgcn_raw_buffer_store_b128(o16, rs_out, valid ? (pix_off(m) + cdir) * 2u : HALO_OOB, 0, 0);
+      if (FUSE && valid)
+        bnb_accum(bk, p.bnb.alpha != nullptr, load8<unsigned short>(reinterpret_cast<const unsigned short*>(&o16)),
+                  load8<unsigned short>(reinterpret_cast<const unsigned short*>(&xr[jg])), bq);
+    }
+#pragma unroll
+    for (int i = 0; i < NAI; i++) aoff[i] = aoffn[i];
+  }
+  // ---- the workgroup's sums: the lanes that share a channel meet in LDS (every image / ring request has landed) --
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (FUSE) {
+    constexpr int G = 16 * 2;                          // lanes (mg, l16) share an 8-channel chunk
+    float* red = reinterpret_cast<float*>(smem);
+    MSML_LDS_REGION(red, G * 3 * BN * 4);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) red[((mg * 16 + l16) * 3 + q) * BN + cdir + j] = bq[q][j];
+    __syncthreads();
+    for (int i = t; i < 3 * BN; i += NT) {
+      const int q = i / BN, c = i % BN;
+      float sum = 0.f;
+      for (int g = 0; g < G; g++) sum += red[(g * 3 + q) * BN + c];
+      bnb_emit(p.bnb.partial, 1, blockIdx.x, q, BN, c, sum);
+    }
+  } else if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem) + wave * 64 * 33;
+    MSML_LDS_REGION(smem, NW * 64 * 33 * 4);
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        red[lane * 33 + g * 4 + j] = s1[g][j];
+        red[lane * 33 + 16 + g * 4 + j] = s2[g][j];
+      }
+    __syncthreads();
+    if (mg == 0) {                                     // channel kl = 16 g + 4 q + j lives in the 16 lanes 16 q + rr of both row groups
+      const int which = lane >> 5, kl = lane & 31;
+      const int k = which * 16 + (kl >> 4) * 4 + (kl & 3), qq = (kl >> 2) & 3;
+      float sum = 0.f;
+#pragma unroll
+      for (int gm = 0; gm < 2; gm++)
+#pragma unroll 8
+        for (int rr = 0; rr < 16; rr++) sum += red[gm * KG * 64 * 33 + (qq * 16 + rr) * 33 + k];
+      stats_emit(p.stats, 1, blockIdx.x, which, BN, kg * 32 + kl, sum);
+    }
+  }
+#endif
+}
+
 template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false>
 static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;      // two halo images + eight private weight rings
@@ -691,6 +957,16 @@ static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   });
   dim3 grid(a.N * a.tpy * a.tpx, a.coutp / BN);
   k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB><<<grid, dim3(512), lds, st>>>(a);
+}
+
+static int halo_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+  }
+  return n;
 }
 
 // Shape test shared by the dispatch and by msml_conv2d_kernel (the name query).
@@ -753,6 +1029,32 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   if (bin) {                             // BatchNorm backward in the prologue: 16x16x32 FUSE instantiations only
     if (wide) launch_halo<256, 1, true, false, false, true, true>(a, st);
     else launch_halo<128, 2, true, false, false, true, true>(a, st);
+    return true;
+  }
+  // 128-channel tile, several rounds of tiles per launch (128 -> 128 @ 28x28, 56x56): the persistent kernel.
+  // MSML_HALO_PERSIST=0: one tile per workgroup as before
+  // (read per call: the tests compare the two)
+  const char* pe = getenv("MSML_HALO_PERSIST");
+  const bool persist = pe == nullptr || atoi(pe) != 0;
+  if (persist && m16 >= 2 && !wide && coutp == 128 && !x3 && !xin && !bin && !bias && !scale && !alpha && !residual &&
+      tiles >= 2L * halo_num_cus() && (!stats || a.stats_acc) && (!bnb || bnb->acc) &&
+      (long)N * H * W * 128 * 2 < 0x70000000L) {
+    const size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;
+    const int grid = halo_num_cus();
+    const unsigned int out_bytes = (unsigned int)((long)N * H * W * 128 * 2);
+    if (bnb) {
+      static std::once_flag once;
+      std::call_once(once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo_p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      });
+      k_conv_halo_p<true><<<dim3(grid), dim3(512), lds, st>>>(a, (int)tiles, out_bytes);
+    } else {
+      static std::once_flag once;
+      std::call_once(once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo_p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      });
+      k_conv_halo_p<false><<<dim3(grid), dim3(512), lds, st>>>(a, (int)tiles, out_bytes);
+    }
     return true;
   }
   if (m16 && !x3 && (wide || m16 >= 2)) {

@@ -1345,3 +1345,48 @@ def test_conv_x3_small_maps(shape):
     wv = (wh + (conv.weight.detach() - wh).to(torch.bfloat16).float()).double()
     ref = extra(F.conv2d(xv, wv, None, 1, (r // 2, s_ // 2))).permute(0, 2, 3, 1)
     assert (got.double() - ref).abs().max().item() <= 4e-5 * ref.abs().max().item()
+
+
+# k_conv_halo_p: the persistent 128-channel tile (several rounds of 14 x 14 tiles per launch): (N, H, W) with >= 512 tiles --
+# four tiles per image, ragged tiles (27 x 40: 6 per image), more tiles than twice the workgroups
+@pytest.mark.parametrize("shape", [(130, 28, 28), (90, 27, 40), (260, 28, 28)])
+def test_conv_halo_persistent_128_channel_tile(shape, monkeypatch):
+    """Forward + accumulator-mode statistics and backward-data + fused BatchNorm sums on the persistent kernel: outputs
+    bit-identical to the one-tile-per-workgroup kernel (same per-tile arithmetic), sums equal to f32 rounding (the tiles are
+    added in another order), both against f64 torch (backbones/frb/iresnet.py:56-67, layer2's 128-channel blocks)."""
+    n, h, w = shape
+    c = 128
+    g = torch.Generator().manual_seed(n + h)
+    x = torch.randn(n, c, h, w, generator=g).bfloat16().float()
+    wt = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5).bfloat16().float()
+    xd = ops.to_nhwc(x.cuda(), _lib.BF16)
+    wp = ops.pack_weight(wt.cuda(), False, c, 0, _lib.BF16)
+    wpt = ops.pack_weight(wt.cuda(), True, c, 0, _lib.BF16)
+    dy = torch.randn(n, c, h, w, generator=g).bfloat16().float()
+    dyd = ops.to_nhwc(dy.cuda(), _lib.BF16)
+    bnx = torch.randn(n, h, w, c, generator=g).bfloat16().cuda()
+    coef = (torch.rand(4, c, generator=g) + 0.5).cuda()
+    alpha = torch.full((c,), 0.25, device="cuda")
+
+    def run():
+        acc = ops.stats_acc(c, xd.device)
+        y = torch.empty(n, h, w, c, dtype=torch.bfloat16, device="cuda")
+        _lib.call("msml_conv2d_acc", xd, c, None, 0, wp, wp.shape[0], None, y, c, acc, n, h, w, h, w, 3, 3, 1, 1, 1, 0,
+                  _lib.BF16, _lib.BF16)
+        dx, bacc = ops.conv_dgrad_bnbwd(dyd, wpt, c, 3, 3, 1, 1, 1, h, w, bnx, coef, alpha)
+        torch.cuda.synchronize()
+        return y, acc.clone(), dx, bacc.clone()
+
+    y1, a1, dx1, b1 = run()
+    monkeypatch.setenv("MSML_HALO_PERSIST", "0")
+    y0, a0, dx0, b0 = run()
+    monkeypatch.delenv("MSML_HALO_PERSIST")
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    assert torch.allclose(a1.sum(0), a0.sum(0), rtol=1e-5, atol=1e-5 * a0.sum(0).abs().max().item())
+    assert torch.allclose(b1.sum(0), b0.sum(0), rtol=1e-5, atol=1e-5 * b0.sum(0).abs().max().item())
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    got = ops.to_nchw(y1, c).cpu().double()
+    assert (got - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+    assert torch.allclose(a1.sum(0)[0].cpu(), ref.sum((0, 2, 3)), rtol=0, atol=1e-3 * ref.abs().max().item() * (n * h * w) ** 0.5)
+    dref = F.conv_transpose2d(dy.double(), wt.double(), None, 1, 1)
+    assert (ops.to_nchw(dx1, c).cpu().double() - dref).abs().max().item() <= 1.5e-2 * dref.abs().max().item()
