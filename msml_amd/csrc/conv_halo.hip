@@ -239,6 +239,11 @@ k_conv_halo(const ConvHaloArgs p) {
     __syncthreads();
   }
   int cs = 0, tr = 0, ts = 0;                          // slab, tap row / column of stage q
+#if defined(HALO_PRIO)
+  // (experiment: one static priority for half of the waves -- the two waves of a SIMD otherwise run their MFMA phases in
+  // lockstep, sharing the pipe, and then wait / request together with the pipe idle)
+  if (HALO_PRIO == 1 ? (wave >= 4) : (wave < 4)) __builtin_amdgcn_s_setprio(1);
+#endif
   u32x4 a[2][MTW], b[2];
 #ifdef HALO_ABLATE_READS
   u32x4 a16x[2][MTW], b16x[2][2];                      // (ablation build: fragments read once, reused by every stage)
@@ -688,6 +693,24 @@ k_conv_halo(const ConvHaloArgs p) {
 // Same tiling, fragment maps and per-tile arithmetic as k_conv_halo<128, 2, FUSE, ..., M16>: outputs are bit-identical,
 // the sums differ in the order the tiles are added.  Plain forward (+ accumulator-mode statistics) and backward-data with
 // the fused BatchNorm sums (accumulator mode; register layout of -DHALO_FDIR); coutp == 128.
+#ifdef HALO_TRACE
+// (-DHALO_TRACE, tools/halo_trace.py: wave `HALO_TRACE_WAVE` of workgroup 0 stamps s_memrealtime at the points of every stage)
+__device__ unsigned long long g_halo_trace[8192];
+extern "C" int msml_halo_trace_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_halo_trace), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#define HALO_STAMP(k)                                                                           \
+  do {                                                                                          \
+    if (blockIdx.x == 0 && wave == HALO_TRACE_WAVE && lane == 0 && tix < 8192 - 8)              \
+      g_halo_trace[tix++] = ((unsigned long long)(k) << 56) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffffull); \
+  } while (0)
+#ifndef HALO_TRACE_WAVE
+#define HALO_TRACE_WAVE 0
+#endif
+#else
+#define HALO_STAMP(k)
+#endif
+
 template <bool FUSE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_bytes) {
@@ -776,8 +799,18 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
   issue_a(aoff, 0, 0);
   issue_b(0, 0, 0);
   __syncthreads();                                     // (drains vmcnt first)
+#if defined(HALO_PRIO)
+  if (HALO_PRIO == 1 ? (wave >= 4) : (wave < 4)) __builtin_amdgcn_s_setprio(1);
+#endif
   int gs = 0, gq = 0;                                  // running slab / stage counters: image buffer gs & 1, weight slot gq & 1
   bool first = true;
+#ifdef HALO_TRACE
+  int tix = 0;
+#endif
+  HALO_STAMP(9);
+#ifdef HALO_TRACE
+  if (wave == 0 && lane == 0) g_halo_trace[4096 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // every workgroup: start ...
+#endif
   for (; tile < ntiles; tile += gridDim.x) {
     const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
     const int y0 = ty * TH, x0 = (trem - ty * p.tpx) * TW;
@@ -794,6 +827,7 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
       int ncs = cs, ntr = tr, nts = ts + 1;
       if (nts == 3) { nts = 0; ntr++; }
       if (ntr == 3) { ntr = 0; ncs++; }
+      HALO_STAMP(1);
       // this wave's weights of stage q have landed.  Stage 0 of a later tile: they were requested BEFORE the previous
       // tile's epilogue, whose NG stores (always issued, out of range when masked) are the only younger operations.
       // (Also requesting stage 1's weights before the epilogue, so that stage 1 does not wait for the stores to be
@@ -804,6 +838,7 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
       if (q == 0 && !first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+      HALO_STAMP(2);
       if (q + 1 < nstage) issue_b(ncs, ntr * 3 + nts, (gq + 1) & 1);
       else issue_b(0, 0, (gq + 1) & 1);                // the next tile's first stage (past the end: a harmless re-read)
       if ((tr | ts) == 0) {                            // first tap of a slab: the next slab's image, this tile's or the next one's
@@ -811,6 +846,7 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
         else issue_a(aoffn, 0, (gs + 1) & 1);
       }
       __builtin_amdgcn_sched_barrier(0);
+      HALO_STAMP(3);
       const int r = p.flip ? 2 - tr : tr, s = p.flip ? 2 - ts : ts;
       const int arow = l16 + s, asw = skey(arow);
       const char* Arow = As + (gs & 1) * ABYTES + (((r << PL2) + i0 * 32) * 128) + arow * 128;
@@ -847,9 +883,11 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
           }
         __builtin_amdgcn_sched_barrier(0);
       }
+      HALO_STAMP(4);
       if (ncs != cs) {                                 // slab switch (also the tile's end): the next image has landed
         __syncthreads();                               // everywhere, and nobody reads the buffer the one after overwrites
         gs++;
+        HALO_STAMP(5);
       }
       cs = ncs; tr = ntr; ts = nts;
     }
@@ -899,10 +937,14 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
     }
 #pragma unroll
     for (int i = 0; i < NAI; i++) aoff[i] = aoffn[i];
+    HALO_STAMP(6);
   }
   // ---- the workgroup's sums: the lanes that share a channel meet in LDS (every image / ring request has landed) --
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef HALO_TRACE
+  if (wave == 0 && lane == 0) g_halo_trace[4096 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();  // ... and end of its tiles
+#endif
   if (FUSE) {
     constexpr int G = 16 * 2;                          // lanes (mg, l16) share an 8-channel chunk
     float* red = reinterpret_cast<float*>(smem);
