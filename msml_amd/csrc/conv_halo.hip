@@ -54,6 +54,24 @@ struct ConvHaloArgs {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+#ifdef HALO_TRACE
+// (-DHALO_TRACE, tools/halo_trace.py: wave `HALO_TRACE_WAVE` of workgroup 0 stamps s_memrealtime at the points of every stage)
+__device__ unsigned long long g_halo_trace[8192];
+extern "C" int msml_halo_trace_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_halo_trace), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#define HALO_STAMP(k)                                                                           \
+  do {                                                                                          \
+    if (blockIdx.x == 0 && wave == HALO_TRACE_WAVE && lane == 0 && tix < 8192 - 8)              \
+      g_halo_trace[tix++] = ((unsigned long long)(k) << 56) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffffull); \
+  } while (0)
+#ifndef HALO_TRACE_WAVE
+#define HALO_TRACE_WAVE 0
+#endif
+#else
+#define HALO_STAMP(k)
+#endif
+
 // FUSE: backward-data launch with the fused BatchNorm backward-reduce (no bias / scale / PReLU /
 // residual / statistics in that case) -- a compile-time split keeps both epilogues in registers.
 // BN output channels per workgroup, NWM wave groups along the pixel rows: (256, 1) = 8 waves x
@@ -239,6 +257,10 @@ k_conv_halo(const ConvHaloArgs p) {
     __syncthreads();
   }
   int cs = 0, tr = 0, ts = 0;                          // slab, tap row / column of stage q
+#ifdef HALO_TRACE
+  int tix = 0;
+  if (wave == 0 && lane == 0) g_halo_trace[4096 + 2 * (blockIdx.x & 1023)] = __builtin_amdgcn_s_memrealtime();
+#endif
 #if defined(HALO_PRIO)
   // (experiment: one static priority for half of the waves -- the two waves of a SIMD otherwise run their MFMA phases in
   // lockstep, sharing the pipe, and then wait / request together with the pipe idle)
@@ -254,7 +276,9 @@ k_conv_halo(const ConvHaloArgs p) {
     if (ntr == 3) { ntr = 0; ncs++; }
     // this wave's weights of stage q (issued one stage ago) have landed; queue stage q + 1 and,
     // at the first tap of a slab, this wave's share of the next slab's image
+    HALO_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HALO_STAMP(2);
 #ifndef HALO_ABLATE_LOADS
     if (q + 1 < nstage) {
       issue_b(ncs, ntr * 3 + nts, (q + 1) & 1);
@@ -271,6 +295,7 @@ k_conv_halo(const ConvHaloArgs p) {
     if ((XF || XB) && tr == 0 && ts == (wave < 4 ? 1 : 2) && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
 #endif
     __builtin_amdgcn_sched_barrier(0);
+    HALO_STAMP(3);
 #ifndef HALO_ABLATE_COMPUTE
     const int r = p.flip ? 2 - tr : tr, s = p.flip ? 2 - ts : ts;
     if constexpr (M16) {
@@ -370,10 +395,15 @@ k_conv_halo(const ConvHaloArgs p) {
     }
     }
 #endif
-    if (ncs != cs && ncs < nslab) __syncthreads();     // slab switch: next image landed everywhere
+    HALO_STAMP(4);
+    if (ncs != cs && ncs < nslab) {
+      __syncthreads();                                 // slab switch: next image landed everywhere
+      HALO_STAMP(5);
+    }
     cs = ncs; tr = ntr; ts = nts;
   }
   __syncthreads();
+  HALO_STAMP(5);
 
   // ---------------- epilogue: affine / PReLU, BatchNorm partials, LDS transpose, 16-B stores -----
 #ifdef HALO_ABLATE_EPILOGUE
@@ -679,6 +709,10 @@ k_conv_halo(const ConvHaloArgs p) {
       for (int c = t; c < 2 * BN; c += NT)
         p.stats[((long)row * 2 + c / BN) * p.coutp + n0 + c % BN] = 0.f;
   }
+  HALO_STAMP(6);
+#ifdef HALO_TRACE
+  if (wave == 0 && lane == 0) g_halo_trace[4096 + 2 * (blockIdx.x & 1023) + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
 }
 
@@ -693,24 +727,6 @@ k_conv_halo(const ConvHaloArgs p) {
 // Same tiling, fragment maps and per-tile arithmetic as k_conv_halo<128, 2, FUSE, ..., M16>: outputs are bit-identical,
 // the sums differ in the order the tiles are added.  Plain forward (+ accumulator-mode statistics) and backward-data with
 // the fused BatchNorm sums (accumulator mode; register layout of -DHALO_FDIR); coutp == 128.
-#ifdef HALO_TRACE
-// (-DHALO_TRACE, tools/halo_trace.py: wave `HALO_TRACE_WAVE` of workgroup 0 stamps s_memrealtime at the points of every stage)
-__device__ unsigned long long g_halo_trace[8192];
-extern "C" int msml_halo_trace_read(unsigned long long* dst, int n) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_halo_trace), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
-}
-#define HALO_STAMP(k)                                                                           \
-  do {                                                                                          \
-    if (blockIdx.x == 0 && wave == HALO_TRACE_WAVE && lane == 0 && tix < 8192 - 8)              \
-      g_halo_trace[tix++] = ((unsigned long long)(k) << 56) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffffull); \
-  } while (0)
-#ifndef HALO_TRACE_WAVE
-#define HALO_TRACE_WAVE 0
-#endif
-#else
-#define HALO_STAMP(k)
-#endif
-
 template <bool FUSE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_bytes) {

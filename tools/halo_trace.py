@@ -13,7 +13,8 @@ from msml_amd import _lib, ops  # noqa: E402
 
 
 def main():
-    n, c, h = 256, 128, 28
+    c, h = (int(v) for v in (sys.argv[1:3] if len(sys.argv) > 2 else (128, 28)))
+    n = 256
     x = torch.randn(n, h, h, c, device="cuda").bfloat16()
     w = torch.randn(c, c, 3, 3, device="cuda") * 0.03
     wp = ops.pack_weight(w, False, c, 0, _lib.BF16)
