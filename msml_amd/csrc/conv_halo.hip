@@ -85,10 +85,18 @@ extern "C" int msml_halo_trace_read(unsigned long long* dst, int n) {
 // (MI355X_MICROARCH.md, DVFS give-back item 7).  Plain forward and FUSE launches only (no XF / X3).
 // XB: backward-data launch whose input is the BatchNorm backward of (in = dy, bin.x = the BatchNorm's saved input), applied
 // per slab in LDS from the producer's accumulated sums, written through to bin.store (M16 + FUSE instantiations only).
-template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false>
+// R15 (round 5, M16 kernels): the weight ring with a prefetch distance of 1.5 stages on the same 8 KB per wave.  A stage's
+// weights are two k-window halves [w][32 rows][64 B] (chunk c at c ^ ((row >> 2) & 3), the 64-B-row swizzle of
+// conv_line.hip); half w = 0 of stage s + 2 is requested in the MIDDLE of stage s (its slot is free once the w = 0 fragments
+// are in registers), half w = 1 of stage s + 1 at the start of stage s: two requests at a time, the mid-stage ones in the
+// shadow of the MFMAs, instead of four in front of every stage with all eight waves queueing on the CU's one path into LDS;
+// every wait is counted (s_waitcnt vmcnt(N) returns when all but the N youngest requests are done: N = 4, + 4 while a slab
+// image requested after the wanted half is still among them), and the image is requested after the mid-stage weights.
+template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false, bool R15 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo(const ConvHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!R15 || M16, "the half-stage ring rides on the 16x16x32 tiling");
   constexpr int PL2 = 4, PITCH = 16, MT = 7, KG = BN / 32, NW = KG * NWM, NT = NW * 64, BM = MT * 32;
   constexpr int TW = 14, TH = 14, HR = TH + 2, HPX = HR << PL2;
   constexpr int MTW = NWM == 1 ? MT : 4;               // accumulator tiles of one wave (at most)
@@ -208,6 +216,22 @@ k_conv_halo(const ConvHaloArgs p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(b + i * 1024), 16, boffg[i] + col, 0, 0, 0);
   };
 
+  // R15: half (tap, slab cs, window w) -> slot `buf`: two requests of 16 rows x 64 B
+  auto key2 = [](int row) { return (row >> 2) & 3; };
+  unsigned int boffh[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = i * 16 + (lane >> 2);
+    boffh[i] = (unsigned int)((n0 + kg * 32 + row) * p.Ktot) * 2u + (unsigned int)(((lane & 3) ^ key2(row)) * 16);
+  }
+  auto issue_h = [&](int cs_, int tap, int w, int buf) {
+    char* b = Bs + wave * 8192 + buf * 4096 + w * 2048;
+    const unsigned int col = (unsigned int)(tap * p.C + cs_ * 64 + w * 32) * 2u;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(b + i * 1024), 16, boffh[i] + col, 0, 0, 0);
+  };
+
   // D = W_frag x X_frag: accumulator rows = output channels, columns (lanes) = pixels, so a lane
   // ends up with 4 consecutive channels of one pixel per register quad (8-B LDS stores below)
   static_assert(!M16 || !X3, "the 16x16x32 variant serves the plain forward, FUSE and XF launches");
@@ -240,12 +264,19 @@ k_conv_halo(const ConvHaloArgs p) {
 #pragma unroll
     for (int w = 0; w < 2; w++) {
       const int row = 16 * g + l16;
-      bfr16[g][w] = wave * 8192 + row * 128 + (((4 * w + q16) ^ skey(row)) << 4);
+      bfr16[g][w] = R15 ? wave * 8192 + w * 2048 + row * 64 + ((q16 ^ key2(row)) << 4)
+                        : wave * 8192 + row * 128 + (((4 * w + q16) ^ skey(row)) << 4);
     }
 
   const int nslab = p.C >> 6, nstage = nslab * 9;
   issue_a(0, 0);
-  issue_b(0, 0, 0);
+  if constexpr (R15) {                                 // stage 0 whole, window 0 of stage 1 (stage q = slab q / 9, tap q % 9)
+    issue_h(0, 0, 0, 0);
+    issue_h(0, 0, 1, 0);
+    issue_h(0, 1, 0, 1);
+  } else {
+    issue_b(0, 0, 0);
+  }
   if (XF) {
     if (p.xin.acc) bn_in_fill_acc(p.xin, xtab, p.C, t, NT, blockIdx.x == 0 && blockIdx.y == 0);
     else bn_in_fill(p.xin, xtab, 0, p.C, t, NT);
@@ -267,6 +298,7 @@ k_conv_halo(const ConvHaloArgs p) {
   if (HALO_PRIO == 1 ? (wave >= 4) : (wave < 4)) __builtin_amdgcn_s_setprio(1);
 #endif
   u32x4 a[2][MTW], b[2];
+  int img_m1 = 0, img_m2 = 0;                          // R15: a slab image was requested in the middle of stage q - 1 / q - 2
 #ifdef HALO_ABLATE_READS
   u32x4 a16x[2][MTW], b16x[2][2];                      // (ablation build: fragments read once, reused by every stage)
 #endif
@@ -277,6 +309,19 @@ k_conv_halo(const ConvHaloArgs p) {
     // this wave's weights of stage q (issued one stage ago) have landed; queue stage q + 1 and,
     // at the first tap of a slab, this wave's share of the next slab's image
     HALO_STAMP(1);
+    if constexpr (R15) {
+      // window 0 of this stage (requested in the middle of stage q - 2); younger: window 1 of this stage, window 0 of the
+      // next one, and a slab image if one was requested in the middle of one of the last two stages
+      if (img_m1 | img_m2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      HALO_STAMP(2);
+      // window 1 of stage q + 1 (its slot: read last in stage q - 1); past the last stage: a harmless re-read that keeps
+      // the request pattern, and with it the counts, the same to the end
+      {
+        const int qn = q + 1 < nstage ? q + 1 : q;
+        issue_h(qn / 9, qn % 9, 1, (q + 1) & 1);
+      }
+    } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     HALO_STAMP(2);
 #ifndef HALO_ABLATE_LOADS
@@ -285,6 +330,7 @@ k_conv_halo(const ConvHaloArgs p) {
       if ((tr | ts) == 0 && cs + 1 < nslab) issue_a(cs + 1, (cs + 1) & 1);
     }
 #endif
+    }
     // (the image chunks requested one stage ago have landed for this wave: the wait above)
     // (round 5: waves 4-7, the SIMD partners of 0-3, transform one tap later -- one wave's VALU beside the other's MFMAs;
     // bit-identical, 128 @ 28x28 bn + conv 103.6 -> 101.8 us, the step 29.41 / 29.50 -> 29.36 / 29.39 ms on one box.
@@ -292,7 +338,12 @@ k_conv_halo(const ConvHaloArgs p) {
 #ifdef HALO_XF_NO_STAGGER
     if ((XF || XB) && tr == 0 && ts == 1 && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
 #else
-    if ((XF || XB) && tr == 0 && ts == (wave < 4 ? 1 : 2) && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
+    if constexpr (R15) {
+      // (the image was requested in the middle of tap 0: by tap 3 two waits with four requests to spare lie behind it)
+      if ((XF || XB) && tr == 1 && ts == (wave < 4 ? 0 : 1) && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
+    } else {
+      if ((XF || XB) && tr == 0 && ts == (wave < 4 ? 1 : 2) && cs + 1 < nslab) xform(cs + 1, (cs + 1) & 1);
+    }
 #endif
     __builtin_amdgcn_sched_barrier(0);
     HALO_STAMP(3);
@@ -326,6 +377,14 @@ k_conv_halo(const ConvHaloArgs p) {
 #pragma unroll
       for (int ph = 0; ph < 4; ph++) {
         const int cb = ph & 1, nb = cb ^ 1, w = ph >> 1, hf = ph & 1;
+        if constexpr (R15) {
+          if (ph == 1) {
+            // window 1 of this stage (requested at the start of stage q - 1); younger: window 0 of stage q + 1, the
+            // image of the middle of stage q - 1 (if any), window 1 of stage q + 1
+            if (img_m1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          }
+        }
 #ifndef HALO_ABLATE_READS
         if (ph + 1 < 4) {
           const int nw = (ph + 1) >> 1, nhf = (ph + 1) & 1;
@@ -349,6 +408,20 @@ k_conv_halo(const ConvHaloArgs p) {
                   __builtin_bit_cast(bf16x8, b16[w & 1][g]), __builtin_bit_cast(bf16x8, a16[cb][j]),
                   acc4[hf * NGH + j][g], 0, 0, 0);
           }
+        if constexpr (R15) {
+          if (ph == (wave < 4 ? 1 : 2)) {              // (the two waves of a SIMD one phase apart: one requests while the other computes)
+            // middle of the stage, behind the MFMAs just issued: window 0 of stage q + 2 into the slot whose fragments are
+            // in registers, then (first tap of a slab) the next slab's image
+            const int qn = q + 2 < nstage ? q + 2 : q;
+            issue_h(qn / 9, qn % 9, 0, q & 1);
+            img_m2 = img_m1;
+            img_m1 = 0;
+            if ((tr | ts) == 0 && cs + 1 < nslab) {
+              issue_a(cs + 1, (cs + 1) & 1);
+              img_m1 = 1;
+            }
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -397,7 +470,16 @@ k_conv_halo(const ConvHaloArgs p) {
 #endif
     HALO_STAMP(4);
     if (ncs != cs && ncs < nslab) {
-      __syncthreads();                                 // slab switch: next image landed everywhere
+      if constexpr (R15) {
+        // (no drain of the request queue: this wave's share of the next image was requested nine stages ago and the
+        // counted waits since have long covered it; what is in flight are the next stages' weights.  LDS traffic of the
+        // in-LDS BatchNorm is waited for, the barrier orders the rest)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      } else {
+        __syncthreads();                               // slab switch: next image landed everywhere
+      }
       HALO_STAMP(5);
     }
     cs = ncs; tr = ntr; ts = nts;
@@ -1001,7 +1083,7 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
 #endif
 }
 
-template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false>
+template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false, bool R15 = false>
 static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;      // two halo images + eight private weight rings
   size_t olds = (size_t)224 * (BN + 8) * 2;
@@ -1010,11 +1092,11 @@ static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   if (XB) lds += 7 * 512 * sizeof(float);              // backward coefficient table, C <= 512
   static std::once_flag attr_once;                     // (per template instantiation; launches come from
   std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB, R15>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   dim3 grid(a.N * a.tpy * a.tpx, a.coutp / BN);
-  k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB><<<grid, dim3(512), lds, st>>>(a);
+  k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB, R15><<<grid, dim3(512), lds, st>>>(a);
 }
 
 static int halo_num_cus() {
@@ -1115,15 +1197,22 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
     }
     return true;
   }
+  // the half-stage weight ring (template parameter R15) on the 256-channel tile; MSML_HALO_R15=0 (read per call: the tests
+  // compare the two): the two-slot ring with full waits
+  const char* r15e = getenv("MSML_HALO_R15");
+  const bool r15 = r15e != nullptr && atoi(r15e) != 0;
   if (m16 && !x3 && (wide || m16 >= 2)) {
     if (xin) {                           // (same tiling as the plain launch: the two stay bit-identical)
-      if (wide) launch_halo<256, 1, false, true, false, true>(a, st);
+      if (wide && r15) launch_halo<256, 1, false, true, false, true, false, true>(a, st);
+      else if (wide) launch_halo<256, 1, false, true, false, true>(a, st);
       else launch_halo<128, 2, false, true, false, true>(a, st);
     } else if (bnb) {
-      if (wide) launch_halo<256, 1, true, false, false, true>(a, st);
+      if (wide && r15) launch_halo<256, 1, true, false, false, true, false, true>(a, st);
+      else if (wide) launch_halo<256, 1, true, false, false, true>(a, st);
       else launch_halo<128, 2, true, false, false, true>(a, st);
     } else {
-      if (wide) launch_halo<256, 1, false, false, false, true>(a, st);
+      if (wide && r15) launch_halo<256, 1, false, false, false, true, false, true>(a, st);
+      else if (wide) launch_halo<256, 1, false, false, false, true>(a, st);
       else launch_halo<128, 2, false, false, false, true>(a, st);
     }
     return true;
