@@ -308,6 +308,11 @@ k_conv_halo(const ConvHaloArgs p) {
     if (ntr == 3) { ntr = 0; ncs++; }
     // this wave's weights of stage q (issued one stage ago) have landed; queue stage q + 1 and,
     // at the first tap of a slab, this wave's share of the next slab's image
+#ifdef HALO_SKEW
+    // (experiment: the second wave of every SIMD half a stage behind the first, re-established after every slab-switch
+    // barrier -- while one waits for its weights and requests the next ones the other is in its MFMA phase)
+    if (wave >= 4 && (tr | ts) == 0) __builtin_amdgcn_s_sleep(HALO_SKEW);
+#endif
     HALO_STAMP(1);
     if constexpr (R15) {
       // window 0 of this stage (requested in the middle of stage q - 2); younger: window 1 of this stage, window 0 of the
