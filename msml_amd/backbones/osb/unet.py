@@ -32,7 +32,8 @@ class _GlobalConvModule(nn.Module):
             # x feeds both branches: their two input gradients meet in conv_l1's backward-data epilogue
             xl, _, x = conv(self.conv_l1, x, tee=True)
         else:
-            xl, _ = conv(self.conv_l1, x)
+            xa, x = Fh.fanout2(x)
+            xl, _ = conv(self.conv_l1, xa)
         xl, _ = conv(self.conv_l2, xl)
         xr, _ = conv(self.conv_r1, x)
         xr, _ = conv(self.conv_r2, xr)
@@ -70,17 +71,18 @@ class Unet(nn.Module):
         self.s = s
 
     def forward(self, x):
-        x0 = conv_bn(self.conv1, self.bn1, x, prelu=self.prelu)
-        x1 = self.layer1(x0)
-        x2 = self.layer2(x1)
-        x3 = self.layer3(x2)
+        # (every encoder output has two consumers, the next stage and a GCM: Fh.fanout2 sums their gradients)
+        x0, x0g = Fh.fanout2(conv_bn(self.conv1, self.bn1, x, prelu=self.prelu))
+        x1, x1g = Fh.fanout2(self.layer1(x0))
+        x2, x2g = Fh.fanout2(self.layer2(x1))
+        x3, x3g = Fh.fanout2(self.layer3(x2))
         x4 = self.layer4(x3)
         xx = Fh.bn_act(x4, None, self.bn2)
         seg0, _ = conv(self.deconv1, self.gcm1(xx))
-        seg1, _ = conv(self.deconv2, seg0, self.gcm2(x3), c1=self.s)
-        seg2, _ = conv(self.deconv3, seg1, self.gcm3(x2), c1=self.s)
-        seg3, _ = conv(self.deconv4, seg2, self.gcm4(x1), c1=self.s)
-        seg5_, _ = conv(self.deconv5, seg3, self.gcm5(x0), c1=self.s)
+        seg1, _ = conv(self.deconv2, seg0, self.gcm2(x3g), c1=self.s)
+        seg2, _ = conv(self.deconv3, seg1, self.gcm3(x2g), c1=self.s)
+        seg3, _ = conv(self.deconv4, seg2, self.gcm4(x1g), c1=self.s)
+        seg5_, _ = conv(self.deconv5, seg3, self.gcm5(x0g), c1=self.s)
         seg5 = Fh.dap(seg5_)
         return [seg0.detach(), seg1.detach(), seg2.detach(), seg3.detach(), seg5]
 

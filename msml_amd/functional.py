@@ -400,6 +400,37 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
+class _FanOut2(torch.autograd.Function):
+    """A tensor with two consumers (the OSB's encoder outputs feed the next stage AND a GCM, backbones/osb/unet.py:205-226;
+    a GCM input feeds both of its branches, :29-38): the two gradients are summed by msml_add on the backward's stream
+    instead of by the autograd engine's own element-wise add."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        ga, gb = ga.contiguous(), gb.contiguous()
+        out = torch.empty_like(ga)
+        call("msml_add", ga, gb, out, out.numel(), DTYPE_OF[ga.dtype])
+        return out
+
+
+def fanout2(x):
+    """(x, x) for a tensor that two branches consume; with autograd on, their gradients meet in msml_add."""
+    if (torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad and x.is_cuda
+            and x.dtype in DTYPE_OF):
+        a, b = _FanOut2.apply(x)
+        for k in ("_msml_stats", "_msml_bn3"):          # (what a producer attached for a following IBasicBlock: the first
+            if k in x.__dict__:                         # branch is the one that continues the backbone)
+                a.__dict__[k] = x.__dict__[k]
+        return a, b
+    return x, x
+
+
 class _Dap(torch.autograd.Function):
     """NHWC 18-channel map -> final_seg NCHW f32 (N, 2, H, W)."""
 
