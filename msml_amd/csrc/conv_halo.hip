@@ -1114,6 +1114,24 @@ static int halo_num_cus() {
   return n;
 }
 
+// Shapes of the persistent 128-channel tile (k_conv_halo_p): 128 output channels, 64 k input channels (ONE 64-channel slab
+// included: 64 -> 128 @ 56x56, conv1 of the first block of layer2, backbones/frb/iresnet.py:166-170 -- the nine-stage K loop
+// whose prologue and epilogue ruled the one-tile kernel out runs back to back there), at least two rounds of tiles.
+// MSML_HALO_PERSIST=0 / MSML_HALO_NO_ONE_SLAB=1 (read per call: the tests compare): off / 128 input channels and more only.
+int msml_conv_halo_persist_shape(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                                 int pad_h, int pad_w) {
+  const char* pe = getenv("MSML_HALO_PERSIST");
+  if (pe != nullptr && atoi(pe) == 0) return 0;
+  if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return 0;
+  if (coutp != 128 || kop < coutp || c0p % 64 != 0 || c0p < 64) return 0;
+  if (c0p == 64 && getenv("MSML_HALO_NO_ONE_SLAB") != nullptr) return 0;
+  const long tiles = (long)N * cdiv(H, 14) * cdiv(W, 14);
+  if (tiles < 2L * halo_num_cus() || (long)N * H * W * 10 < tiles * 224 * 7) return 0;
+  if ((long)N * H * W * c0p * 2 >= 0x70000000L || (long)N * H * W * 128 * 2 >= 0x70000000L || (long)kop * 9 * c0p * 2 >= 0x70000000L)
+    return 0;
+  return 1;
+}
+
 // Shape test shared by the dispatch and by msml_conv2d_kernel (the name query).
 bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                             int stride, int pad_h, int pad_w, bool want_stats) {
@@ -1139,7 +1157,11 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
                              int stride, int pad_h, int pad_w, int transposed, hipStream_t st,
                              const float* scale, const float* alpha, const void* residual, int res_first,
                              const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin, int x3, const BnBwdIn* bin) {
-  if (!msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
+  static const int m16_ = getenv("MSML_HALO_M16") ? atoi(getenv("MSML_HALO_M16")) : 2;
+  const bool pshape = m16_ >= 2 && !x3 && !xin && !bin && !bias && !scale && !alpha && !residual &&
+                      (!stats || msml_tl_stats_acc) && (!bnb || bnb->acc) &&
+                      msml_conv_halo_persist_shape(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) != 0;
+  if (!pshape && !msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
     return false;
   if (bin && (!bnb || !transposed || x3 || xin || c0p > 512)) return false;
   if (x3 && (bnb || xin || stats || transposed)) return false;
@@ -1176,14 +1198,8 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
     else launch_halo<128, 2, true, false, false, true, true>(a, st);
     return true;
   }
-  // 128-channel tile, several rounds of tiles per launch (128 -> 128 @ 28x28, 56x56): the persistent kernel.
-  // MSML_HALO_PERSIST=0: one tile per workgroup as before
-  // (read per call: the tests compare the two)
-  const char* pe = getenv("MSML_HALO_PERSIST");
-  const bool persist = pe == nullptr || atoi(pe) != 0;
-  if (persist && m16 >= 2 && !wide && coutp == 128 && !x3 && !xin && !bin && !bias && !scale && !alpha && !residual &&
-      tiles >= 2L * halo_num_cus() && (!stats || a.stats_acc) && (!bnb || bnb->acc) &&
-      (long)N * H * W * 128 * 2 < 0x70000000L) {
+  // 128-channel tile, several rounds of tiles per launch (128 -> 128 @ 28x28, 64 -> 128 @ 56x56): the persistent kernel
+  if (pshape) {
     const size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;
     const int grid = halo_num_cus();
     const unsigned int out_bytes = (unsigned int)((long)N * H * W * 128 * 2);

@@ -550,6 +550,8 @@ int msml_conv_halo2_tiling(int c0p, int kop, int coutp, int N, int H, int W, int
                            int pad_h, int pad_w, int transposed, int x3);
 int msml_conv_s2r_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride, int pad_h,
                           int pad_w, int transposed);
+int msml_conv_halo_persist_shape(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
+                                 int pad_h, int pad_w);
 bool msml_conv_halo_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                             int stride, int pad_h, int pad_w, bool want_stats);
 bool msml_conv_ws_applies(int c0p, int kop, int coutp, int N, int H, int W, int P, int Q, int R, int S,
@@ -714,6 +716,9 @@ extern "C" const char* msml_conv2d_kernel(int c0p, int c1p, int coutp, int N, in
   if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
       msml_conv_ws_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
     return "k_conv_ws<64 -> 64 channels, weights resident, persistent>";    // (or k_conv_s2r<stride 1> without fused sums / residual)
+  if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
+      msml_conv_halo_persist_shape(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w))
+    return "k_conv_halo_p<14x14 px x 128 ch, persistent>";       // (training launches: no affine epilogue, accumulator-mode sums)
   if (fast && c1p == 0 && out_dtype == MSML_BF16 &&
       msml_conv_halo_applies(c0p, cdiv(coutp, bn) * bn, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
     return coutp % 256 == 0 ? "k_conv_halo<14x14 px x 256 ch, 8 waves>" : "k_conv_halo<14x14 px x 128 ch, 8 waves>";

@@ -1349,20 +1349,23 @@ def test_conv_x3_small_maps(shape):
 
 # k_conv_halo_p: the persistent 128-channel tile (several rounds of 14 x 14 tiles per launch): (N, H, W) with >= 512 tiles --
 # four tiles per image, ragged tiles (27 x 40: 6 per image), more tiles than twice the workgroups
-@pytest.mark.parametrize("shape", [(130, 28, 28), (90, 27, 40), (260, 28, 28)])
+@pytest.mark.parametrize("shape", [(130, 28, 28), (90, 27, 40), (260, 28, 28), (40, 56, 56, 64), (140, 28, 28, 256)])
 def test_conv_halo_persistent_128_channel_tile(shape, monkeypatch):
     """Forward + accumulator-mode statistics and backward-data + fused BatchNorm sums on the persistent kernel: outputs
     bit-identical to the one-tile-per-workgroup kernel (same per-tile arithmetic), sums equal to f32 rounding (the tiles are
     added in another order), both against f64 torch (backbones/frb/iresnet.py:56-67, layer2's 128-channel blocks)."""
-    n, h, w = shape
+    n, h, w = shape[:3]
+    cin = shape[3] if len(shape) > 3 else 128         # (64: one slab per tile; 256: four)
     c = 128
-    g = torch.Generator().manual_seed(n + h)
-    x = torch.randn(n, c, h, w, generator=g).bfloat16().float()
-    wt = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5).bfloat16().float()
+    g = torch.Generator().manual_seed(n + h + cin)
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16().float()
+    wt = (torch.randn(c, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).bfloat16().float()
     xd = ops.to_nhwc(x.cuda(), _lib.BF16)
-    wp = ops.pack_weight(wt.cuda(), False, c, 0, _lib.BF16)
-    wpt = ops.pack_weight(wt.cuda(), True, c, 0, _lib.BF16)
-    dy = torch.randn(n, c, h, w, generator=g).bfloat16().float()
+    wp = ops.pack_weight(wt.cuda(), False, cin, 0, _lib.BF16)
+    # the backward-data launch of the test is a 128-output-channel conv of its own: dY with `cin` channels -> dX with 128
+    wt2 = (torch.randn(cin, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5).bfloat16().float()
+    wpt = ops.pack_weight(wt2.cuda(), True, cin, 0, _lib.BF16)
+    dy = torch.randn(n, cin, h, w, generator=g).bfloat16().float()
     dyd = ops.to_nhwc(dy.cuda(), _lib.BF16)
     bnx = torch.randn(n, h, w, c, generator=g).bfloat16().cuda()
     coef = (torch.rand(4, c, generator=g) + 0.5).cuda()
@@ -1371,7 +1374,7 @@ def test_conv_halo_persistent_128_channel_tile(shape, monkeypatch):
     def run():
         acc = ops.stats_acc(c, xd.device)
         y = torch.empty(n, h, w, c, dtype=torch.bfloat16, device="cuda")
-        _lib.call("msml_conv2d_acc", xd, c, None, 0, wp, wp.shape[0], None, y, c, acc, n, h, w, h, w, 3, 3, 1, 1, 1, 0,
+        _lib.call("msml_conv2d_acc", xd, cin, None, 0, wp, wp.shape[0], None, y, c, acc, n, h, w, h, w, 3, 3, 1, 1, 1, 0,
                   _lib.BF16, _lib.BF16)
         dx, bacc = ops.conv_dgrad_bnbwd(dyd, wpt, c, 3, 3, 1, 1, 1, h, w, bnx, coef, alpha)
         torch.cuda.synchronize()
@@ -1388,5 +1391,5 @@ def test_conv_halo_persistent_128_channel_tile(shape, monkeypatch):
     got = ops.to_nchw(y1, c).cpu().double()
     assert (got - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
     assert torch.allclose(a1.sum(0)[0].cpu(), ref.sum((0, 2, 3)), rtol=0, atol=1e-3 * ref.abs().max().item() * (n * h * w) ** 0.5)
-    dref = F.conv_transpose2d(dy.double(), wt.double(), None, 1, 1)
+    dref = F.conv_transpose2d(dy.double(), wt2.double(), None, 1, 1)
     assert (ops.to_nchw(dx1, c).cpu().double() - dref).abs().max().item() <= 1.5e-2 * dref.abs().max().item()
