@@ -712,7 +712,14 @@ def test_bn_backward_row_and_accumulator_protocols_agree(n, k, c, h, stride, fol
         out[acc] = (dxc, dx, pg, partial.double().sum(0))
     a, b = out[True], out[False]
     assert torch.equal(a[0], b[0])
-    assert torch.equal(a[3], b[3])                     # the three sums, in f64: identical totals
+    # the persistent 128-channel tile (accumulator mode only) adds the tiles of a workgroup in f32 before its f64 atomics:
+    # its totals equal the row protocol's to f32 rounding, not bit for bit
+    name = _lib.value("msml_conv2d_kernel", k, 0, c, n, ho, ho, h, h, 3, 3, stride, 1, 1, 1, _lib.BF16, _lib.BF16, 0).decode()
+    if "k_conv_halo_p" in name:
+        assert torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-5 * b[3].abs().max().item())
+        fold = True
+    else:
+        assert torch.equal(a[3], b[3])                 # the three sums, in f64: identical totals
     if not fold:
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     else:
