@@ -462,6 +462,93 @@ def timed(fn, steps, warm):
     return (time.perf_counter() - t0) / steps
 
 
+def timed_throttled(fn, steps, warm):
+    """timed() with at most two steps in flight (as the headline's loop: a host that runs many steps ahead pins every
+    step's activations until the caching allocator starts returning memory to the driver)."""
+    inflight = []
+
+    def one():
+        if len(inflight) >= 2:
+            inflight.pop(0).synchronize()
+        fn()
+        ev = torch.cuda.Event()
+        ev.record()
+        inflight.append(ev)
+    for _ in range(warm):
+        one()
+    torch.cuda.synchronize()
+    inflight.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def train_mode(a, rank, local_rank, steps, warm, what):
+    """One more BASELINE.json training configuration on the line (`modes`): the SAME step as the headline (Trainer.step)
+    on another network / head size, issued eagerly with the side streams AND as one hipGraph replay; `value` is the
+    faster of the two (as --launch auto), both times are reported, plus the sum of the step's kernel-event times on one
+    stream (what the GPU needs when nothing overlaps and nothing waits for the host) and the whole-step roofline fraction."""
+    import gc
+    from msml_amd import ops
+    r = Trainer(a, rank, local_rank, 1)
+    side, osb = torch.cuda.Stream(), torch.cuda.Stream()
+    ops.WGRAD_STREAM, ops.OSB_STREAM = side, osb
+    t_eager = timed_throttled(r.step, steps, warm)
+    t_graph, graph = None, None
+    try:
+        s0 = torch.cuda.Stream()
+        s0.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s0):
+            r.step()
+        torch.cuda.current_stream().wait_stream(s0)
+        torch.cuda.synchronize()
+        static = tuple(t.clone() for t in r.next_batch())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            r.step(static)
+
+        def replay():
+            for dst, src in zip(static, r.next_batch()):
+                dst.copy_(src)
+            graph.replay()
+        t_graph = timed_throttled(replay, steps, 3)
+    except Exception as e:                                  # pragma: no cover (diagnostic path)
+        print("train_mode: graph capture failed: %r" % (e,), file=sys.stderr)
+        torch.cuda.synchronize()
+    graph = None
+    gc.collect()
+    # kernel time of one step, one stream, an event pair around every instrumented launch
+    ops.WGRAD_STREAM = ops.OSB_STREAM = None
+    r.step()
+    ops.PROFILE.start()
+    for _ in range(2):
+        r.step()
+    prof = ops.PROFILE.stop()
+    k_ms = sum(v["ms"] for v in prof.values()) / 2
+    dt = min(t for t in (t_eager, t_graph) if t is not None)
+    value = a.batch / dt
+    f_img = F_FWD_GF[a.frb] * 3.0
+    out = {"value": round(value, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 2), "batch": a.batch,
+           "launch": "hipGraph replay" if (t_graph is not None and t_graph <= t_eager) else "eager, side streams",
+           "ms_per_step_eager": round(t_eager * 1e3, 2),
+           "ms_per_step_graph": None if t_graph is None else round(t_graph * 1e3, 2),
+           "kernel_event_ms_per_step": round(k_ms, 2),
+           "roofline_step": {"bound": "mfma", "achieved": round(value * f_img / 1e3, 2), "peak": PEAK_TFLOPS["bf16"],
+                             "unit": "TFLOP/s", "frac": round(value * f_img / 1e3 / PEAK_TFLOPS["bf16"], 4),
+                             "gflop_per_image": round(f_img, 3)},
+           "what": what}
+    if r.emu > 1:
+        out["head"] = "rank 0 of a %d-way class-parallel %d-id head: %d local rows x %d gathered feature rows, collectives omitted" \
+            % (r.emu, a.classes, a.classes // r.emu, a.batch * r.emu)
+        out["max_allocated_gb"] = round(torch.cuda.max_memory_allocated() / 2.0 ** 30, 2)
+    del r
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def extra_modes(args, rank, local_rank):
     """Short measurements of the other precision modes on the same workload (rank 0, N == 1), so that
     every mode that meets the reference's tolerances has a number from the same run as the headline:
@@ -496,6 +583,17 @@ def extra_modes(args, rank, local_rank):
     del r
     gc.collect()
     torch.cuda.empty_cache()
+    # BASELINE.json configs[1] and configs[3]: the same training step on the other two networks
+    a = copy.copy(args)
+    a.frb, a.classes, a.batch, a.emulate_world, a.data = "iresnet18", 10000, 128, 1, "resident"
+    out["train_config2"] = train_mode(a, rank, local_rank, 20, 8, "BASELINE.json configs[1]: ires18-MSML + ArcFace 10 000-id "
+                                      "PartialFC, batch 128, bf16, 1 x MI355X -- fwd + bwd + clip + SGD")
+    a = copy.copy(args)
+    a.frb, a.classes, a.batch, a.emulate_world, a.data = "iresnet100", 2000000, 256, 8, "resident"
+    torch.cuda.reset_peak_memory_stats()
+    out["train_config4_shard"] = train_mode(a, rank, local_rank, 6, 4, "BASELINE.json configs[3] at its per-GPU size: ires100-"
+                                            "variant MSML + one of eight 250 000-row shards of a 2 000 000-id PartialFC, "
+                                            "batch 256 per GPU (2048 gathered feature rows), bf16")
     a = copy.copy(args)
     a.dtype, a.mode, a.precision = "f32", "train", None
     from msml_amd import ops
@@ -510,14 +608,29 @@ def extra_modes(args, rank, local_rank):
     return out
 
 
-def launch_ranks(n):
-    """Start `n` rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, one GPU
-    each), wait for all of them and return the exit code: 0 only if every rank exited 0.  stdout of rank 0 (the JSON
-    line) is passed through as the only stdout of this process; the other ranks' stdout goes to stderr.  A rank that
-    dies takes the others down (they would otherwise sit in a collective until the watchdog fires)."""
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, cut by a cgroup CPU quota when one is set (the GPU boxes
+    expose 256 logical CPUs to os.cpu_count() but grant a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and period > 0:
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def rank_env(n, environ, cpus=None):
+    """Environment shared by the n rank processes launch_ranks() starts (RANK / LOCAL_RANK are added per rank)."""
     import socket
-    import subprocess
-    env = dict(os.environ)
+    env = dict(environ)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     if "MASTER_PORT" not in env:
         with socket.socket() as sk:                       # a free port (closed again before the ranks bind it)
@@ -525,7 +638,20 @@ def launch_ranks(n):
             env["MASTER_PORT"] = str(sk.getsockname()[1])
     env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    # a rank is one Python thread issuing launches plus a few tiny CPU ops: its share of the USABLE CPUs, at most four OpenMP
+    # threads (cpu_count() // n handed every rank 32 threads on a 16-CPU share of a 256-CPU host)
+    cpus = usable_cpus() if cpus is None else cpus
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(4, cpus // n))))
+    return env
+
+
+def launch_ranks(n):
+    """Start `n` rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, one GPU
+    each), wait for all of them and return the exit code: 0 only if every rank exited 0.  stdout of rank 0 (the JSON
+    line) is passed through as the only stdout of this process; the other ranks' stdout goes to stderr.  A rank that
+    dies takes the others down (they would otherwise sit in a collective until the watchdog fires)."""
+    import subprocess
+    env = rank_env(n, os.environ)
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -563,6 +689,7 @@ def main():
         cpus = sorted(os.sched_getaffinity(0))[:args.cpu_share]
         os.sched_setaffinity(0, cpus)
         torch.set_num_threads(max(1, len(cpus)))
+        args.cpu_share = len(cpus)                      # (a box with fewer CPUs than asked for: report what was granted)
     if "WORLD_SIZE" in os.environ or args.gpus == 1:
         # stdout carries the JSON line and nothing else: keep the real stdout for it and point fd 1 at stderr, so that
         # whatever a library prints from C (gloo's "[Gloo] Rank 0 is connected to ...", ROCm notices) cannot land there
@@ -750,6 +877,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    if args.cpu_share > 0 and len(os.sched_getaffinity(0)) != args.cpu_share:
+        # (one row of profiles/r05_cpu_share.log reported cpu_share = 256 for a K = 1 run -- an unpinned run must
+        # never be reported as a pinned one)
+        raise SystemExit("bench.py: --cpu-share %d but the timed region ran with %d CPUs in the affinity mask"
+                         % (args.cpu_share, len(os.sched_getaffinity(0))))
     evs = step_events[-(args.steps + 1):]
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))
     median_ms = step_ms[len(step_ms) // 2] if step_ms else None

@@ -48,6 +48,11 @@ enum { MSML_ARITH_ADD = 0, MSML_ARITH_SUB = 1, MSML_ARITH_MUL = 2, MSML_ARITH_DI
 
 int msml_version(void);
 const char* msml_last_error(void);
+/* 1 when the library was built with -DMSML_EXPERIMENTS (tools/build_variant.py --all MSML_EXPERIMENTS): the measured-slower
+ * kernel variants of DESIGN.md section 8 are instantiated and their opt-in switches live (MSML_HALO_R15, MSML_BNBWD_IN,
+ * MSML_BNIN_ACC_WS, MSML_HALO_WGRAD_S2).  The shipped library returns 0: those entry points answer
+ * MSML_ERR_UNSUPPORTED / their *_applies queries 0. */
+int msml_has_experiments(void);
 /* Id of the graph capture `stream` is currently part of (hipStreamGetCaptureInfo; every stream forked into
  * one capture reports the same id), 0 when the stream is not capturing, negative on a HIP error.  The host
  * side keys per-capture scratch state on it (zeroed accumulator chunks: a second capture must not inherit the
@@ -549,7 +554,8 @@ int msml_bn_act_bwd_apply_next(const void* dy, const void* x, const float* scale
  * acc_in (double[8][2][c0p], the producer's sums) in the kernel prologue, the normalised input applied in LDS and written
  * to act_out (NHWC like in0; the weight gradient reads it), coef_out = float[4][c0p] (scale, shift, mean, invstd), running
  * statistics updated, the output's sums added to acc_out (zero-initialised double[8][2][coutp]).  Bit-identical to
- * msml_bn_fin_act_fwd + msml_conv2d_acc.  Shapes: msml_conv2d_bnin_acc_applies (the halo-tile conv). */
+ * msml_bn_fin_act_fwd + msml_conv2d_acc.  Shapes: msml_conv2d_bnin_acc_applies -- 1: served by the halo-tile conv, 2: by the
+ * weights-stationary 64-channel kernel (experiment builds only, msml_has_experiments), 0: not covered. */
 int msml_conv2d_bnin_acc_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
                                  int pad_h, int pad_w);
 int msml_conv2d_bnin_acc(const void* in0, int c0p, const double* acc_in, double count, const float* gamma,

@@ -1122,6 +1122,8 @@ int msml_conv_halo_persist_shape(int c0p, int kop, int coutp, int N, int H, int 
                                  int pad_h, int pad_w) {
   const char* pe = getenv("MSML_HALO_PERSIST");
   if (pe != nullptr && atoi(pe) == 0) return 0;
+  if (getenv("MSML_NO_HALO_CONV") != nullptr || getenv("MSML_HALO_WIDE_ONLY") != nullptr) return 0;   // (the halo conv's own
+  // off-switches cover this 128-channel instantiation too)
   if (R != 3 || S != 3 || stride != 1 || pad_h != 1 || pad_w != 1 || P != H || Q != W) return 0;
   if (coutp != 128 || kop < coutp || c0p % 64 != 0 || c0p < 64) return 0;
   if (c0p == 64 && getenv("MSML_HALO_NO_ONE_SLAB") != nullptr) return 0;
@@ -1194,9 +1196,13 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   // the variant to the 256-channel tile.
   static const int m16 = getenv("MSML_HALO_M16") ? atoi(getenv("MSML_HALO_M16")) : 2;
   if (bin) {                             // BatchNorm backward in the prologue: 16x16x32 FUSE instantiations only
+#ifdef MSML_EXPERIMENTS
     if (wide) launch_halo<256, 1, true, false, false, true, true>(a, st);
     else launch_halo<128, 2, true, false, false, true, true>(a, st);
     return true;
+#else
+    return false;                        // (measured slower: `XB` is instantiated in experiment builds only, tools/build_variant.py)
+#endif
   }
   // 128-channel tile, several rounds of tiles per launch (128 -> 128 @ 28x28, 64 -> 128 @ 56x56): the persistent kernel
   if (pshape) {
@@ -1220,20 +1226,26 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   }
   // the half-stage weight ring (template parameter R15) on the 256-channel tile; MSML_HALO_R15=0 (read per call: the tests
   // compare the two): the two-slot ring with full waits
+  // (experiment builds only, -DMSML_EXPERIMENTS: measured slower)
+#ifdef MSML_EXPERIMENTS
   const char* r15e = getenv("MSML_HALO_R15");
   const bool r15 = r15e != nullptr && atoi(r15e) != 0;
+  if (m16 && !x3 && wide && r15) {
+    if (xin) launch_halo<256, 1, false, true, false, true, false, true>(a, st);
+    else if (bnb) launch_halo<256, 1, true, false, false, true, false, true>(a, st);
+    else launch_halo<256, 1, false, false, false, true, false, true>(a, st);
+    return true;
+  }
+#endif
   if (m16 && !x3 && (wide || m16 >= 2)) {
     if (xin) {                           // (same tiling as the plain launch: the two stay bit-identical)
-      if (wide && r15) launch_halo<256, 1, false, true, false, true, false, true>(a, st);
-      else if (wide) launch_halo<256, 1, false, true, false, true>(a, st);
+      if (wide) launch_halo<256, 1, false, true, false, true>(a, st);
       else launch_halo<128, 2, false, true, false, true>(a, st);
     } else if (bnb) {
-      if (wide && r15) launch_halo<256, 1, true, false, false, true, false, true>(a, st);
-      else if (wide) launch_halo<256, 1, true, false, false, true>(a, st);
+      if (wide) launch_halo<256, 1, true, false, false, true>(a, st);
       else launch_halo<128, 2, true, false, false, true>(a, st);
     } else {
-      if (wide && r15) launch_halo<256, 1, false, false, false, true, false, true>(a, st);
-      else if (wide) launch_halo<256, 1, false, false, false, true>(a, st);
+      if (wide) launch_halo<256, 1, false, false, false, true>(a, st);
       else launch_halo<128, 2, false, false, false, true>(a, st);
     }
     return true;

@@ -577,9 +577,10 @@ extern "C" int msml_conv2d_bnin_applies(int c0p, int coutp, int N, int H, int W,
                                         int stride, int pad_h, int pad_w, int want_stats) {
   if (getenv("MSML_NO_FAST_CONV") || c0p > 1024 || (long)N * P * Q >= (1L << 24)) return 0;
   const int bn = msml_conv_tile_n(coutp), kop = cdiv(coutp, bn) * bn;
-  return (msml_conv_ws_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0) ||
-          msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0))
-             ? 1 : 0;
+#ifdef MSML_EXPERIMENTS      // (the weights-stationary kernel takes an input transform in experiment builds only)
+  if (msml_conv_ws_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0)) return 1;
+#endif
+  return msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, want_stats != 0) ? 1 : 0;
 }
 
 extern "C" int msml_conv2d_bnin(const void* in0, int c0p, const float* in_scale, const float* in_shift,
@@ -612,7 +613,9 @@ extern "C" int msml_conv2d_bnin_acc_applies(int c0p, int coutp, int N, int H, in
                                             int stride, int pad_h, int pad_w) {
   if (getenv("MSML_NO_FAST_CONV") || c0p > 1024 || c0p % 8 || 256 % (c0p / 8) || (long)N * P * Q >= (1L << 24)) return 0;
   const int bn = msml_conv_tile_n(coutp), kop = cdiv(coutp, bn) * bn;
+#ifdef MSML_EXPERIMENTS      // (the weights-stationary kernel's prologue transform measured slower: experiment builds only)
   if (msml_conv_ws_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, true)) return 2;
+#endif
   return msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, true) ? 1 : 0;
 }
 
@@ -657,6 +660,9 @@ extern "C" int msml_conv2d_bnin_acc(const void* in0, int c0p, const double* acc_
 // input channels (the LDS coefficient table), accumulator-mode sums on both BatchNorms.
 extern "C" int msml_conv2d_bnbwd_in_acc_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S,
                                                 int stride, int pad_h, int pad_w) {
+#ifndef MSML_EXPERIMENTS     // measured slower than the two launches: compiled into experiment builds only
+  return 0;
+#endif
   if (getenv("MSML_NO_FAST_CONV") || c0p > 512 || c0p % 8 || 256 % (c0p / 8) || coutp % 8 || 256 % (coutp / 8) ||
       (long)N * P * Q >= (1L << 24))
     return 0;

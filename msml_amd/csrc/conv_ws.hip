@@ -581,6 +581,9 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
     return false;
   if (bnb && (bias || scale || alpha || residual || stats)) return false;
   if (xin && (bnb || transposed)) return false;
+#ifndef MSML_EXPERIMENTS
+  if (xin) return false;       // (BatchNorm in this kernel's prologue measured slower, DESIGN section 8: experiment builds only)
+#endif
   ConvWsArgs a;
   a.tpy = cdiv(H, 14); a.tpx = cdiv(W, 14);
   a.ntiles = N * a.tpy * a.tpx;
@@ -603,8 +606,11 @@ bool msml_conv_ws_dispatch(const void* in0, int c0p, const void* wp, int kop, co
   // 112x112 forward 431 -> 385 us, @ 56x56 100 -> 93 us, the step 29.38 -> 29.17 / 29.26 ms (one box, twice): default;
   // MSML_WS_M16=0 restores the 32x32x16 kernels.
   static const bool m16 = !(getenv("MSML_WS_M16") && atoi(getenv("MSML_WS_M16")) == 0);
+#ifdef MSML_EXPERIMENTS
   if (xin) { if (m16) launch_ws<false, true, true>(a, st); else launch_ws<false, true>(a, st); }   // (same tiling as the plain launch)
-  else if (bnb) { if (m16) launch_ws<true, false, true>(a, st); else launch_ws<true>(a, st); }
+  else
+#endif
+  if (bnb) { if (m16) launch_ws<true, false, true>(a, st); else launch_ws<true>(a, st); }
   else { if (m16) launch_ws<false, false, true>(a, st); else launch_ws<false>(a, st); }
   return true;
 }

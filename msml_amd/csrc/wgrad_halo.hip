@@ -362,6 +362,9 @@ int msml_wgrad_halo_s2_splits(int up, int vp, int A, int Breal, int N, int H, in
   // Measured (round 5, tools/bench_conv.py --only wgrad, batch 256): NOT faster than the im2col kernel -- 64 @ 112 152 vs 153 us,
   // 128 @ 56 136 vs 124, 256 @ 28 110 vs 121: the four X planes are 64 KB of LDS fill per strip against 34 KB at stride 1, and
   // only 64-row tiles fit.  Opt-in (read per call, so that a test can switch it on): MSML_HALO_WGRAD_S2=1.
+#ifndef MSML_EXPERIMENTS
+  return 0;                    // (the S2 instantiation exists in experiment builds only: tools/build_variant.py --all MSML_EXPERIMENTS)
+#endif
   if (getenv("MSML_NO_HALO_WGRAD") != nullptr || getenv("MSML_HALO_WGRAD_S2") == nullptr) return 0;
   if (R != 3 || S != 3 || stride != 2 || pad_h != 1 || pad_w != 1 || (H & 1) || (W & 1) || P != H / 2 || Q != W / 2) return 0;
   if (up % 64 != 0 || vp % 64 != 0 || A != up || Breal != vp) return 0;
@@ -394,7 +397,12 @@ bool msml_wgrad_halo_s2_launch(const void* u, int up, const void* v, int vp, flo
   a.xin = BnIn{nullptr, nullptr, nullptr};
   const int tiles = (up / 64) * (vp / 64);
   a.remap = (getenv("MSML_WGRAD_HALO_NO_REMAP") == nullptr && tiles >= 4 && splits % 8 == 0) ? 1 : 0;
+#ifdef MSML_EXPERIMENTS
   wh_launch<64, false, false, true>(a, dim3(up / 64, vp / 64, splits), st);
+#else
+  (void)st;
+  return false;
+#endif
   return true;
 }
 

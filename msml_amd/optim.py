@@ -121,6 +121,11 @@ class FlatSGD:
         if self.flat_g.is_cuda:
             self.train_stream = torch.cuda.current_stream()   # the stream backward kernels are issued on
         self.grad_scale = 1.0
+        if getattr(self, "buckets", None) is not None and (self.reported or any(self.fired)):
+            # a backward pass that raised left reports behind: this step starts from a clean slate
+            self.pending = [b[2] for b in self.buckets]
+            self.fired = [False] * len(self.buckets)
+            self.reported = set()
         self.flat_g.zero_()
         base = self.flat_g.data_ptr()
         for p in self.params:        # re-attach the views if something replaced .grad
@@ -154,6 +159,8 @@ class FlatSGD:
             self.buckets.append([start, cur, count])
         self.pending = [b[2] for b in self.buckets]
         self.fired = [False] * len(self.buckets)
+        self.reported = set()
+        self.duplicate_reports = 0
         self.works = []
         self._half = []
         self.train_stream = torch.cuda.current_stream()     # refreshed by zero_grad()
@@ -197,6 +204,13 @@ class FlatSGD:
         bi = self.bucket_of.get(id(p))
         if bi is None or self.fired[bi]:
             return
+        # one report per parameter and step: a parameter whose module ran twice in the forward would report after its FIRST
+        # gradient kernel -- count it (tests assert zero) and never let it release the bucket early
+        if id(p) in self.reported:
+            self.duplicate_reports += 1
+            self.pending[bi] = max(self.pending[bi], 1) + (1 << 20)      # this bucket waits for all_reduce_grads()
+            return
+        self.reported.add(id(p))
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
             self._fire(bi)
@@ -230,6 +244,7 @@ class FlatSGD:
             self.grad_scale = 1.0 / self.ov_world     # applied by step() through the clip coefficient
             self.pending = [b[2] for b in self.buckets]
             self.fired = [False] * len(self.buckets)
+            self.reported = set()
             self.works = []
             return
         ops.wgrad_stream_join()

@@ -6,8 +6,8 @@ oracle/bf16_emul.py (plain PyTorch, no HIP code) against the f32 reference golde
 Needs neither the reference nor a GPU (the goldens it compares with were recorded from the reference by
 oracle/make_golden.py).  Keys: "<case>/loss_seg", "<case>/loss_cls", "<case>/gnorm" (relative errors),
 "<case>/grad/<parameter>" (norm-wise relative error of the picked gradient elements, clip factor of the golden
-applied exactly as tests/test_gpu_parity2.py does), "<case>/stat/<buffer>" -- each the MAXIMUM over five draws of
-the rounding noise (bf16_emul.GRID_SHIFT; the per-draw values are kept under "<case>/draw<u>/<parameter>").  The GPU tests derive their tolerances
+applied exactly as tests/test_gpu_parity2.py does), "<case>/stat/<buffer>" -- each the MAXIMUM over the draws (five; 32
+for the batch-4 cases) of the rounding noise (bf16_emul.GRID_SHIFT; the per-draw values are kept under "<case>/draw<u>/<parameter>").  The GPU tests derive their tolerances
 from these numbers (2 x the per-group maximum) instead of fitting them to the HIP path's own error.
 """
 import os
@@ -38,6 +38,14 @@ CASES = [  # (key, golden file, frb, batch, refinit)
 
 
 DRAWS = (0.0, 0.31, -0.27, 0.14, -0.43)      # quantiser grid shifts (bf16_emul._r): five draws of the rounding noise
+# Batch-4 cases (round 6, VERDICT r5 weak 1 / ADVICE r5): 32 draws on an even grid of shifts.  At batch 4 the draws of one
+# and the same step spread by 3-4 x in the head group (BatchNorm1d over four samples in front of an s = 64 head), so the
+# tests bound those cases at a FIXED percentile of the draws (tests/helpers.py: 2 x p90) instead of 3 x the median of five.
+DRAWS_B4 = tuple(round((i + 0.5) / 32 - 0.5, 4) for i in range(32))
+
+
+def draws_of(bs):
+    return DRAWS_B4 if bs == 4 else DRAWS
 
 
 def emulated_step(frb, bs, refinit, C=1000, shift=0.0):
@@ -61,18 +69,30 @@ def emulated_step(frb, bs, refinit, C=1000, shift=0.0):
 
 def main():
     torch.set_num_threads(8)
+    # `python oracle/make_bf16_floor.py <case> ...` re-records the named cases only and keeps the others as committed
+    only = set(sys.argv[1:])
+    out_path = os.path.join(ROOT, "tests", "golden", "bf16_floor.npz")
     rec = {}
+    if only:
+        old = np.load(out_path)
+        rec = {k: old[k] for k in old.files if k.split("/")[0] not in only}
     for key, fname, frb, bs, refinit in CASES:
+        if only and key not in only:
+            continue
         g = load(fname)
         groups = {}
 
         def put(name, v):           # every entry = the maximum over the draws
             rec[name] = np.float64(max(float(rec.get(name, 0.0)), float(v)))
-        for shift in DRAWS:
+        for shift in draws_of(bs):
             m, seg_loss, cls_loss, gnorm = emulated_step(frb, bs, refinit, shift=shift)
             put(key + "/loss_seg", abs(seg_loss / g["seg_loss"] - 1))
             put(key + "/loss_cls", abs(cls_loss / g["cls_loss"] - 1))
             put(key + "/gnorm", abs(gnorm / g["grad_norm"] - 1))
+            # (per-draw scalars: the >= 32-draw cases bound these at a percentile too, tests/helpers.py)
+            rec["%s/scalar%+.4f/loss_seg" % (key, shift)] = np.float64(abs(seg_loss / g["seg_loss"] - 1))
+            rec["%s/scalar%+.4f/loss_cls" % (key, shift)] = np.float64(abs(cls_loss / g["cls_loss"] - 1))
+            rec["%s/scalar%+.4f/gnorm" % (key, shift)] = np.float64(abs(gnorm / g["grad_norm"] - 1))
             params = dict(m.named_parameters())
             clip = float(5.0 / (g["grad_norm"] + 1e-6))
             for k in g.files:
@@ -82,7 +102,7 @@ def main():
                         continue
                     e = rel_err(pick(params[n].grad, g[k].size) * clip, g[k])
                     put("%s/grad/%s" % (key, n), e)
-                    rec["%s/draw%+.2f/%s" % (key, shift, n)] = np.float64(e)
+                    rec["%s/draw%+.4f/%s" % (key, shift, n)] = np.float64(e)
                     grp = bf16_emul.param_group(n)
                     groups[grp] = max(groups.get(grp, 0.0), e)
             sd = m.state_dict()
@@ -94,7 +114,7 @@ def main():
         bf16_emul.GRID_SHIFT = 0.0
         print("%-18s seg %.2e cls %.2e gnorm %.2e | %s" % (key, rec[key + "/loss_seg"], rec[key + "/loss_cls"],
               rec[key + "/gnorm"], "  ".join("%s %.3f" % kv for kv in sorted(groups.items()))), flush=True)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "bf16_floor.npz"), **rec)
+    np.savez_compressed(out_path, **rec)
 
 
 if __name__ == "__main__":

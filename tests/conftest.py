@@ -23,6 +23,7 @@ def pytest_sessionstart(session):
     config = session.config
     config._pfc_ranks = None
     config._bench2 = None
+    config._bench4 = None
     expr = getattr(config.option, "markexpr", "") or ""
     if "gpu" not in expr or "not gpu" in expr or os.environ.get("MSML_NO_RANK_CHILDREN"):
         return
@@ -53,6 +54,18 @@ def pytest_sessionstart(session):
                                         "--warmup", "1", "--frb", "iresnet18", "--batch", "32", "--classes", "1000",
                                         "--no-extra-modes", "--no-cpu-baseline", "--no-kernel-events"],
                                        stdout=bout, stderr=berr, env=benv, cwd=ROOT), outdir)
+    # ... and a FOUR-rank rehearsal (VERDICT r5 item 9 asked for eight: a GPU box allows six processes on its card at
+    # once, pytest itself is one of them) once the children above are gone (tests/after_pids.py polls their pids and
+    # never touches the GPU).  bench.launch_ranks -> 4 ranks on device 0 under gloo, bucketed all-reduce + label prefetch
+    # + OSB-under-collectives with four participants; test_bench_four_ranks_one_gpu collects it.
+    wait_for = [str(p.pid) for p in procs] + [str(config._bench2[0].pid)]
+    b4out = open(os.path.join(outdir, "bench4.out"), "w")
+    b4err = open(os.path.join(outdir, "bench4.err"), "w")
+    config._bench4 = (subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "after_pids.py")] + wait_for +
+                                       ["--", sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2",
+                                        "--warmup", "1", "--frb", "iresnet18", "--batch", "32", "--classes", "10000",
+                                        "--no-extra-modes", "--no-cpu-baseline", "--no-kernel-events", "--no-calibration"],
+                                       stdout=b4out, stderr=b4err, env=benv, cwd=ROOT), outdir)
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -61,14 +74,20 @@ def pytest_sessionfinish(session, exitstatus):
         for p in ranks[0]:
             if p.poll() is None:
                 p.kill()
-    b2 = getattr(session.config, "_bench2", None)
-    if b2 and b2[0].poll() is None:
-        b2[0].terminate()            # the launcher takes its ranks down with it (SIGTERM handler in bench.launch_ranks)
+    for key in ("_bench2", "_bench4"):
+        b = getattr(session.config, key, None)
+        if b and b[0].poll() is None:
+            b[0].terminate()         # the launcher takes its ranks down with it (SIGTERM handler in bench.launch_ranks)
 
 
 @pytest.fixture(scope="session")
 def bench2_result(request):
     return request.config._bench2
+
+
+@pytest.fixture(scope="session")
+def bench4_result(request):
+    return request.config._bench4
 
 
 @pytest.fixture(scope="session")

@@ -54,20 +54,22 @@ def cosine(a, b):
 BF16_CAP = 0.35          # no norm-wise gradient bound of a bf16 training-step test is looser than this
 
 
-def bf16_tolerances(case, cap=BF16_CAP, wide_spread=False):
+def bf16_tolerances(case, cap=BF16_CAP):
     """Tolerances of a bf16 training-step test, DERIVED from the bf16 error floor of the CPU oracle under the rounding
-    model of oracle/bf16_emul.py (tests/golden/bf16_floor.npz, recorded by oracle/make_bf16_floor.py for five draws of
-    the rounding noise).  Per parameter group (oracle.bf16_emul.param_group: osb / head / frb_early / frb_late):
-    floor = MEDIAN over the draws of the group's worst gradient error in that draw, bound = min(3 x floor, cap).
-    (Round 3 used 2 x the MAXIMUM over the draws, uncapped: one outlier draw at batch 4 -- BatchNorm1d over four
-    samples in front of an s = 64 head -- put the head bound of ires100 b4 at 1.29, which an all-zero gradient passes;
-    VERDICT r3 weak #1.)  losses / gnorm / running statistics: 2 x their recorded floor (maximum over the draws) with absolute minima.
-    wide_spread (the batch-4 goldens only): bound = min(max(3 x median, 2 x maximum), cap).  At batch 4 the five EMULATED draws
-    of one and the same step spread by 3.7 x (ires18_b4_fill `classification.weight`: 0.031 ... 0.116, gradient norm floor
-    17 %), i.e. which side of 3 x median a build lands on is decided by its summation order: round 5 moved the stride-2 /
-    7x7 convs to another kernel (other order of the f32 accumulation, per-kernel f64 tests and the per-block f64 check
-    green) and the same test read classification.weight 0.052 -> 0.159 against 0.144 while its gradient norm went from
-    10.5 % to 1.0 % off the reference's.  The cap still applies, so a zero gradient cannot pass."""
+    model of oracle/bf16_emul.py (tests/golden/bf16_floor.npz, recorded by oracle/make_bf16_floor.py).  Per parameter
+    group (oracle.bf16_emul.param_group: osb / head / frb_early / frb_late) a draw's value is the group's worst gradient
+    error in that draw, and the bound is a FIXED statistic of the draws, never re-fitted to a build:
+      * cases recorded with >= 32 draws (the batch-4 goldens, round 6): min(2 x p90 over the draws, cap).  At batch 4 the
+        draws of one and the same step spread by 3-10 x in the head group (ires18_b4_fill: 0.020 ... 0.198 over 32 draws;
+        BatchNorm1d over four samples in front of an s = 64 head), so which side of a multiple of the MEDIAN a build lands
+        on is decided by its summation order -- round 5 moved the stride-2 / 7x7 convs to other kernels and the same test
+        read classification.weight 0.052 -> 0.159 against 3 x median-of-five = 0.144, and answered with a `wide_spread`
+        switch (max(3 x median, 2 x maximum) of five draws: VERDICT r5 weak 1).  That switch is gone; the
+        percentile rule is the one VERDICT r5 item 8 names.
+      * cases with five draws (batch >= 8, spread <= 1.4 x): min(3 x median, cap), as since round 4.
+    (Round 3 used 2 x the MAXIMUM over the draws, uncapped: one outlier draw put the head bound of ires100 b4 at 1.29,
+    which an all-zero gradient passes; VERDICT r3 weak #1.  The cap applies to every rule, so a zero gradient cannot
+    pass.)  losses / gnorm / running statistics: 2 x their recorded floor (maximum over the draws) with absolute minima."""
     from oracle.bf16_emul import param_group
     fl = load("bf16_floor.npz")
     draws = sorted({k.split("/")[1] for k in fl.files if k.startswith(case + "/draw")})
@@ -81,12 +83,14 @@ def bf16_tolerances(case, cap=BF16_CAP, wide_spread=False):
             if v:
                 per.append(max(v))
         if per:
-            bound = 3.0 * float(np.median(per))
-            if wide_spread:
-                bound = max(bound, 2.0 * max(per))
+            bound = 2.0 * float(np.percentile(per, 90)) if len(per) >= 32 else 3.0 * float(np.median(per))
             tol[grp] = min(bound, cap)
     stat = max([float(fl[k]) for k in fl.files if k.startswith(case + "/stat/")] + [0.0])
-    tol["loss"] = max(2.0 * max(float(fl[case + "/loss_seg"]), float(fl[case + "/loss_cls"])), 2e-3)
-    tol["gnorm"] = max(2.0 * float(fl[case + "/gnorm"]), 5e-3)
+
+    def scalar(name):          # 2 x p90 over the draws where >= 32 were recorded, else 2 x their maximum
+        per = [float(fl[k]) for k in fl.files if k.startswith(case + "/scalar") and k.endswith("/" + name)]
+        return 2.0 * (float(np.percentile(per, 90)) if len(per) >= 32 else float(fl[case + "/" + name]))
+    tol["loss"] = max(scalar("loss_seg"), scalar("loss_cls"), 2e-3)
+    tol["gnorm"] = max(scalar("gnorm"), 5e-3)
     tol["stat"] = max(2.0 * stat, 5e-3)
     return tol

@@ -11,6 +11,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _diff_report(a, b, what):
+    """One line on where two flat gradients differ (count, largest difference, first / last offset, non-finite values)."""
+    ne = (a != b) | (a.isnan() != b.isnan())
+    k = int(ne.sum().item())
+    if k == 0:
+        return "%s: identical" % what
+    idx = ne.nonzero().flatten()
+    d = (a.double() - b.double()).abs()
+    d = torch.where(d.isnan(), torch.zeros_like(d), d)
+    return ("%s: %d of %d elements differ, max |diff| %.3e (|a| max %.3e), offsets %d..%d, non-finite a %d b %d"
+            % (what, k, a.numel(), float(d.max().item()), float(a.abs().nan_to_num().max().item()), int(idx[0].item()),
+               int(idx[-1].item()), int((~a.isfinite()).sum().item()), int((~b.isfinite()).sum().item())))
+
+
 def main():
     rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     import torch
@@ -70,6 +84,8 @@ def main():
                 StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
             loss.backward()
             fired = sum(opt.fired) if overlap else 0
+            if overlap:
+                out["ddp_duplicate_reports"] = out.get("ddp_duplicate_reports", 0) + opt.duplicate_reports
             opt.all_reduce_grads(world)
             torch.cuda.synchronize()
             return opt.averaged_grad().clone(), fired, (len(opt.buckets) if overlap else 0)
@@ -79,6 +95,12 @@ def main():
     ga, _, _ = grads(False)
     gb, fired, nb = grads(True)
     out["ddp_equal"] = int(torch.equal(ga, gb))
+    # what differs, should the two ever differ (the compute is run-to-run deterministic: static tile schedules, f64
+    # accumulators): a second plain run separates "the backward itself is not reproducible" from "the overlapped reduce
+    # raced", the offsets say which parameters
+    ga2, _, _ = grads(False)
+    out["ddp_plain_reproducible"] = int(torch.equal(ga, ga2))
+    out["ddp_diag"] = _diff_report(ga, gb, "plain vs overlapped") + " | " + _diff_report(ga, ga2, "plain vs plain")
     out["ddp_fired_during_backward"] = fired
     out["ddp_buckets"] = nb
     out["ddp_gsum"] = float(ga.double().abs().sum().item())

@@ -93,3 +93,18 @@ def test_bench_gpus_n_starts_its_own_ranks_and_reports_their_failure():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=120, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_rank_environment_of_the_self_launcher():
+    """bench.launch_ranks' environment for N = 8 on a 16-CPU share: a loopback rendezvous on a free
+    port, WORLD_SIZE / LOCAL_WORLD_SIZE, dmabuf IPC, and OpenMP threads from the USABLE CPUs (two per rank), never from
+    os.cpu_count() (256 on the GPU boxes); what the caller already set is kept."""
+    import bench
+    env = bench.rank_env(8, {"PATH": "/bin"}, cpus=16)
+    assert env["MASTER_ADDR"] == "127.0.0.1" and 1024 < int(env["MASTER_PORT"]) < 65536
+    assert env["WORLD_SIZE"] == env["LOCAL_WORLD_SIZE"] == "8"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["OMP_NUM_THREADS"] == "2"
+    assert bench.rank_env(8, {}, cpus=256)["OMP_NUM_THREADS"] == "4" and bench.rank_env(8, {}, cpus=4)["OMP_NUM_THREADS"] == "1"
+    kept = bench.rank_env(2, {"MASTER_PORT": "29501", "OMP_NUM_THREADS": "7", "MASTER_ADDR": "10.0.0.1"}, cpus=16)
+    assert (kept["MASTER_PORT"], kept["OMP_NUM_THREADS"], kept["MASTER_ADDR"]) == ("29501", "7", "10.0.0.1")
+    assert 1 <= bench.usable_cpus() <= (os.cpu_count() or 1)

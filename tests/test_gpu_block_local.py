@@ -8,7 +8,8 @@ resblock_bottle (backbones/fm/fmoperator.py:53-68) -- is checked ON ITS OWN: msm
 actual bf16 input, the BatchNorm coefficients it saved, the gradient it received and the gradient it returned (module
 hooks add the block's forward OUTPUT); the
 parameter gradients are read from the flat arena (every parameter is used once, the arena was zeroed).  ONE block is
-then recomputed in f64 torch on the CPU (the oracle's block class, filled with the HIP model's parameters) from those
+then recomputed in f64 torch (the oracle's block class, filled with the HIP model's parameters; since round 6 on the
+device with MIOpen off -- REF_DEV below -- and cross-checked against the CPU run on the small network) from those
 same tensors, and the forward output, dX, dW, dgamma, dbeta, dalpha and the saved statistics must agree to what bf16 storage costs THAT
 block on THOSE operands: the bound of every quantity is 2 x the error of the same block recomputed on the CPU under
 the bf16 rounding model of oracle/bf16_emul.py (three draws) -- a few per cent for an IBasicBlock, 5-7 % for the FM
@@ -38,6 +39,16 @@ PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_deco
 # bound = FLOOR_X x (the block's own emulated bf16 error, worst of three draws) + an absolute term
 # (per-channel sums: 3 x -- single channels of 64-512 are noisier than a norm over a whole tensor)
 FLOOR_X, CHAN_X, NORM_ABS, FRAC_ABS, CHAN_ABS, ELEM_TOL, STAT_TOL = 2.0, 3.0, 5e-3, 5e-4, 1e-2, 5e-2, 1e-2
+# Where the one-block recomputations (f64 truth + emulated bf16 draws, plain torch on the oracle's module classes) run.
+# Round 6: on the device by default, with MIOpen switched off (torch's own im2col + rocBLAS dgemm / sgemm kernels and
+# native BatchNorm / PReLU kernels -- no half-precision path anywhere): the same arithmetic as on the CPU, 5-10 x
+# faster (the two block-by-block tests took 126 s of the suite's 418 s on 16 CPU threads).  "cpu" restores the CPU
+# run; test_local_check_catches_an_injected_fault runs the small network BOTH ways and requires the rows to agree.
+REF_DEV = os.environ.get("MSML_LOCAL_REF_DEV", "cuda")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
 
 
 def _step_with_taps(frb, bs, fault=""):
@@ -81,9 +92,9 @@ def _step_with_taps(frb, bs, fault=""):
     return m, taps, grads
 
 
-def _nchw64(t, c):
-    """NHWC storage tensor (bf16, padded channels) -> NCHW f64 on the CPU, first c channels."""
-    return t[..., :c].permute(0, 3, 1, 2).float().cpu().double().contiguous()
+def _nchw64(t, c, dev="cpu"):
+    """NHWC storage tensor (bf16, padded channels) -> NCHW f64 on `dev`, first c channels."""
+    return t[..., :c].permute(0, 3, 1, 2).float().to(dev).double().contiguous()
 
 
 def _frac_beyond(got, want, tol):
@@ -94,7 +105,7 @@ def _frac_beyond(got, want, tol):
     return float((np.abs(got - want) > tol * np.abs(want).max()).mean())
 
 
-def _ref_block(kind, mod, dtype):
+def _ref_block(kind, mod, dtype, dev="cpu"):
     if kind == "iblock":
         cout, cin = mod.conv1.weight.shape[:2]
         ref = om.IBasicBlock(cin, cout, mod.conv2.stride[0], mod.downsample is not None)
@@ -104,7 +115,7 @@ def _ref_block(kind, mod, dtype):
     ref = ref.to(dtype).train()
     ref.load_state_dict({k: v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu()
                          for k, v in mod.state_dict().items()}, strict=True)
-    return ref, cin, cout
+    return ref.to(dev), cin, cout
 
 
 def _errors(got, want, terms):
@@ -120,7 +131,12 @@ def _errors(got, want, terms):
     return tens, chan
 
 
-def _check_block(kind, name, mod, t, grads):
+def _check_block(kind, name, mod, t, grads, dev=None):
+    with torch.backends.cudnn.flags(enabled=False):       # (MIOpen off: torch's native f64 / f32 conv kernels on the device)
+        return _check_block_on(kind, name, mod, t, grads, REF_DEV if dev is None else dev)
+
+
+def _check_block_on(kind, name, mod, t, grads, dev):
     """Recompute ONE block from the tensors its HIP backward consumed: in f64 (the truth) and, for the bound, in f32
     under the bf16 rounding model of oracle/bf16_emul.py (every stored activation / activation gradient rounded, bf16
     conv operands -- plain PyTorch hooks, no HIP code) for three draws of the rounding noise.  The emulation's own
@@ -132,9 +148,9 @@ def _check_block(kind, name, mod, t, grads):
     against the root-sum-square of its TERMS -- the scale on which roundings of the terms add up -- not against the
     sum itself."""
     prefix = name + "."
-    ref, cin, cout = _ref_block(kind, mod, torch.float64)
-    x64 = _nchw64(t["x"], cin).requires_grad_()
-    dout64 = _nchw64(t["dout"], cout)
+    ref, cin, cout = _ref_block(kind, mod, torch.float64, dev)
+    x64 = _nchw64(t["x"], cin, dev).requires_grad_()
+    dout64 = _nchw64(t["dout"], cout, dev)
     feats, terms, hooks = {}, {}, []
 
     def watch(mname, m):
@@ -144,12 +160,12 @@ def _check_block(kind, name, mod, t, grads):
 
             def bwd(g):
                 if isinstance(m, torch.nn.PReLU):
-                    terms[mname + ".weight"] = (g * z.clamp_max(0)).pow(2).sum((0, 2, 3)).sqrt().numpy()
+                    terms[mname + ".weight"] = _np((g * z.clamp_max(0)).pow(2).sum((0, 2, 3)).sqrt())
                 else:
                     mu = z.mean((0, 2, 3), keepdim=True)
                     xh = (z - mu) / (z.var((0, 2, 3), unbiased=False, keepdim=True) + m.eps).sqrt()
-                    terms[mname + ".bias"] = g.pow(2).sum((0, 2, 3)).sqrt().numpy()
-                    terms[mname + ".weight"] = (g * xh).pow(2).sum((0, 2, 3)).sqrt().numpy()
+                    terms[mname + ".bias"] = _np(g.pow(2).sum((0, 2, 3)).sqrt())
+                    terms[mname + ".weight"] = _np((g * xh).pow(2).sum((0, 2, 3)).sqrt())
             out.register_hook(bwd)
         hooks.append(m.register_forward_hook(fwd))
     for mname, m in ref.named_modules():
@@ -159,10 +175,10 @@ def _check_block(kind, name, mod, t, grads):
     y64.backward(dout64)
     for h in hooks:
         h.remove()
-    want = {"dx": x64.grad.numpy()}
+    want = {"dx": _np(x64.grad)}
     if t.get("out") is not None:           # the block's FORWARD output from the same input (train-mode statistics)
-        want["out"] = y64.detach().numpy()
-    want.update({pn: p.grad.numpy() for pn, p in ref.named_parameters()})
+        want["out"] = _np(y64)
+    want.update({pn: _np(p.grad) for pn, p in ref.named_parameters()})
     got = {"dx": _nchw64(t["dx"], cin).numpy()}
     if "out" in want:
         got["out"] = _nchw64(t["out"], cout).numpy()
@@ -171,7 +187,7 @@ def _check_block(kind, name, mod, t, grads):
     # the local bf16 floor: the same block, f32, under the rounding model, three draws
     f_tens, f_chan = {}, {}
     for shift in (0.0, 0.31, -0.27):
-        emu, _, _ = _ref_block(kind, mod, torch.float32)
+        emu, _, _ = _ref_block(kind, mod, torch.float32, dev)
         bf16_emul.emulate(emu)
         bf16_emul.GRID_SHIFT = shift
         try:
@@ -180,10 +196,10 @@ def _check_block(kind, name, mod, t, grads):
             ye.backward(dout64.float())
         finally:
             bf16_emul.GRID_SHIFT = 0.0
-        ge = {"dx": bf16_emul._r(xe.grad).double().numpy()}
+        ge = {"dx": _np(bf16_emul._r(xe.grad).double())}
         if "out" in want:
-            ge["out"] = bf16_emul._r(ye.detach()).double().numpy()
-        ge.update({pn: p.grad.double().numpy() for pn, p in emu.named_parameters()})
+            ge["out"] = _np(bf16_emul._r(ye.detach()).double())
+        ge.update({pn: _np(p.grad.double()) for pn, p in emu.named_parameters()})
         a, b = _errors(ge, want, terms)
         for k, (e, fr) in a.items():
             f_tens[k] = (max(f_tens.get(k, (0, 0))[0], e), max(f_tens.get(k, (0, 0))[1], fr))
@@ -199,15 +215,15 @@ def _check_block(kind, name, mod, t, grads):
         k = t[key].float().cpu().double().numpy()
         z = feats[b]
         c = z.shape[1]
-        mean = z.mean((0, 2, 3)).numpy()
-        var = z.var((0, 2, 3), unbiased=False).numpy()
+        mean = _np(z.mean((0, 2, 3)))
+        var = _np(z.var((0, 2, 3), unbiased=False))
         eps = getattr(ref, b).eps
         stats.append((b + ".mean", float(np.abs(k[2][:c] - mean).max() / np.sqrt(var + eps).max()), STAT_TOL))
         stats.append((b + ".invstd", float(np.abs(k[3][:c] * np.sqrt(var + eps) - 1.0).max()), STAT_TOL))
     return tens, frac, chan, stats
 
 
-def _run_local_check(frb, bs, fault=""):
+def _run_local_check(frb, bs, fault="", dev=None):
     """Returns (model, rows, n IBasicBlocks, n bottlenecks); rows = {family: [(name, hip error, bound)]}."""
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     m, taps, grads = _step_with_taps(frb, bs, fault)
@@ -217,14 +233,14 @@ def _run_local_check(frb, bs, fault=""):
     t0 = time.time()
     for kind, wid, t in taps:
         name, mod = by_w[wid]
-        for fam, part in zip(rows, _check_block(kind, name, mod, t, grads)):
+        for fam, part in zip(rows, _check_block(kind, name, mod, t, grads, dev)):
             rows[fam] += [(name + "." + what, e, b) for what, e, b in part]
     n_i = sum(1 for k, _, _ in taps if k == "iblock")
     n_b = len(taps) - n_i
     print("local f64 check %s b%d%s: %d IBasicBlocks (FRB + OSB) + %d FM bottlenecks; %d tensor gradients, %d per-channel "
-          "parameter gradients; %.0f s of CPU (f64 truth + 3 emulated bf16 draws per block)"
+          "parameter gradients; %.0f s on %s (f64 truth + 3 emulated bf16 draws per block)"
           % (frb, bs, " FAULT=" + fault if fault else "", n_i, n_b, len(rows["norm-wise"]), len(rows["per-channel"]),
-             time.time() - t0))
+             time.time() - t0, dev or REF_DEV))
     for fam, rr in rows.items():
         top = sorted(rr, key=lambda r: -r[1] / r[2])[:4]
         print("   %s, closest to their bounds: " % fam + "; ".join("%s %.2e (bound %.2e)" % r for r in top))
@@ -265,6 +281,16 @@ def test_local_check_catches_an_injected_fault():
     bad = _bad(rows)
     assert {r[1] for r in bad if r[0] == "norm-wise"} == {n + ".dx" for n in faulty}, bad[:12]
     assert all(r[1].endswith(".dx") and r[1][:-3] in faulty for r in bad), bad[:12]
-    # and the unfaulted small network passes in full
+    # and the unfaulted small network passes in full -- with the one-block recomputations on the device (the default,
+    # REF_DEV) AND on the CPU: the f64 truth is the same arithmetic on either, so the HIP path's errors must read the
+    # same (the bounds come from f32 emulations whose bf16 roundings may fall differently: same size, not same digits)
     _, rows, _, _ = _run_local_check("iresnet18", 8)
     assert not _bad(rows), _bad(rows)[:10]
+    if REF_DEV != "cpu":
+        _, rows_cpu, _, _ = _run_local_check("iresnet18", 8, dev="cpu")
+        assert not _bad(rows_cpu), _bad(rows_cpu)[:10]
+        for fam in rows:
+            assert [r[0] for r in rows[fam]] == [r[0] for r in rows_cpu[fam]]
+            for (n, e, b), (_, ec, bc) in zip(rows[fam], rows_cpu[fam]):
+                assert abs(e - ec) <= 1e-5 + 1e-4 * ec, (fam, n, e, ec)
+                assert abs(b - bc) <= 0.25 * bc + 1e-3, (fam, n, b, bc)

@@ -9,6 +9,17 @@ from msml_amd import _lib, ops
 
 pytestmark = pytest.mark.gpu
 
+
+def _experiments():
+    """The measured-slower kernel variants are compiled into experiment builds only
+    (tools/build_variant.py --all MSML_EXPERIMENTS, selected with MSML_LIB; tools/experiments_run.sh runs their tests)."""
+    return bool(_lib.value("msml_has_experiments"))
+
+
+def needs_experiments():
+    if not _experiments():
+        pytest.skip("kernel variant of an experiment build (tools/experiments_run.sh; profiles/r06_experiments_variant.log)")
+
 # (Cin1, Cin2, Cout, H, R, S, stride, pad_h, pad_w, bias)
 SHAPES = [
     (3, 0, 64, 28, 3, 3, 1, 1, 1, False),      # FRB stem (C=3 padded to 8)
@@ -478,6 +489,8 @@ BNIN = [
 @pytest.mark.parametrize("shape", BNIN)
 def test_conv_bn_in_lds_matches_unfused(shape, with_alpha):
     n, cin, cout, h, w_ = shape
+    if cin == 64:                # (the weights-stationary kernel takes an input transform in experiment builds only)
+        needs_experiments()
     g = torch.Generator().manual_seed(sum(shape) + int(with_alpha))
     x = ops.to_nhwc(torch.randn(n, cin, h, w_, generator=g).cuda(), _lib.BF16)
     w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).cuda()
@@ -798,6 +811,8 @@ def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     statistics updated by one workgroup) against msml_bn_fin_act_fwd + msml_conv2d_acc: activation, conv output, saved
     coefficients and running statistics bit for bit, output statistics to the order of the f64 adds."""
     n, cin, cout, h, w_ = shape
+    if cin == 64:                # (k_conv_ws's prologue transform: measured slower, experiment builds only)
+        needs_experiments()
     g = torch.Generator().manual_seed(sum(shape) + int(with_alpha))
     x = ops.to_nhwc((torch.randn(n, cin, h, w_, generator=g) * 1.7 + 0.3).cuda(), _lib.BF16)
     w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).cuda()
@@ -843,6 +858,7 @@ def test_conv_dgrad_bn_backward_in_the_prologue(shape, with_alpha):
     sums of the next BatchNorm backward in ONE launch, against msml_bn_fin_bwd_apply + msml_conv2d_bnbwd_acc: the
     BatchNorm's input gradient (written through), the conv's input gradient and the parameter gradients bit for bit,
     the lower sums to the order of the f64 adds."""
+    needs_experiments()                   # (measured slower than the two launches: the XB instantiations are not shipped)
     n, cdy, cdx, h, w_ = shape            # dy has cdy channels (the conv's output side), dx cdx
     g = torch.Generator().manual_seed(sum(shape) + int(with_alpha))
     rnd = lambda *s: torch.randn(*s, generator=g)       # noqa: E731
@@ -1138,6 +1154,7 @@ def test_conv_s2r_64_channel_stride2(shape):
 @pytest.mark.parametrize("accumulate", [False, True])
 @pytest.mark.parametrize("shape", [(6, 64, 64, 56), (3, 64, 64, 112), (9, 128, 128, 28), (4, 64, 128, 26), (5, 256, 256, 28)])
 def test_conv_wgrad_stride2_on_the_strip_kernel(shape, accumulate, monkeypatch):
+    needs_experiments()
     monkeypatch.setenv("MSML_HALO_WGRAD_S2", "1")         # (opt-in: measured not faster than the im2col kernel)
     n, cin, cout, h = shape
     g = torch.Generator().manual_seed(sum(shape))
@@ -1249,6 +1266,52 @@ def test_conv_x3_with_the_leading_batchnorm_folded_in(shape):
     tol = 4e-5 * ref.abs().max().item()
     assert (two.double() - ref).abs().max().item() <= tol          # (the unfolded pair meets the same bar)
     assert (got.double() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("ratio", [6.0, 50.0])
+def test_conv_x3_batchnorm_fold_under_cancellation(ratio):
+    """with running_mean >> sqrt(running_var) on the block input the folded form conv(W s, x) + sum(W t) is a
+    difference of two large terms, and the split-bf16 rounding of the first is amplified by |mean| / std.  Block input with
+    mean / std = `ratio` per channel, against f64 torch at the 2e-4 parity bar of the embedding path (the output scale):
+    ratio 6 is folded and inside the bar; ratio 50 is REFUSED by functional.bn_conv_bn_eval_x3 (X3_FOLD_MAX_RATIO = 8) --
+    IBasicBlock.forward then runs the separate pass, which meets the bar at any ratio."""
+    import torch.nn as nn
+    from msml_amd import functional as Fh
+    n, cin, cout, h, w = 4, 128, 128, 28, 28
+    g = torch.Generator().manual_seed(int(ratio))
+    std = torch.rand(cin, generator=g) + 0.5
+    mean = std * ratio * (torch.randint(0, 2, (cin,), generator=g).float() * 2 - 1)
+    x = (torch.randn(n, h, w, cin, generator=g) * std + mean).cuda()
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=False).cuda()
+    bn1, bn2 = nn.BatchNorm2d(cin).cuda().eval(), nn.BatchNorm2d(cout).cuda().eval()
+    prelu = nn.PReLU(cout).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+        bn1.weight.copy_(torch.rand(cin, generator=g) + 0.5)
+        bn1.bias.copy_(torch.randn(cin, generator=g) * 0.5)
+        bn1.running_mean.copy_(mean)
+        bn1.running_var.copy_(std * std)
+        bn2.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        bn2.bias.copy_(torch.randn(cout, generator=g) * 0.5)
+        bn2.running_mean.copy_(torch.randn(cout, generator=g) * 0.3)
+        bn2.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+        prelu.weight.copy_(torch.rand(cout, generator=g) * 0.5)
+    xs = Fh.x3_from_f32(x)
+    with torch.no_grad():
+        xv = Fh.x3_to_f32(xs).double().permute(0, 3, 1, 2)
+        ref = prelu.double()(bn2.double()(conv.double()(bn1.double()(xv)))).permute(0, 2, 3, 1)
+    for mod in (conv, bn1, bn2, prelu):
+        mod.float()
+    tol = 2e-4 * ref.abs().max().item()
+    out = Fh.bn_conv_bn_eval_x3(xs, bn1, conv, bn2, prelu)
+    two = Fh.x3_to_f32(Fh.conv_bn_eval_x3(Fh.bn_act_x3(xs, bn1), None, conv, bn2, prelu, None, 0, False))
+    assert (two.double() - ref).abs().max().item() <= tol
+    if ratio > Fh.X3_FOLD_MAX_RATIO:
+        assert out is None                                    # refused: the block falls back to the separate pass
+        assert Fh.bn_conv_bn_eval_x3(xs, bn1, conv, bn2, prelu) is None      # (cached decision)
+    else:
+        assert out is not None
+        assert (Fh.x3_to_f32(out).double() - ref).abs().max().item() <= tol
 
 
 # k_conv_halo2 with the split-bf16 epilogue (config 5): (N, C, H, stride) -- stride-2 layers on 14 x 14 tiles (128- and 256-wide

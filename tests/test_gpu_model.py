@@ -179,6 +179,31 @@ def test_seg_loss_g7():
             assert_cs(lg.grad, g["grad_cs_%s_%s" % (rp, rk)], 1e-4)
 
 
+def test_seg_loss_refuses_blobs_that_differ_from_target_on_every_call():
+    """blobs must equal target (train.py:258 passes a clone).  The first call checks on the host and raises; every
+    later call checks on the device without a synchronisation and turns loss AND gradient into NaN on a mismatch
+    (the first-call-only check left later callers with a silently wrong loss)."""
+    logit, msk = seg_inputs()
+    msk = msk.cuda()
+    other = 1 - msk
+    crit = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")
+    with pytest.raises(NotImplementedError):
+        crit(logit.cuda(), other, msk)
+    crit = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")
+    lg = logit.cuda().requires_grad_(True)
+    ref = crit(lg, msk.clone(), msk)                      # call 1: equal, host check passes
+    lg2 = logit.cuda().requires_grad_(True)
+    ok = crit(lg2, msk.clone(), msk)                      # call 2: equal clone, device check
+    ok.backward()
+    assert torch.equal(ok.detach(), ref.detach()) and torch.isfinite(lg2.grad).all()
+    lg3 = logit.cuda().requires_grad_(True)
+    bad = crit(lg3, other, msk)                           # call 3: differs -> poisoned, no exception, no sync
+    bad.backward()
+    assert torch.isnan(bad).item() and torch.isnan(lg3.grad).all()
+    with pytest.raises(NotImplementedError):
+        crit(logit.cuda(), msk[:, :50], msk)              # a shape mismatch is a host-side fact: raises at once
+
+
 def test_heads_g5():
     from msml_amd.headers import AMArcFace, AMCosFace, Softmax
     g = load("g5_heads.npz")

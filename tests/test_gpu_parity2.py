@@ -58,7 +58,7 @@ def test_train_step_g4_bf16_fused_path(variant, bs):
         refinit_frb_convs(m)
     # (batch 4: BatchNorm over four images -- the EMULATED bf16 floor of the early-FRB gradients already has a median
     # of 0.31-0.38 over the rounding draws, above the 0.35 cap the batch >= 8 tests use; cap 0.5 here)
-    tol = bf16_tolerances(FLOOR_CASE[(variant, bs)], cap=0.5 if bs == 4 else 0.35, wide_spread=bs == 4)
+    tol = bf16_tolerances(FLOOR_CASE[(variant, bs)], cap=0.5 if bs == 4 else 0.35)
     x, msk = eval_inputs(bs)
     label = synthetic.labels(bs, 1000, seed=1)
     m.train()
@@ -201,6 +201,9 @@ def test_fm_visualisation_hooks_as_qeval_is_vis(tmp_path, fp16):
         assert rel_err(op.contaminated_feat, yf) < tol
         assert rel_err(op.mask_feat, mk) < tol
         assert rel_err(op.purified_feat, yf * mk) < tol
+        if not fp16 and k < 2:
+            continue       # (the scatter plots of the two large stages -- 200 k / 100 k points each, 6 s of matplotlib --
+            # are drawn once, in the fp16=True case: the saved vectors above are what the precision modes change)
         paths = op.plot_intermediate_features(gt_occ_msk=mask, save_folder=str(tmp_path))
         assert [os.path.basename(q) for q in paths] == ["fm_cm_%d_mul.jpg" % op.height, "fm_cp_%d_mul.jpg" % op.height]
         assert all(os.path.getsize(q) > 1000 for q in paths)

@@ -96,3 +96,110 @@ def test_training_run_losses_fall(fp16, steps):
     off = ~torch.eye(BATCH, dtype=torch.bool, device="cuda")
     if (same & off).any() and (~same).any():
         assert float(sim[same & off].mean()) > float(sim[~same].mean())
+
+
+# ---- bf16 against exact-f32 over a whole run --------------------------------------------------------
+T_IDS, T_BATCH, T_STEPS = 64, 128, 200
+
+
+def _trajectory(fp16, faces):
+    """T_STEPS steps of the reference's loop (train.py:252-277) on ires18 at batch 128 from a fixed initialisation and a
+    fixed batch stream; returns (cls loss per step, seg loss per step, the trained model in eval mode)."""
+    torch.manual_seed(11)                                 # same initial weights in both modes
+    model = MSML("iresnet18", "unet", (1, 1, 1, 1), 8, fp16=fp16, fm_params=(3, 2, "sigmoid", "mul"),
+                 header_type="AMArcFace", header_params=(64.0, 0.48, 0.0, 0.0), peer_params=dict(PEER_OFF)).cuda().train()
+    for p in model.classification.parameters():
+        p.requires_grad_(False)
+    torch.manual_seed(12)
+    pfc = PartialFC(0, 0, 1, T_BATCH, False, ArcMargin(32.0, 0.2, 0.0, 0.0), T_IDS, fp16=fp16)
+    opt = FlatSGD([{"params": [p for p in model.parameters() if p.requires_grad], "lr": 0.02}], 0.9, 5e-4, 5.0)
+    opt_pfc = FlatSGD([{"params": [pfc.sub_weight], "lr": 0.02}], 0.9, 5e-4, None)
+    pfc.adopt_flat_optimizer(opt_pfc)
+    seg_crit = StructureConsensuLossFunction(10.0, 5.0, "idx", "idx")
+    if fp16:
+        ops.WGRAD_STREAM, ops.OSB_STREAM = torch.cuda.Stream(), torch.cuda.Stream()
+    cls_hist, seg_hist = [], []
+    try:
+        for step in range(T_STEPS):
+            g = torch.Generator().manual_seed(5000 + step)
+            lab = torch.randint(0, T_IDS, (T_BATCH,), generator=g)
+            src = (faces[lab] + torch.randn(T_BATCH, 112, 112, 3, generator=g) * 12.0).clamp(0, 255).to(torch.uint8).cuda()
+            lab = lab.cuda()
+            img, msk, _ori, _desc = data.augment(src, seed=3, offset=step * T_BATCH, mode="train", want_ori=False)
+            opt.zero_grad()
+            feature, final_seg, _kd = model(img)
+            seg_loss = seg_crit(final_seg, msk, msk)
+            fn = Fh.normalize(feature)
+            x_grad, loss_v = pfc.forward_backward(lab, fn, opt_pfc)
+            torch.autograd.backward([fn, seg_loss], [x_grad, None])
+            opt.step()
+            opt_pfc.step()
+            pfc.update()
+            cls_hist.append(loss_v.detach().float().reshape(()))
+            seg_hist.append(seg_loss.detach().float().reshape(()))
+    finally:
+        ops.WGRAD_STREAM = ops.OSB_STREAM = None
+        opt.release()
+        opt_pfc.release()
+    cls_hist = torch.stack(cls_hist).cpu().tolist()
+    seg_hist = torch.stack(seg_hist).cpu().tolist()
+    return cls_hist, seg_hist, model.eval()
+
+
+def _verification_accuracy(model, faces, n_pairs=600):
+    """10-fold pair-cosine verification accuracy (the config-5 protocol: orig + flip embeddings summed in f64,
+    eval/verification.py:239-306, eval/qeval_mxnet.py:326-390) on held-out noisy, block-occluded copies of the training
+    identities: even pairs same identity, odd pairs different identities."""
+    from msml_amd import verification
+    g = torch.Generator().manual_seed(777)
+    a = torch.randint(0, T_IDS, (n_pairs,), generator=g)
+    off = torch.randint(1, T_IDS, (n_pairs,), generator=g)
+    same = (torch.arange(n_pairs) % 2 == 0)
+    b = torch.where(same, a, (a + off) % T_IDS)
+    ids = torch.stack((a, b), 1).reshape(-1)                                # rows 2i, 2i + 1 = pair i
+    src = (faces[ids] + torch.randn(2 * n_pairs, 112, 112, 3, generator=g) * 12.0).clamp(0, 255).to(torch.uint8).cuda()
+    embs = []
+    for s in range(0, 2 * n_pairs, 200):
+        img, _, _, _ = data.augment(src[s:s + 200], seed=9, offset=s, mode="block", flip=False, light=False, want_ori=False)
+        embs.append(verification.extract_embeddings(model, img))
+    _, _, acc, val, _, far = verification.evaluate(torch.cat(embs), same.numpy())
+    return float(acc.mean()), val, far
+
+
+def test_bf16_training_walks_the_exact_f32_trajectory():
+    """ONE comparison of the headline dtype with the reference's arithmetic over a whole run (the
+    reference keeps its FRB in fp32 under autocast, backbones/frb/iresnet.py:208, and trains as train.py:252-277):
+    ires18-MSML + 64-id PartialFC, batch 128, 200 steps of the same learnable task from the same initial weights and
+    the same batch stream, once on the fused bf16 path (side streams on, what bench.py times) and once on the
+    exact-f32 path.  Per-step losses differ by rounding and then by the chaos of SGD, so the STATED bands are on
+    window means: the classification loss of the two runs within 20 % (+ 0.02 absolute) of each other over every
+    25-step window, the segmentation loss within 5 %; and the task metric at the end -- 10-fold pair verification
+    accuracy under block occlusion, the config-5 protocol -- equal within 1.5 points, both far above chance."""
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(T_IDS, 3, 7, 7, generator=g)
+    faces = (torch.nn.functional.interpolate(base, size=(112, 112), mode="bilinear", align_corners=False) * 255) \
+        .permute(0, 2, 3, 1).contiguous()
+    c16, s16, m16 = _trajectory(True, faces)
+    acc16, val16, far16 = _verification_accuracy(m16, faces)
+    del m16
+    torch.cuda.empty_cache()
+    c32, s32, m32 = _trajectory(False, faces)
+    acc32, val32, far32 = _verification_accuracy(m32, faces)
+    assert all(math.isfinite(v) for v in c16 + s16 + c32 + s32)
+    win = 25
+    rows = []
+    for w0 in range(0, T_STEPS, win):
+        mean = lambda h: sum(h[w0:w0 + win]) / win          # noqa: E731
+        rows.append((w0, mean(c16), mean(c32), mean(s16), mean(s32)))
+    print("bf16 vs f32 trajectory, ires18 b%d, %d steps: window means (cls bf16 / f32, seg bf16 / f32)" % (T_BATCH, T_STEPS))
+    for w0, a, b, c, d in rows:
+        print("   steps %3d-%3d: cls %.4f / %.4f (%+.1f %%)   seg %.4f / %.4f (%+.2f %%)"
+              % (w0, w0 + win - 1, a, b, 100 * (a / b - 1), c, d, 100 * (c / d - 1)))
+    print("   verification accuracy (10-fold, block occlusion): bf16 %.4f  f32 %.4f | TAR@FAR1e-3 %.3f / %.3f"
+          % (acc16, acc32, val16, val32))
+    assert rows[-1][2] < 0.25 * rows[0][2] and rows[-1][1] < 0.25 * rows[0][1]      # both runs learn the identities
+    for w0, a, b, c, d in rows:
+        assert abs(a - b) <= 0.20 * b + 0.02, (w0, a, b)
+        assert abs(c - d) <= 0.05 * d, (w0, c, d)
+    assert acc16 > 0.9 and acc32 > 0.9, (acc16, acc32)
+    assert abs(acc16 - acc32) <= 0.015, (acc16, acc32)
