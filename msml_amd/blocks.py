@@ -217,9 +217,6 @@ def _bn_bwd_dgrad(dy, up_x, up_k, up_alpha, pgr, part, cp, h, w, bn_x, coef, alp
     return dc, dx, acc
 
 
-_UNIT = {}
-
-
 def _dgrad_plus(dy, cp, h, w, other):
     """dX of a stride-1 conv plus another gradient of the same tensor, summed in the conv epilogue
     (msml_conv2d_fused with unit scale / zero shift and `other` as its residual) instead of a separate add pass."""
@@ -230,11 +227,7 @@ def _dgrad_plus(dy, cp, h, w, other):
         call("msml_add", dx, other, dx, dx.numel(), BF16)
         return dx
     wp = ops.PACKS.get(wparam, True, 0, cout, 0, cin, cout, 0, BF16)
-    key = (cinp, dy.device)
-    unit = _UNIT.get(key)
-    if unit is None:
-        unit = _UNIT[key] = (torch.ones(cinp, dtype=torch.float32, device=dy.device),
-                             torch.zeros(cinp, dtype=torch.float32, device=dy.device))
+    unit = ops.unit_coef(cinp, dy.device)
     n, p, q, c0p = dy.shape
     out = torch.empty(n, h, w, cinp, dtype=torch.bfloat16, device=dy.device)
     name = "conv_igemm"

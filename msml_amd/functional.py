@@ -212,17 +212,10 @@ class _ConvTee(torch.autograd.Function):
         return ((dtee if g[0] is None else g[0]),) + tuple(g[1:])
 
 
-_UNIT_COEF = {}
-
-
 def _unit_coef(cp, device):
-    """(ones, zeros) f32 [cp]: unit scale / zero shift of a fused conv epilogue that only adds its residual."""
-    key = (cp, device)
-    u = _UNIT_COEF.get(key)
-    if u is None:
-        u = _UNIT_COEF[key] = (torch.ones(cp, dtype=torch.float32, device=device),
-                               torch.zeros(cp, dtype=torch.float32, device=device))
-    return u
+    """(ones, zeros) f32 [cp]: unit scale / zero shift of a fused conv epilogue that only adds its residual
+    (ops.unit_coef: one cache for every stream, filled host-synchronously)."""
+    return ops.unit_coef(cp, device)
 
 
 def conv_tee(x0, x1, weight, bias, cfg, wp=None):

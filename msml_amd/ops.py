@@ -186,6 +186,28 @@ def stats_acc(c, device, nq=2):
     return ACC_ARENA.get(c, device, nq)
 
 
+_UNIT_COEF = {}
+
+
+def unit_coef(cp, device):
+    """(ones, zeros) f32 [cp]: unit scale / zero shift of a fused conv epilogue that only adds its residual
+    (msml_conv2d_fused as "backward-data + another gradient").  Cached per (cp, device) and shared by EVERY stream:
+    the two constants are therefore filled through a host-synchronous copy -- a `torch.ones` on the creating stream is
+    ordered on that stream only, and the first OTHER stream to pick the cached tensors up (the OSB's GCM tee on its side
+    stream right after the FM tee on a backed-up main stream, or the reverse) could read them before the fill kernel
+    had run: a wrong first step, once per process (round 6: found through test_partial_fc_hip_two_ranks_one_gpu, whose
+    first backward of the process differed from its second in one run of three on a box shared by five processes).
+    Inside a graph capture nothing may synchronise: the constants are then created on the capturing stream and NOT cached."""
+    key = (cp, device)
+    u = _UNIT_COEF.get(key)
+    if u is None:
+        if torch.cuda.is_current_stream_capturing():
+            return (torch.ones(cp, dtype=torch.float32, device=device), torch.zeros(cp, dtype=torch.float32, device=device))
+        u = _UNIT_COEF[key] = (torch.ones(cp, dtype=torch.float32).to(device), torch.zeros(cp, dtype=torch.float32).to(device))
+        torch.cuda.current_stream(device).synchronize()      # (pageable H2D copies are synchronous already: belt and braces)
+    return u
+
+
 def conv_out_size(h, r, stride, pad, transposed, out_pad=0):
     if transposed:
         return (h - 1) * stride - 2 * pad + r + out_pad

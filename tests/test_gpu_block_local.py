@@ -32,7 +32,6 @@ from oracle import bf16_emul
 from oracle import model as om
 from oracle.fill import fill_module
 from oracle.inputs import eval_inputs
-from tests.helpers import rel_err
 
 pytestmark = pytest.mark.gpu
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}
@@ -100,9 +99,17 @@ def _nchw64(t, c, dev="cpu"):
 def _frac_beyond(got, want, tol):
     """Fraction of elements whose error exceeds tol x the largest reference element.  (A maximum over millions of
     elements is not a usable statistic behind a PReLU: where the pre-activation sits within a bf16 rounding of zero the
-    two sides take different branches and that element's gradient differs by (1 - alpha) x its incoming gradient.)"""
-    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
-    return float((np.abs(got - want) > tol * np.abs(want).max()).mean())
+    two sides take different branches and that element's gradient differs by (1 - alpha) x its incoming gradient.)
+    f64 torch tensors on one device (round 6: the comparisons run where the recomputation ran -- numpy on the host spent
+    more time on the 25-million-element maps than the recomputation itself)."""
+    if not isinstance(got, torch.Tensor):            # (tests/test_gpu_module_local.py passes numpy arrays)
+        got, want = torch.as_tensor(np.asarray(got, np.float64)), torch.as_tensor(np.asarray(want, np.float64))
+    return float(((got - want).abs() > tol * want.abs().max()).double().mean())
+
+
+def _rel(got, want):
+    """Norm-wise relative error ||got - want|| / ||want|| of two f64 tensors (tests.helpers.rel_err on the device)."""
+    return float((got - want).norm() / want.norm().clamp_min(1e-30))
 
 
 def _ref_block(kind, mod, dtype, dev="cpu"):
@@ -125,9 +132,9 @@ def _errors(got, want, terms):
     tens, chan = {}, {}
     for k, w in want.items():
         if k in terms:
-            chan[k] = float((np.abs(got[k] - w) / terms[k].clip(1e-300)).max())
+            chan[k] = float(((got[k] - w).abs() / terms[k].clamp_min(1e-300)).max())
         else:
-            tens[k] = (rel_err(got[k], w), _frac_beyond(got[k], w, ELEM_TOL))
+            tens[k] = (_rel(got[k], w), _frac_beyond(got[k], w, ELEM_TOL))
     return tens, chan
 
 
@@ -160,12 +167,12 @@ def _check_block_on(kind, name, mod, t, grads, dev):
 
             def bwd(g):
                 if isinstance(m, torch.nn.PReLU):
-                    terms[mname + ".weight"] = _np((g * z.clamp_max(0)).pow(2).sum((0, 2, 3)).sqrt())
+                    terms[mname + ".weight"] = (g * z.clamp_max(0)).pow(2).sum((0, 2, 3)).sqrt().double()
                 else:
                     mu = z.mean((0, 2, 3), keepdim=True)
                     xh = (z - mu) / (z.var((0, 2, 3), unbiased=False, keepdim=True) + m.eps).sqrt()
-                    terms[mname + ".bias"] = _np(g.pow(2).sum((0, 2, 3)).sqrt())
-                    terms[mname + ".weight"] = _np((g * xh).pow(2).sum((0, 2, 3)).sqrt())
+                    terms[mname + ".bias"] = g.pow(2).sum((0, 2, 3)).sqrt().double()
+                    terms[mname + ".weight"] = (g * xh).pow(2).sum((0, 2, 3)).sqrt().double()
             out.register_hook(bwd)
         hooks.append(m.register_forward_hook(fwd))
     for mname, m in ref.named_modules():
@@ -175,14 +182,14 @@ def _check_block_on(kind, name, mod, t, grads, dev):
     y64.backward(dout64)
     for h in hooks:
         h.remove()
-    want = {"dx": _np(x64.grad)}
+    want = {"dx": x64.grad.detach()}
     if t.get("out") is not None:           # the block's FORWARD output from the same input (train-mode statistics)
-        want["out"] = _np(y64)
-    want.update({pn: _np(p.grad) for pn, p in ref.named_parameters()})
-    got = {"dx": _nchw64(t["dx"], cin).numpy()}
+        want["out"] = y64.detach()
+    want.update({pn: p.grad.detach() for pn, p in ref.named_parameters()})
+    got = {"dx": _nchw64(t["dx"], cin, dev)}
     if "out" in want:
-        got["out"] = _nchw64(t["out"], cout).numpy()
-    got.update({pn: grads[prefix + pn].double().numpy() for pn in want if pn not in ("dx", "out")})
+        got["out"] = _nchw64(t["out"], cout, dev)
+    got.update({pn: grads[prefix + pn].to(dev).double() for pn in want if pn not in ("dx", "out")})
     h_tens, h_chan = _errors(got, want, terms)
     # the local bf16 floor: the same block, f32, under the rounding model, three draws
     f_tens, f_chan = {}, {}
@@ -196,10 +203,10 @@ def _check_block_on(kind, name, mod, t, grads, dev):
             ye.backward(dout64.float())
         finally:
             bf16_emul.GRID_SHIFT = 0.0
-        ge = {"dx": _np(bf16_emul._r(xe.grad).double())}
+        ge = {"dx": bf16_emul._r(xe.grad).double()}
         if "out" in want:
-            ge["out"] = _np(bf16_emul._r(ye.detach()).double())
-        ge.update({pn: _np(p.grad.double()) for pn, p in emu.named_parameters()})
+            ge["out"] = bf16_emul._r(ye.detach()).double()
+        ge.update({pn: p.grad.double() for pn, p in emu.named_parameters()})
         a, b = _errors(ge, want, terms)
         for k, (e, fr) in a.items():
             f_tens[k] = (max(f_tens.get(k, (0, 0))[0], e), max(f_tens.get(k, (0, 0))[1], fr))

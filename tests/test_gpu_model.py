@@ -544,6 +544,10 @@ def test_block_bn_inside_conv_is_bit_neutral(cfg):
     from msml_amd import ops
     from msml_amd.backbones.frb.iresnet import IBasicBlock
     n, cin, cout, h = cfg
+    from msml_amd import _lib as _l
+    if cin == 64 and not _l.value("msml_has_experiments"):
+        pytest.skip("the weights-stationary 64-channel kernel takes an input transform in experiment builds only "
+                    "(tools/experiments_run.sh)")
     torch.manual_seed(sum(cfg))
     blk = IBasicBlock(cin, cout, 1, None)
     for p in blk.parameters():

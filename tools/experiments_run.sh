@@ -13,5 +13,3 @@ echo "== variant tests (msml_has_experiments = 1)"
 python -m pytest tests/test_gpu_conv.py -q -m gpu -k "bn_in_lds or from_accumulator or backward_in_the_prologue or stride2_on_the_strip"
 echo "== halo conv tests with the half-stage weight ring (MSML_HALO_R15=1)"
 MSML_HALO_R15=1 python -m pytest tests/test_gpu_conv.py -q -m gpu -k "halo and not halo2"
-echo "== block function with the opt-in fusions on (MSML_BNBWD_IN=1 MSML_BNIN_ACC_WS=1)"
-MSML_BNBWD_IN=1 MSML_BNIN_ACC_WS=1 python -m pytest tests/test_gpu_model.py tests/test_gpu_block_local.py -q -m gpu -k "block_function or injected_fault"
