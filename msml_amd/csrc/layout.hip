@@ -334,6 +334,48 @@ __global__ void __launch_bounds__(256) k_stem_im2col(const float* __restrict__ x
   }
 }
 
+// The stems' own case (3 channels, 3x3, pad 1, KP = 32, W <= 128) through LDS (round 6): the gather above issues eight scattered
+// 4-B loads per 16-B store and ran at 1.9-2.1 TB/s (0.13 ms for the 243 MB of the FRB stem at batch 256, a quarter of which is
+// algorithmic).  Here a workgroup owns ROWS output rows of one image: the 3 x (ROWS * STRIDE + 2) input rows are loaded once,
+// coalesced, into an LDS tile with a zero halo (every input element crosses the memory system once per workgroup instead of
+// nine times), and every thread assembles (pixel, 8-k chunk) units from LDS -- consecutive threads store consecutive 16 B.
+template <typename T, int STRIDE>
+__global__ void __launch_bounds__(256) k_stem_im2col_lds(const float* __restrict__ x, T* __restrict__ out, int N, int H, int W,
+                                                         int P, int Q) {
+  constexpr int ROWS = 4, NR = (ROWS - 1) * STRIDE + 3, WMAX = 128;
+  __shared__ float tile[3][NR][WMAX + 2];
+  const int t = threadIdx.x;
+  const int tiles_y = (P + ROWS - 1) / ROWS;
+  const int n = blockIdx.x / tiles_y, oy0 = (blockIdx.x % tiles_y) * ROWS;
+  const int iy0 = oy0 * STRIDE - 1;
+  const float* xn = x + (long)n * 3 * H * W;
+  for (int i = t; i < 3 * NR * W; i += 256) {
+    const int c = i / (NR * W), rem = i - c * (NR * W), row = rem / W, ix = rem - row * W;
+    const int iy = iy0 + row;
+    tile[c][row][ix + 1] = ((unsigned)iy < (unsigned)H) ? xn[((long)c * H + iy) * W + ix] : 0.f;
+  }
+  for (int i = t; i < 3 * NR * 2; i += 256) {
+    const int c = i / (NR * 2), rem = i - c * (NR * 2), row = rem >> 1;
+    tile[c][row][(rem & 1) ? W + 1 : 0] = 0.f;
+  }
+  __syncthreads();
+  const int units = ROWS * Q * 4;
+  for (int i = t; i < units; i += 256) {
+    const int k0 = (i & 3) * 8, pix = i >> 2;
+    const int orow = pix / Q, ox = pix - orow * Q;
+    const int oy = oy0 + orow;
+    if (oy >= P) break;
+    Vec8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = k0 + j, tap = k / 3, c = k - tap * 3;
+      const int r = tap / 3, s2 = tap - r * 3;
+      v.v[j] = tap < 9 ? tile[c][orow * STRIDE + r][ox * STRIDE + s2] : 0.f;
+    }
+    store8<T>(out + (((long)n * P + oy) * Q + ox) * 32 + k0, v);
+  }
+}
+
 extern "C" int msml_stem_im2col(const float* x, void* out, int N, int C, int H, int W, int P, int Q, int R,
                                 int S, int stride, int pad, int KP, int dtype, void* stream) {
   MSML_CHECK(x && out && N > 0 && C > 0 && H > 0 && W > 0 && P > 0 && Q > 0 && R > 0 && S > 0 && stride > 0,
@@ -342,6 +384,20 @@ extern "C" int msml_stem_im2col(const float* x, void* out, int N, int C, int H, 
              R * S * C, KP);
   const long total = (long)N * P * Q * (KP / 8);
   const int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+  const bool no_lds = getenv("MSML_NO_STEM_LDS") != nullptr;      // A/B switch, read per call (the test compares both kernels)
+  if (!no_lds && C == 3 && R == 3 && S == 3 && pad == 1 && KP == 32 && W <= 128 && (stride == 1 || stride == 2) &&
+      P == (H + 2 - 3) / stride + 1 && Q == (W + 2 - 3) / stride + 1) {
+    const int lgrid = N * ((P + 3) / 4);
+    if (stride == 1) {
+      MSML_DISPATCH_DTYPE(dtype, "stem_im2col",
+                          (k_stem_im2col_lds<DT, 1>)<<<lgrid, 256, 0, (hipStream_t)stream>>>(x, (DT*)out, N, H, W, P, Q);)
+    } else {
+      MSML_DISPATCH_DTYPE(dtype, "stem_im2col",
+                          (k_stem_im2col_lds<DT, 2>)<<<lgrid, 256, 0, (hipStream_t)stream>>>(x, (DT*)out, N, H, W, P, Q);)
+    }
+    MSML_LAUNCH_OK("stem_im2col");
+    return MSML_OK;
+  }
   if (C == 3 && R == 3 && S == 3) {
     MSML_DISPATCH_DTYPE(dtype, "stem_im2col",
                         (k_stem_im2col<DT, 3, 3, 3>)<<<grid, 256, 0, (hipStream_t)stream>>>(x, (DT*)out, N, C, H, W, P,

@@ -1463,3 +1463,23 @@ def test_conv_halo_persistent_128_channel_tile(shape, monkeypatch):
     assert torch.allclose(a1.sum(0)[0].cpu(), ref.sum((0, 2, 3)), rtol=0, atol=1e-3 * ref.abs().max().item() * (n * h * w) ** 0.5)
     dref = F.conv_transpose2d(dy.double(), wt2.double(), None, 1, 1)
     assert (ops.to_nchw(dx1, c).cpu().double() - dref).abs().max().item() <= 1.5e-2 * dref.abs().max().item()
+
+
+# the stems' im2col through LDS (k_stem_im2col_lds) against the gather kernel it replaces: (N, H, W, stride) -- the two stems of
+# the step (112 x 112, stride 1 and 2), ragged row groups (P % 4 != 0), odd widths, one image
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(3, 112, 112, 1), (2, 112, 112, 2), (5, 30, 42, 1), (4, 30, 42, 2), (1, 7, 9, 1), (2, 13, 128, 2)])
+def test_stem_im2col_through_lds_is_the_gather(shape, dtype, monkeypatch):
+    n, h, w_, stride = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, 3, h, w_, generator=g).cuda()
+    dt = _lib.BF16 if dtype == "bf16" else _lib.F32
+    got = ops.stem_im2col(x, 3, 3, stride, 1, dtype=dt)
+    monkeypatch.setenv("MSML_NO_STEM_LDS", "1")
+    ref = ops.stem_im2col(x, 3, 3, stride, 1, dtype=dt)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    # and against unfold: k = (r * 3 + s) * 3 + c, zeros above k = 27
+    cols = F.unfold(x, 3, padding=1, stride=stride).view(n, 3, 9, -1).permute(0, 3, 2, 1).reshape(n, got.shape[1], got.shape[2], 27)
+    want = cols.bfloat16().float() if dtype == "bf16" else cols
+    assert torch.equal(got[..., :27].float(), want) and float(got[..., 27:].float().abs().max()) == 0.0
