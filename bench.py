@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # MI355X_MICROARCH.md (dense)
-ROUND = "r05"                                     # PMC summaries of OTHER rounds are never quoted (kernels change)
+ROUND = "r06"                                     # PMC summaries of OTHER rounds are never quoted (kernels change)
 # forward GFLOP per image (hooks on the imported reference); F_train = 3 x F_fwd (section 3)
 F_FWD_GF = {"iresnet18": 8.446, "iresnet34": 12.146, "iresnet50": 15.845, "iresnet100": 27.406}
 PEER_OFF = {"use_ori": False, "use_conv": False, "mask_trans": "conv", "use_decoder": False}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round PMC collection on the GPU box (each pass: --pmc only, the program itself after `--`).  Results under gpurun_out/.
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-.}"
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/pmc_$R
 rm -rf $O && mkdir -p $O
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/shapes/fetch -- python3 tools/pmc_shapes.py > $O/shapes_fetch.log 2>&1 || exit 1
