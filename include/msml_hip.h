@@ -240,6 +240,17 @@ int msml_bn_fin_bwd_apply(const void* dy, const void* x, const float* scale, con
                           int add_w, void* dx, void* dres, float* dgamma, float* dbeta, float* dalpha,
                           int accumulate, long M, int C, const void* next_x, const float* next_mean,
                           const float* next_invstd, double* next_acc, int dtype, void* stream);
+/* msml_bn_fin_bwd_apply whose NEXT BatchNorm is followed by a PReLU (round 6; the stems, iresnet.py:209-211 / unet.py:193-195:
+ * conv -> bn -> prelu -> first IBasicBlock's bn1): dx is the gradient of PReLU(next_x * next_scale + next_shift) and next_acc
+ * receives that BatchNorm's three sums (sum g', sum g' * xhat, sum dx * min(z, 0); g' = dx through the PReLU mask), so the
+ * stem's own backward is an apply pass only (msml_bn_fin_bwd_apply with next_acc as its `acc`). */
+int msml_bn_fin_bwd_apply_next_act(const void* dy, const void* x, const float* scale, const float* shift,
+                                   const float* alpha, const float* save_mean, const float* save_invstd,
+                                   const double* acc, const void* residual_first, const void* add, int add_h,
+                                   int add_w, void* dx, void* dres, float* dgamma, float* dbeta, float* dalpha,
+                                   int accumulate, long M, int C, const void* next_x, const float* next_scale,
+                                   const float* next_shift, const float* next_alpha, const float* next_mean,
+                                   const float* next_invstd, double* next_acc, int dtype, void* stream);
 int msml_bn_act_bwd_acc(const void* dy, const void* x, const float* scale, const float* shift,
                         const float* alpha, const float* save_mean, const float* save_invstd,
                         const void* residual_first, const void* add, void* dx, void* dres, float* dgamma,

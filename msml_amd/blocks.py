@@ -300,9 +300,15 @@ def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None, add_s2=Fa
         if nxt is not None and 256 % (c // 8) == 0:
             nacc = ops.stats_acc(c, x.device, 3)
             with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (5 if add is not None else 4)):
-                call("msml_bn_fin_bwd_apply", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial, None, add, ah, aw,
-                     dx, None, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, nxt[0], nxt[1][2], nxt[1][3],
-                     nacc, BF16)
+                if len(nxt) > 2 and nxt[2] is not None:
+                    # the NEXT BatchNorm is followed by a PReLU (a stem): its sums through the PReLU mask
+                    call("msml_bn_fin_bwd_apply_next_act", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial, None, add,
+                         ah, aw, dx, None, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, nxt[0], nxt[1][0],
+                         nxt[1][1], nxt[2], nxt[1][2], nxt[1][3], nacc, BF16)
+                else:
+                    call("msml_bn_fin_bwd_apply", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], partial, None, add, ah, aw,
+                         dx, None, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, nxt[0], nxt[1][2], nxt[1][3],
+                         nacc, BF16)
             pgr.done()
             return dx, nacc
         with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (4 if add is not None else 3)):
@@ -310,7 +316,9 @@ def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None, add_s2=Fa
                  dx, None, pgr.tg[0], pgr.tg[1], pgr.tg[2], int(pgr.inplace), m, c, None, None, None, None, BF16)
     else:
         cw = torch.empty(98 * c, dtype=torch.float32, device=x.device)
-        if nxt is not None and 256 % (c // 8) == 0:
+        if nxt is not None and len(nxt) > 2 and nxt[2] is not None:
+            nxt = ()            # (partial-row protocol: no PReLU-aware NEXT kernel -- the stem reduces its own sums)
+        if nxt and 256 % (c // 8) == 0:
             npart = torch.empty(_lib.value("msml_bn_act_bwd_apply_rows", m, c), 3, c, dtype=torch.float32,
                                 device=x.device)
             with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * (5 if add is not None else 4)):
@@ -447,7 +455,10 @@ def _iblock_fwd_fast(x, bp, xstats):
 
 class _IBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bp, xstats, pc2, pk3, *params):
+    def forward(ctx, x, bp, xstats, pc2, pk3, palpha, *params):
+        # (pc2, pk3, palpha): saved input, coefficients and PReLU slope (None: no activation) of the BatchNorm that
+        # produced x -- the previous block's bn3, or a stem's bn + prelu
+        ctx.palpha = palpha
         if _iblock_fwd_applies(x, bp):
             fast = _iblock_fwd_fast(x, bp, xstats)
             if fast is not None:
@@ -547,7 +558,7 @@ class _IBlock(torch.autograd.Function):
         g1 = _ParamGrads((bn1[0], bn1[1], None), x.shape[-1], dev)
         if pc2 is not None and part1 is not None and ops.FUSE_BN_BWD:
             # x is the previous block's output: reduce its bn3 sums while writing its output gradient
-            dx, pprev = _bn_bwd(do1, x, k1, None, g1, part1, add=join, nxt=(pc2, pk3), add_s2=join_s2)
+            dx, pprev = _bn_bwd(do1, x, k1, None, g1, part1, add=join, nxt=(pc2, pk3, ctx.palpha), add_s2=join_s2)
             if pprev is not None:
                 dx._msml_bn3_partial = pprev
         else:
@@ -558,7 +569,7 @@ class _IBlock(torch.autograd.Function):
         grads += [g1.out(0), g1.out(1), g2.out(0), g2.out(1), g2.out(2), g3.out(0), g3.out(1)]
         if ds is not None:
             grads += [gd.out(0), gd.out(1)]
-        return (dx, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None) + tuple(grads)
 
 
 def iblock(blk, x):
@@ -577,7 +588,8 @@ def iblock(blk, x):
         blk.__dict__["_msml_pack"] = bp       # (plain attribute: not a module / parameter registration)
     xd = x.__dict__ if hasattr(x, "__dict__") else {}
     xstats, prev = xd.get("_msml_stats"), xd.get("_msml_bn3")
-    out, ostats = _IBlock.apply(x, bp, xstats, prev[0] if prev else None, prev[1] if prev else None, *bp["params"])
+    out, ostats = _IBlock.apply(x, bp, xstats, prev[0] if prev else None, prev[1] if prev else None,
+                                prev[2] if prev and len(prev) > 2 else None, *bp["params"])
     last = bp.pop("_last_bn3", None)
     if ostats.numel():
         out._msml_stats = ostats           # read by the next block (same tensor object in nn.Sequential)

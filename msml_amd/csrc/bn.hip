@@ -706,7 +706,10 @@ extern "C" int msml_bn_act_bwd(const void* dy, const void* x, const float* scale
 // atomics of the producer: a backward-data conv's fused epilogue, the NEXT pass of another apply, or k_bn_bwd_reduce),
 // every workgroup folds them and keeps k1 = s0 / n, k2 = s1 / n of all channels in LDS, workgroup 0 writes the
 // parameter gradients.  NEXT / ADD_S2 as in k_bn_bwd_apply; NEXT adds into nacc (zero-initialised, same format).
-template <typename T, bool NEXT, bool ADD_S2>
+// NACT (round 6): the NEXT BatchNorm is followed by a PReLU (the stems: conv -> bn -> prelu, iresnet.py:209-211,
+// unet.py:193-195, whose output the first IBasicBlock's bn1 normalises): its three sums are formed through the PReLU
+// mask of z = nx * nscale + nshift -- sum g', sum g' * xhat, sum dx * min(z, 0) with g' = dx * (z > 0 ? 1 : nalpha).
+template <typename T, bool NEXT, bool ADD_S2, bool NACT = false>
 __global__ void __launch_bounds__(256) k_bn_fin_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ alpha, const float* __restrict__ mean,
@@ -718,7 +721,10 @@ __global__ void __launch_bounds__(256) k_bn_fin_bwd_apply(const T* __restrict__ 
                                                           T* __restrict__ dres, long n8, int C8,
                                                           const T* __restrict__ nx, const float* __restrict__ nmean,
                                                           const float* __restrict__ ninvstd, double* __restrict__ nacc,
-                                                          int aH, int aW) {
+                                                          int aH, int aW, const float* __restrict__ nscale = nullptr,
+                                                          const float* __restrict__ nshift = nullptr,
+                                                          const float* __restrict__ nalpha = nullptr) {
+  static_assert(!NACT || NEXT, "NACT qualifies the NEXT BatchNorm");
   extern __shared__ float ck[];                        // [2][C]: k1, k2
   const int C = C8 * 8, t = threadIdx.x;
   MSML_LDS_REGION(ck, 2 * C * 4);
@@ -752,9 +758,13 @@ __global__ void __launch_bounds__(256) k_bn_fin_bwd_apply(const T* __restrict__ 
   const float rcpW = ADD_S2 ? 1.0f / (float)aW : 0.f, rcpH = ADD_S2 ? 1.0f / (float)aH : 0.f;
   const int aPw = (aW + 1) >> 1, aPh = (aH + 1) >> 1;
   const Coef8 nmu = ldc8(NEXT ? nmean : nullptr, c0, 0.f), nis = ldc8(NEXT ? ninvstd : nullptr, c0, 1.f);
-  float nq0[8], nq1[8];
+  const Coef8 nsc = ldc8(NACT ? nscale : nullptr, c0, 1.f), nsh = ldc8(NACT ? nshift : nullptr, c0, 0.f),
+              nal = ldc8(NACT ? nalpha : nullptr, c0, 1.f);
+  float nq0[8], nq1[8], nq2[NACT ? 8 : 1];
 #pragma unroll
   for (int j = 0; j < 8; j++) nq0[j] = nq1[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < (NACT ? 8 : 1); j++) nq2[j] = 0.f;
   for (long i = tid; i < n8; i += (long)gridDim.x * blockDim.x) {
     Vec8 g = load8<T>(dy + i * 8);
     Vec8 v = load8<T>(x + i * 8);
@@ -791,20 +801,30 @@ __global__ void __launch_bounds__(256) k_bn_fin_bwd_apply(const T* __restrict__ 
       const Vec8 o = round8<T>(v), xn = load8<T>(nx + i * 8);
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        nq0[j] += o.v[j];
-        nq1[j] += o.v[j] * ((xn.v[j] - nmu.v[j]) * nis.v[j]);
+        float gn = o.v[j];
+        if (NACT) {
+          const float z = xn.v[j] * nsc.v[j] + nsh.v[j];
+          if (z <= 0.f) {
+            nq2[j] += gn * z;
+            gn *= nal.v[j];
+          }
+        }
+        nq0[j] += gn;
+        nq1[j] += gn * ((xn.v[j] - nmu.v[j]) * nis.v[j]);
       }
     }
   }
   if (NEXT) {
-    __shared__ float red[2][256][9];
+    constexpr int NQN = NACT ? 3 : 2;
+    __shared__ float red[NQN][256][9];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       red[0][t][j] = nq0[j];
       red[1][t][j] = nq1[j];
+      if (NACT) red[NQN - 1][t][j] = nq2[j];
     }
     __syncthreads();
-    for (int i = t; i < 2 * C; i += 256) {
+    for (int i = t; i < NQN * C; i += 256) {
       const int q = i / C, c = i % C, cx = c >> 3, j = c & 7;
       float sum = 0.f;
       for (int k = cx; k < 256; k += C8) sum += red[q][k][j];
@@ -815,12 +835,13 @@ __global__ void __launch_bounds__(256) k_bn_fin_bwd_apply(const T* __restrict__ 
 
 // residual_first / dres: the PReLU-after-the-sum form of msml_bn_act_bwd (res_first blocks); add / add_h / add_w, next_*:
 // as msml_bn_act_bwd_apply[_next][_s2].  acc: double[8][3][C] filled by the producer; next_acc: zero-initialised.
-extern "C" int msml_bn_fin_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
-                                     const float* alpha, const float* save_mean, const float* save_invstd,
-                                     const double* acc, const void* residual_first, const void* add, int add_h,
-                                     int add_w, void* dx, void* dres, float* dgamma, float* dbeta, float* dalpha,
-                                     int accumulate, long M, int C, const void* next_x, const float* next_mean,
-                                     const float* next_invstd, double* next_acc, int dtype, void* stream) {
+static int bn_fin_bwd_apply_impl(const void* dy, const void* x, const float* scale, const float* shift,
+                                 const float* alpha, const float* save_mean, const float* save_invstd,
+                                 const double* acc, const void* residual_first, const void* add, int add_h,
+                                 int add_w, void* dx, void* dres, float* dgamma, float* dbeta, float* dalpha,
+                                 int accumulate, long M, int C, const void* next_x, const float* next_mean,
+                                 const float* next_invstd, double* next_acc, const float* next_scale,
+                                 const float* next_shift, const float* next_alpha, int dtype, void* stream) {
   MSML_CHECK(dy && x && dx && scale && shift && save_mean && save_invstd && acc && M > 0 && C > 0 && C % 8 == 0,
              MSML_ERR_SHAPE, "bn_fin_bwd_apply: bad args M=%ld C=%d", M, C);
   MSML_CHECK(256 % (C / 8) == 0, MSML_ERR_UNSUPPORTED, "bn_fin_bwd_apply: C/8 = %d must divide 256", C / 8);
@@ -836,12 +857,48 @@ extern "C" int msml_bn_fin_bwd_apply(const void* dy, const void* x, const float*
       (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, acc, (double)M, dgamma, dbeta, dalpha, \
       accumulate, (const DT*)residual_first, (const DT*)add, (DT*)dx, (DT*)dres, n8, C / 8, (const DT*)next_x,      \
       next_mean, next_invstd, next_acc, add_h, add_w);
+#define BN_FIN_LAUNCH_ACT(S2_)                                                                                      \
+  (k_bn_fin_bwd_apply<DT, true, S2_, true>)<<<ew_grid_c(n8, C / 8), 256, lds, st>>>(                                \
+      (const DT*)dy, (const DT*)x, scale, shift, alpha, save_mean, save_invstd, acc, (double)M, dgamma, dbeta, dalpha, \
+      accumulate, (const DT*)residual_first, (const DT*)add, (DT*)dx, (DT*)dres, n8, C / 8, (const DT*)next_x,      \
+      next_mean, next_invstd, next_acc, add_h, add_w, next_scale, next_shift, next_alpha);
+  const bool nact = next_acc && next_alpha;
+  MSML_CHECK(!nact || (next_scale && next_shift), MSML_ERR_SHAPE, "bn_fin_bwd_apply: next_scale / next_shift missing");
   MSML_DISPATCH_DTYPE(dtype, "bn_fin_bwd_apply",
-                      if (next_acc) { if (s2) { BN_FIN_LAUNCH(true, true) } else { BN_FIN_LAUNCH(true, false) } }
+                      if (nact) { if (s2) { BN_FIN_LAUNCH_ACT(true) } else { BN_FIN_LAUNCH_ACT(false) } }
+                      else if (next_acc) { if (s2) { BN_FIN_LAUNCH(true, true) } else { BN_FIN_LAUNCH(true, false) } }
                       else { if (s2) { BN_FIN_LAUNCH(false, true) } else { BN_FIN_LAUNCH(false, false) } })
 #undef BN_FIN_LAUNCH
+#undef BN_FIN_LAUNCH_ACT
   MSML_LAUNCH_OK("bn_fin_bwd_apply");
   return MSML_OK;
+}
+
+extern "C" int msml_bn_fin_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
+                                     const float* alpha, const float* save_mean, const float* save_invstd,
+                                     const double* acc, const void* residual_first, const void* add, int add_h,
+                                     int add_w, void* dx, void* dres, float* dgamma, float* dbeta, float* dalpha,
+                                     int accumulate, long M, int C, const void* next_x, const float* next_mean,
+                                     const float* next_invstd, double* next_acc, int dtype, void* stream) {
+  return bn_fin_bwd_apply_impl(dy, x, scale, shift, alpha, save_mean, save_invstd, acc, residual_first, add, add_h, add_w, dx,
+                               dres, dgamma, dbeta, dalpha, accumulate, M, C, next_x, next_mean, next_invstd, next_acc,
+                               nullptr, nullptr, nullptr, dtype, stream);
+}
+
+// msml_bn_fin_bwd_apply whose NEXT BatchNorm is followed by a PReLU (next_alpha != null): the written dx is the gradient of
+// PReLU(next_x * next_scale + next_shift), and next_acc receives all three sums of that BatchNorm + PReLU.
+extern "C" int msml_bn_fin_bwd_apply_next_act(const void* dy, const void* x, const float* scale, const float* shift,
+                                              const float* alpha, const float* save_mean, const float* save_invstd,
+                                              const double* acc, const void* residual_first, const void* add, int add_h,
+                                              int add_w, void* dx, void* dres, float* dgamma, float* dbeta, float* dalpha,
+                                              int accumulate, long M, int C, const void* next_x, const float* next_scale,
+                                              const float* next_shift, const float* next_alpha, const float* next_mean,
+                                              const float* next_invstd, double* next_acc, int dtype, void* stream) {
+  MSML_CHECK(next_x && next_scale && next_shift && next_alpha && next_mean && next_invstd && next_acc, MSML_ERR_SHAPE,
+             "bn_fin_bwd_apply_next_act: next_* incomplete");
+  return bn_fin_bwd_apply_impl(dy, x, scale, shift, alpha, save_mean, save_invstd, acc, residual_first, add, add_h, add_w, dx,
+                               dres, dgamma, dbeta, dalpha, accumulate, M, C, next_x, next_mean, next_invstd, next_acc,
+                               next_scale, next_shift, next_alpha, dtype, stream);
 }
 
 // msml_bn_act_bwd (no producer-side sums): reduce pass into the accumulator, then the fused finalize + apply

@@ -254,8 +254,8 @@ class _BnAct(torch.autograd.Function):
             ctx.params = (gamma, beta, alpha)
             ctx.save_for_backward(x, coef, alpha, residual if ctx.res_first else None)
             if emit:
-                ctx.mark_non_differentiable(yacc)
-                return y, yacc
+                ctx.mark_non_differentiable(yacc, coef)
+                return y, yacc, coef
             return y
         if training:
             if stats is None:
@@ -303,6 +303,22 @@ class _BnAct(torch.autograd.Function):
             tg = [prm.grad if w else None for w, prm in zip(want, (gamma, beta, alpha_p))]
         else:
             tg = [pg[0], pg[1], pg[2] if alpha is not None else None]
+        # the three sums may already sit in an accumulator: the first IBasicBlock's bn1 apply kernel, which WROTE this dy,
+        # reduced them on the way (blocks._bn_bwd with nxt = (x, coef, alpha); msml_bn_fin_bwd_apply_next_act).  The
+        # attribute travels on the gradient tensor object, as blocks' `_msml_bn3_partial` does between chained blocks.
+        part = dy.__dict__.pop("_msml_bn3_partial", None)
+        if part is not None and part.dtype == torch.float64 and not ctx.res_first and ops.acc_applies(c, dtype):
+            ops.COUNTERS["bn3_partial_hits"] += 1
+            with ops.PROFILE.rec("bn_act_bwd_apply", 0.0, x.numel() * x.element_size() * 3):
+                call("msml_bn_fin_bwd_apply", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], part, None, None, 0, 0, dx,
+                     None, tg[0], tg[1], tg[2], int(inplace), m, c, None, None, None, None, dtype)
+            if inplace:
+                ops.grad_ready(*[prm for w, prm in zip(want, (gamma, beta, alpha_p)) if w])
+            return (dx, None,
+                    pg[0] if want[0] and not inplace else None,
+                    pg[1] if want[1] and not inplace else None,
+                    pg[2] if want[2] and not inplace else None,
+                    dy if has_r else None, None, None, None, None, None, None, None)
         with ops.PROFILE.rec("bn_act_bwd", 0.0, x.numel() * x.element_size() * (5 + (3 if ctx.res_first else 0))):
             if ops.acc_applies(c, dtype):
                 call("msml_bn_act_bwd_acc", dy, x, coef[0], coef[1], alpha, coef[2], coef[3], res, None, dx, dres,
@@ -338,8 +354,12 @@ def bn_act(x, stats, bn, prelu=None, residual=None, res_first=False, emit_stats=
                        residual, bn.running_mean, bn.running_var, training,
                        0.1 if bn.momentum is None else bn.momentum, bn.eps, res_first, emit)
     if emit:
-        y, yacc = out
+        y, yacc, coef = out
         y._msml_stats = yacc
+        # (for the one-node IBasicBlock that follows -- blocks.iblock: its bn1 apply kernel writes THIS BatchNorm's output
+        # gradient and can reduce this BatchNorm's backward sums on the way, PReLU mask included)
+        if residual is None and ops.STEM_BWD_SUMS:
+            y._msml_bn3 = (x, coef, prelu.weight if prelu is not None else None)
         return y
     return out
 
@@ -417,9 +437,12 @@ def fanout2(x):
     if (torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad and x.is_cuda
             and x.dtype in DTYPE_OF):
         a, b = _FanOut2.apply(x)
-        for k in ("_msml_stats", "_msml_bn3"):          # (what a producer attached for a following IBasicBlock: the first
-            if k in x.__dict__:                         # branch is the one that continues the backbone)
-                a.__dict__[k] = x.__dict__[k]
+        # what a producer attached for a following IBasicBlock (the first branch is the one that continues the backbone):
+        # the forward statistics of x.  NOT `_msml_bn3` (round 6): the block behind a fan-out sees only ITS share of x's
+        # gradient, so the sums it would reduce for x's BatchNorm while writing that share are not that BatchNorm's sums
+        # -- they were dropped at the msml_add above anyway, after costing the block's apply kernel another input stream
+        if "_msml_stats" in x.__dict__:
+            a.__dict__["_msml_stats"] = x.__dict__["_msml_stats"]
         return a, b
     return x, x
 

@@ -490,6 +490,9 @@ FUSE_BN_BWD = os.environ.get("MSML_NO_FUSE_BN_BWD") is None
 BLOCK_C_ENTRY = os.environ.get("MSML_BLOCK_C_ENTRY") is not None
 # The stem's BatchNorm + PReLU pass also emits the statistics of its output for layer1's first bn1 (no bn_stats pass)
 EMIT_STEM_STATS = os.environ.get("MSML_NO_EMIT_STEM_STATS") is None
+# ... and in the backward the first block's bn1 apply kernel reduces the stem BatchNorm's three sums while it writes that
+# BatchNorm's output gradient (round 6: the stem's own backward is then an apply pass, 3 streams instead of 5)
+STEM_BWD_SUMS = os.environ.get("MSML_NO_STEM_BWD_SUMS") is None
 # FMCnn: the two gradients of the stage input (same_conv path + act / arith / skip path) summed in same_conv's backward-data
 # epilogue instead of by autograd's fan-out add
 FM_TEE = os.environ.get("MSML_NO_FM_TEE") is None

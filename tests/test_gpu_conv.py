@@ -1483,3 +1483,49 @@ def test_stem_im2col_through_lds_is_the_gather(shape, dtype, monkeypatch):
     cols = F.unfold(x, 3, padding=1, stride=stride).view(n, 3, 9, -1).permute(0, 3, 2, 1).reshape(n, got.shape[1], got.shape[2], 27)
     want = cols.bfloat16().float() if dtype == "bf16" else cols
     assert torch.equal(got[..., :27].float(), want) and float(got[..., 27:].float().abs().max()) == 0.0
+
+
+# msml_bn_fin_bwd_apply_next_act (round 6): the apply pass that writes dx ALSO reduces the three backward sums of the BatchNorm
+# + PReLU that produced its input tensor (a stem in front of the first IBasicBlock): (M pixels, C, stride-2 compact add)
+@pytest.mark.parametrize("s2", [False, True])
+@pytest.mark.parametrize("shape", [(2 * 56 * 56, 64), (3 * 28 * 28, 64), (5 * 14 * 14, 128)])
+def test_bn_backward_apply_reduces_the_sums_of_a_stem_in_front_of_it(shape, s2):
+    m, c = shape
+    n = {2 * 56 * 56: 2, 3 * 28 * 28: 3, 5 * 14 * 14: 5}[m]
+    h = int(round((m // n) ** 0.5))
+    g = torch.Generator().manual_seed(m + c + int(s2))
+    rnd = lambda *s: torch.randn(*s, generator=g)       # noqa: E731
+    dy = rnd(m, c).cuda().bfloat16()
+    x = (rnd(m, c) * 1.3 + 0.2).cuda().bfloat16()                          # input of THIS BatchNorm = output of the stem's PReLU
+    coef = torch.stack([torch.rand(c, generator=g) + 0.5, rnd(c) * 0.3, rnd(c) * 0.2, torch.rand(c, generator=g) + 0.5]).cuda()
+    acc = (torch.randn(8, 3, c, generator=g, dtype=torch.float64) * (m ** 0.5) / 8).cuda()
+    nx = (rnd(m, c) * 0.9 - 0.1).cuda().bfloat16()                         # saved input of the stem's BatchNorm
+    ncoef = torch.stack([torch.rand(c, generator=g) + 0.5, rnd(c) * 0.4, rnd(c) * 0.2, torch.rand(c, generator=g) + 0.5]).cuda()
+    nalpha = (torch.rand(c, generator=g) * 0.4).cuda()
+    add = None
+    ah = aw = 0
+    if s2:                       # the compact gradient of a 1x1 / stride-2 downsample joins at the even pixels
+        add = rnd(n * (h // 2) * (h // 2), c).cuda().bfloat16()
+        ah = aw = h
+
+    def run(fn, *extra):
+        dx = torch.empty_like(x)
+        pg = torch.zeros(3, c, device="cuda")
+        nacc = torch.zeros(8, 3, c, dtype=torch.float64, device="cuda")
+        _lib.call(fn, dy, x, coef[0], coef[1], None, coef[2], coef[3], acc, None, add, ah, aw, dx, None, pg[0], pg[1], None, 0,
+                  m, c, nx, *extra, nacc, _lib.BF16)
+        torch.cuda.synchronize()
+        return dx, pg, nacc
+    dx_a, pg_a, nacc_a = run("msml_bn_fin_bwd_apply", ncoef[2], ncoef[3])                                      # activation-free NEXT
+    dx_b, pg_b, nacc_b = run("msml_bn_fin_bwd_apply_next_act", ncoef[0], ncoef[1], nalpha, ncoef[2], ncoef[3])
+    assert torch.equal(dx_a, dx_b) and torch.equal(pg_a, pg_b)             # the apply itself is the same arithmetic
+    # the three sums through the PReLU mask, from the dx the kernel wrote, in f64
+    gq, xn = dx_b.double(), nx.double()
+    z = nx.float() * ncoef[0] + ncoef[1]
+    neg = z <= 0
+    gp = torch.where(neg, gq * nalpha.double(), gq)
+    xh = (nx.float() - ncoef[2]) * ncoef[3]
+    want = torch.stack((gp.sum(0), (gp * xh.double()).sum(0), torch.where(neg, gq * z.double(), torch.zeros_like(gq)).sum(0)))
+    got = nacc_b.sum(0)
+    assert torch.allclose(got, want, rtol=2e-3, atol=2e-3 * want.abs().max().item()), (got - want).abs().max()
+    assert float(nacc_a[:, 2].abs().max()) == 0.0 and float(nacc_b[:, 2].abs().max()) > 0.0

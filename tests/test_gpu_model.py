@@ -403,6 +403,45 @@ def test_side_streams_match_serial():
     assert torch.equal(a, b)
 
 
+def test_stem_backward_sums_from_the_first_block_match_the_stems_own_reduce(monkeypatch):
+    """Round 6: the first IBasicBlock's bn1 apply kernel reduces the stem BatchNorm's three backward sums (through the
+    stem's PReLU mask) while it writes that BatchNorm's output gradient (msml_bn_fin_bwd_apply_next_act); the stem's own
+    backward is then an apply pass.  Against the step with the stem's own reduce pass (ops.STEM_BWD_SUMS off): every
+    gradient the same to the order of the f32 partial sums -- the stems' conv / BatchNorm / PReLU gradients included --
+    and the FRB's stem (112 x 112) really took the short path.  (The OSB's stem output feeds layer1 AND gcm1 -- a fan-out,
+    functional.fanout2 -- so the first OSB block sees only part of its gradient and that stem keeps its own reduce.)"""
+    from msml_amd import ops
+    from msml_amd.optim import FlatSGD, reference_param_groups
+    x, msk = eval_inputs(8)
+    label = synthetic.labels(8, 50, seed=1)
+
+    def grads(on):
+        monkeypatch.setattr(ops, "STEM_BWD_SUMS", on)
+        m = hip_msml("iresnet18", 50, fp16=True).train()
+        opt = FlatSGD(reference_param_groups(m, 8, 1), 0.9, 5e-4, 5.0)
+        hits0 = ops.COUNTERS["bn3_partial_hits"]
+        try:
+            opt.zero_grad()
+            cls, seg, _ = m(x.cuda(), label.cuda())
+            loss = torch.nn.functional.cross_entropy(cls, label.cuda()) + \
+                StructureConsensuLossFunction(10.0, 5.0)(seg, msk.cuda(), msk.cuda())
+            loss.backward()
+            ops.wgrad_stream_join()
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().float().cpu().numpy().copy() for n, p in m.named_parameters() if p.grad is not None}, \
+                ops.COUNTERS["bn3_partial_hits"] - hits0
+        finally:
+            opt.release()
+    a, hits_a = grads(False)
+    b, hits_b = grads(True)
+    assert hits_b == hits_a + 1                                  # the FRB's stem
+    for n in a:
+        assert rel_err(b[n], a[n]) < 2e-3, (n, rel_err(b[n], a[n]))
+    for n in ("frb.conv1.weight", "frb.bn1.weight", "frb.bn1.bias", "frb.prelu.weight", "osb.conv1.weight", "osb.bn1.weight",
+              "osb.prelu.weight"):
+        assert n in a and np.abs(a[n]).max() > 0, n
+
+
 def test_side_streams_switched_on_mid_run():
     """Serial steps first, then the side streams are switched on (what bench.py does): the scratch
     workspaces grow during the first multi-stream steps, and a buffer dropped on growth must not be
