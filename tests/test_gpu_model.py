@@ -404,9 +404,9 @@ def test_side_streams_match_serial():
 
 
 def test_stem_backward_sums_from_the_first_block_match_the_stems_own_reduce(monkeypatch):
-    """Round 6: the first IBasicBlock's bn1 apply kernel reduces the stem BatchNorm's three backward sums (through the
-    stem's PReLU mask) while it writes that BatchNorm's output gradient (msml_bn_fin_bwd_apply_next_act); the stem's own
-    backward is then an apply pass.  Against the step with the stem's own reduce pass (ops.STEM_BWD_SUMS off): every
+    """Round 6 (opt-in, ops.STEM_BWD_SUMS / MSML_STEM_BWD_SUMS=1: measured not faster, ops.py): the first IBasicBlock's bn1
+    apply kernel reduces the stem BatchNorm's three backward sums (through the stem's PReLU mask) while it writes that
+    BatchNorm's output gradient (msml_bn_fin_bwd_apply_next_act); the stem's own backward is then an apply pass.  Against the step with the stem's own reduce pass (ops.STEM_BWD_SUMS off): every
     gradient the same to the order of the f32 partial sums -- the stems' conv / BatchNorm / PReLU gradients included --
     and the FRB's stem (112 x 112) really took the short path.  (The OSB's stem output feeds layer1 AND gcm1 -- a fan-out,
     functional.fanout2 -- so the first OSB block sees only part of its gradient and that stem keeps its own reduce.)"""
