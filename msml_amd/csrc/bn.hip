@@ -864,6 +864,11 @@ static int bn_fin_bwd_apply_impl(const void* dy, const void* x, const float* sca
       next_mean, next_invstd, next_acc, add_h, add_w, next_scale, next_shift, next_alpha);
   const bool nact = next_acc && next_alpha;
   MSML_CHECK(!nact || (next_scale && next_shift), MSML_ERR_SHAPE, "bn_fin_bwd_apply: next_scale / next_shift missing");
+#ifndef MSML_EXPERIMENTS     // (measured not faster, msml_amd/ops.py STEM_BWD_SUMS: instantiated in experiment builds only)
+  MSML_CHECK(!nact, MSML_ERR_UNSUPPORTED, "bn_fin_bwd_apply_next_act: experiment builds only (msml_has_experiments)");
+#undef BN_FIN_LAUNCH_ACT
+#define BN_FIN_LAUNCH_ACT(S2_)
+#endif
   MSML_DISPATCH_DTYPE(dtype, "bn_fin_bwd_apply",
                       if (nact) { if (s2) { BN_FIN_LAUNCH_ACT(true) } else { BN_FIN_LAUNCH_ACT(false) } }
                       else if (next_acc) { if (s2) { BN_FIN_LAUNCH(true, true) } else { BN_FIN_LAUNCH(true, false) } }

@@ -495,8 +495,10 @@ EMIT_STEM_STATS = os.environ.get("MSML_NO_EMIT_STEM_STATS") is None
 # instead of 5).  Measured, interleaved on one box (20 steps each, one-stream event pass): BatchNorm family 7.575 / 7.635 ms
 # without, 7.644 ms with -- the stem's reduce + apply leaves `bn_act_bwd` (1.76 -> 1.39 ms) and comes back in `bn_act_bwd_apply`
 # (3.04 -> 3.48): the 112 x 112 apply kernel with the compact stride-2 add, the NEXT sums AND the PReLU mask is no longer
-# byte-bound (it ran at 6.8 TB/s before).  Step 29.49 / 30.71 without, 29.90 / 30.68 with.  Opt-in: MSML_STEM_BWD_SUMS=1.
-STEM_BWD_SUMS = os.environ.get("MSML_STEM_BWD_SUMS") is not None
+# byte-bound (it ran at 6.8 TB/s before).  Step 29.49 / 30.71 without, 29.90 / 30.68 with.  Opt-in: MSML_STEM_BWD_SUMS=1
+# on an experiment build.
+# (the kernel variant is instantiated in experiment builds only: tools/build_variant.py --all MSML_EXPERIMENTS)
+STEM_BWD_SUMS = bool(os.environ.get("MSML_STEM_BWD_SUMS")) and bool(_lib.value("msml_has_experiments"))
 # FMCnn: the two gradients of the stage input (same_conv path + act / arith / skip path) summed in same_conv's backward-data
 # epilogue instead of by autograd's fan-out add
 FM_TEE = os.environ.get("MSML_NO_FM_TEE") is None

@@ -1490,6 +1490,7 @@ def test_stem_im2col_through_lds_is_the_gather(shape, dtype, monkeypatch):
 @pytest.mark.parametrize("s2", [False, True])
 @pytest.mark.parametrize("shape", [(2 * 56 * 56, 64), (3 * 28 * 28, 64), (5 * 14 * 14, 128)])
 def test_bn_backward_apply_reduces_the_sums_of_a_stem_in_front_of_it(shape, s2):
+    needs_experiments()                   # (measured not faster, msml_amd/ops.py STEM_BWD_SUMS: not in the shipped library)
     m, c = shape
     n = {2 * 56 * 56: 2, 3 * 28 * 28: 3, 5 * 14 * 14: 5}[m]
     h = int(round((m // n) ** 0.5))
