@@ -814,7 +814,13 @@ k_conv_halo(const ConvHaloArgs p) {
 // Same tiling, fragment maps and per-tile arithmetic as k_conv_halo<128, 2, FUSE, ..., M16>: outputs are bit-identical,
 // the sums differ in the order the tiles are added.  Plain forward (+ accumulator-mode statistics) and backward-data with
 // the fused BatchNorm sums (accumulator mode; register layout of -DHALO_FDIR); coutp == 128.
-template <bool FUSE>
+// XF (round 6): the forward launch whose input is PReLU(BatchNorm(in)) with the coefficients derived from the producer's
+// f64 sums in the prologue (msml_conv2d_bnin_acc): every wave normalises the image chunks it requested itself, one or two
+// taps after the request (its own vmcnt wait orders them; the slab-switch barrier publishes them), and writes the tile's
+// own pixels through for the weight gradient -- k_conv_halo's XF arithmetic, here ALSO for the next tile's first image,
+// which is requested during this tile's last slab.  The one-round kernel paid this transform with its 14-us tile overhead
+// on top (128 @ 28x28: bn 21 + conv 75-85 us as two launches, 96 us fused there); VERDICT r5 item 1.
+template <bool FUSE, bool XF = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -824,8 +830,11 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                                     // [2][HPX][128 B]
   char* Bs = smem + 2 * ABYTES;                        // [NW][2][32][128 B]
+  static_assert(!(FUSE && XF), "the input transform rides on the forward launch");
+  float* xtab = reinterpret_cast<float*>(smem + 2 * ABYTES + NW * 8192);   // XF: [3][C] scale, shift, alpha
   MSML_LDS_REGION(As, 2 * ABYTES);
   MSML_LDS_REGION(Bs, NW * 8192);
+  if (XF) MSML_LDS_REGION(xtab, 3 * p.C * 4);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   auto skey = [](int p_) { return p_ & 7; };
@@ -857,6 +866,33 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
     for (int i = 0; i < NAI; i++)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(a + (wave + i * NW) * 1024), 16,
                                                ao[i] == HALO_OOB ? HALO_OOB : ao[i] + cs * 128u, 0, 0, 0);
+  };
+  // XF: slab cs of the image whose request offsets are `ao`, in buffer `buf`: this wave's chunks (hp & 7 == (lane >> 3) & 7
+  // for every chunk of a lane: ONE channel chunk per lane and slab, coefficients read from the table once); padding stays
+  // zero; the pixels the tile owns (not its halo) are written through
+  auto xform = [&](const unsigned int (&ao)[NAI], int cs, int buf) {
+    char* a = As + buf * ABYTES;
+    const bool has_alpha = p.xin.alpha != nullptr;
+    f32x4 rsc[2], rsh[2], ral[2];
+    const float* tb = xtab + cs * 64 + (((lane & 7) ^ ((lane >> 3) & 7)) << 3);
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      rsc[hf] = *reinterpret_cast<const f32x4*>(tb + hf * 4);
+      rsh[hf] = *reinterpret_cast<const f32x4*>(tb + p.C + hf * 4);
+      ral[hf] = *reinterpret_cast<const f32x4*>(tb + 2 * p.C + hf * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NAI; i++) {
+      const int j = wave + i * NW;
+      const int hp = j * 8 + (lane >> 3);
+      if (ao[i] != HALO_OOB) {
+        bn_in_chunk_r(a + j * 1024 + lane * 16, rsc, rsh, ral, has_alpha);
+        const int hy = hp >> PL2, hx = hp & (PITCH - 1);
+        if (p.xin.store && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.xin.store) + ao[i] + cs * 128u) =
+              *reinterpret_cast<const u32x4*>(a + j * 1024 + lane * 16);
+      }
+    }
   };
   unsigned int boffg[4];
 #pragma unroll
@@ -901,7 +937,12 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
   calc_aoff(tile, aoff);
   issue_a(aoff, 0, 0);
   issue_b(0, 0, 0);
+  if (XF) bn_in_fill_acc(p.xin, xtab, p.C, t, NT, blockIdx.x == 0);
   __syncthreads();                                     // (drains vmcnt first)
+  if (XF) {
+    xform(aoff, 0, 0);
+    __syncthreads();
+  }
 #if defined(HALO_PRIO)
   if (HALO_PRIO == 1 ? (wave >= 4) : (wave < 4)) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -947,6 +988,12 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
       if ((tr | ts) == 0) {                            // first tap of a slab: the next slab's image, this tile's or the next one's
         if (cs + 1 < nslab) issue_a(aoff, cs + 1, (gs + 1) & 1);
         else issue_a(aoffn, 0, (gs + 1) & 1);
+      }
+      // XF: the image requested one (waves 0-3) / two (their SIMD partners 4-7) stages ago has landed for this wave (the
+      // wait above): normalise this wave's chunks of it, one wave's VALU beside its partner's MFMAs
+      if (XF && tr == 0 && ts == (wave < 4 ? 1 : 2)) {
+        if (cs + 1 < nslab) xform(aoff, cs + 1, (gs + 1) & 1);
+        else xform(aoffn, 0, (gs + 1) & 1);
       }
       __builtin_amdgcn_sched_barrier(0);
       HALO_STAMP(3);
@@ -1160,7 +1207,9 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
                              const float* scale, const float* alpha, const void* residual, int res_first,
                              const BnBwdFuse* bnb, int* bnb_rows, const BnIn* xin, int x3, const BnBwdIn* bin) {
   static const int m16_ = getenv("MSML_HALO_M16") ? atoi(getenv("MSML_HALO_M16")) : 2;
-  const bool pshape = m16_ >= 2 && !x3 && !xin && !bin && !bias && !scale && !alpha && !residual &&
+  static const bool xfp_ = !(getenv("MSML_BNIN_ACC_PERSIST") && atoi(getenv("MSML_BNIN_ACC_PERSIST")) == 0);
+  const bool pshape = m16_ >= 2 && !x3 && !bin && !bias && !scale && !alpha && !residual &&
+                      (!xin || (xfp_ && xin->acc && !transposed && !bnb && stats && c0p >= 128 && c0p <= 1024)) &&
                       (!stats || msml_tl_stats_acc) && (!bnb || bnb->acc) &&
                       msml_conv_halo_persist_shape(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) != 0;
   if (!pshape && !msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))
@@ -1209,7 +1258,14 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
     const size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;
     const int grid = halo_num_cus();
     const unsigned int out_bytes = (unsigned int)((long)N * H * W * 128 * 2);
-    if (bnb) {
+    if (xin) {                           // BatchNorm + PReLU of the input formed in the prologue (accumulator mode)
+      const size_t ldsx = lds + 3 * 1024 * sizeof(float);
+      static std::once_flag once;
+      std::call_once(once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo_p<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+      });
+      k_conv_halo_p<false, true><<<dim3(grid), dim3(512), ldsx, st>>>(a, (int)tiles, out_bytes);
+    } else if (bnb) {
       static std::once_flag once;
       std::call_once(once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo_p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -313,7 +313,9 @@ def bnin_acc_applies(n, h, w, cin_p, cout_p, r, s, stride, pad):
         if BNIN_ACC and ACC_STATS and r == 3 and s == 3 and stride == 1 and pad == 1 and acc_applies(cin_p, BF16) and \
                 acc_applies(cout_p, BF16):
             kind = _lib.value("msml_conv2d_bnin_acc_applies", cin_p, cout_p, n, h, w, h, w, 3, 3, 1, 1, 1)
-            ok = (kind == 1 and cin_p >= BNIN_ACC_MIN_C) or (kind == 2 and BNIN_ACC_WS)
+            # kind 3 (round 6): the persistent 128-channel tile takes the launch -- its prologue transform pays at 128 input
+            # channels already (MSML_BNIN_ACC_PERSIST=0: the library answers 1 for these shapes again)
+            ok = (kind == 1 and cin_p >= BNIN_ACC_MIN_C) or (kind == 2 and BNIN_ACC_WS) or kind == 3
         _BNIN_ACC_OK[key] = ok
     return ok
 

@@ -803,6 +803,9 @@ def test_conv_small_map_tiles(shape):
 @pytest.mark.parametrize("with_alpha", [False, True])
 @pytest.mark.parametrize("shape", [(7, 256, 256, 14, 14), (4, 256, 128, 13, 27), (3, 512, 256, 14, 14), (5, 256, 512, 14, 14),
                                    (9, 128, 128, 28, 28), (6, 128, 256, 28, 28),
+                                   # the persistent 128-channel tile (round 6): two and more rounds of tiles, ragged tile column
+                                   # and row, 256 input channels (four slabs per tile)
+                                   (128, 128, 128, 28, 28), (150, 128, 128, 27, 20), (131, 256, 128, 28, 28), (37, 128, 128, 56, 56),
                                    # the weights-stationary 64-channel kernel (round 5): more tiles than CUs, ragged tile column, 112 x 112
                                    (24, 64, 64, 56, 56), (60, 64, 64, 28, 40), (6, 64, 64, 112, 112)])
 def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
@@ -821,7 +824,10 @@ def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     alpha = (torch.rand(cin, generator=g) * 0.3).cuda() if with_alpha else None
     wp = ops.pack_weight(w, False, cin, 0, _lib.BF16)
     m = n * h * w_
-    assert _lib.value("msml_conv2d_bnin_acc_applies", cin, cout, n, h, w_, h, w_, 3, 3, 1, 1, 1) == (2 if cin == 64 else 1)
+    tiles = n * ((h + 13) // 14) * ((w_ + 13) // 14)
+    persistent = cout == 128 and cin >= 128 and tiles >= 512          # (>= two rounds on 256 CUs: k_conv_halo_p)
+    assert _lib.value("msml_conv2d_bnin_acc_applies", cin, cout, n, h, w_, h, w_, 3, 3, 1, 1, 1) == \
+        (2 if cin == 64 else (3 if persistent else 1))
 
     def stats_of_x():
         acc = ops.stats_acc(cin, x.device)
