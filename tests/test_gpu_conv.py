@@ -805,7 +805,7 @@ def test_conv_small_map_tiles(shape):
                                    (9, 128, 128, 28, 28), (6, 128, 256, 28, 28),
                                    # the persistent 128-channel tile (round 6): two and more rounds of tiles, ragged tile column
                                    # and row, 256 input channels (four slabs per tile)
-                                   (128, 128, 128, 28, 28), (150, 128, 128, 27, 20), (131, 256, 128, 28, 28), (37, 128, 128, 56, 56),
+                                   (128, 128, 128, 28, 28), (150, 128, 128, 27, 26), (131, 256, 128, 28, 28), (37, 128, 128, 56, 56),
                                    # the weights-stationary 64-channel kernel (round 5): more tiles than CUs, ragged tile column, 112 x 112
                                    (24, 64, 64, 56, 56), (60, 64, 64, 28, 40), (6, 64, 64, 112, 112)])
 def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
