@@ -567,7 +567,7 @@ int msml_bn_act_bwd_apply_next(const void* dy, const void* x, const float* scale
  * statistics updated, the output's sums added to acc_out (zero-initialised double[8][2][coutp]).  Bit-identical to
  * msml_bn_fin_act_fwd + msml_conv2d_acc.  Shapes: msml_conv2d_bnin_acc_applies -- 1: served by the halo-tile conv, 2: by the
  * weights-stationary 64-channel kernel (experiment builds only, msml_has_experiments), 3: by the persistent 128-channel halo
- * tile (round 6: >= 128 input channels, 128 output channels, at least two rounds of tiles), 0: not covered. */
+ * tile (round 6: 64 k input channels, 128 output channels, at least two rounds of tiles), 0: not covered. */
 int msml_conv2d_bnin_acc_applies(int c0p, int coutp, int N, int H, int W, int P, int Q, int R, int S, int stride,
                                  int pad_h, int pad_w);
 int msml_conv2d_bnin_acc(const void* in0, int c0p, const double* acc_in, double count, const float* gamma,

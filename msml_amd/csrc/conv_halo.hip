@@ -1209,7 +1209,7 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
   static const int m16_ = getenv("MSML_HALO_M16") ? atoi(getenv("MSML_HALO_M16")) : 2;
   static const bool xfp_ = !(getenv("MSML_BNIN_ACC_PERSIST") && atoi(getenv("MSML_BNIN_ACC_PERSIST")) == 0);
   const bool pshape = m16_ >= 2 && !x3 && !bin && !bias && !scale && !alpha && !residual &&
-                      (!xin || (xfp_ && xin->acc && !transposed && !bnb && stats && c0p >= 128 && c0p <= 1024)) &&
+                      (!xin || (xfp_ && xin->acc && !transposed && !bnb && stats && c0p <= 1024)) &&
                       (!stats || msml_tl_stats_acc) && (!bnb || bnb->acc) &&
                       msml_conv_halo_persist_shape(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w) != 0;
   if (!pshape && !msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, stats != nullptr))

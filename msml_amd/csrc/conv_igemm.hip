@@ -616,14 +616,14 @@ extern "C" int msml_conv2d_bnin_acc_applies(int c0p, int coutp, int N, int H, in
 #ifdef MSML_EXPERIMENTS      // (the weights-stationary kernel's prologue transform measured slower: experiment builds only)
   if (msml_conv_ws_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, true)) return 2;
 #endif
-  if (!msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, true)) return 0;
-  // 3: the persistent 128-channel tile takes the launch (round 6: its prologue transform pays from 128 input channels on)
+  // 3: the persistent 128-channel tile takes the launch (round 6: its prologue transform pays from 64 input channels on --
+  // the one-slab shape 64 -> 128 @ 56x56, conv1 of a stage's first block, has no one-round kernel to fall back to)
   static const bool xfp = !(getenv("MSML_BNIN_ACC_PERSIST") && atoi(getenv("MSML_BNIN_ACC_PERSIST")) == 0);
   const char* m16e = getenv("MSML_HALO_M16");
-  if (xfp && (!m16e || atoi(m16e) >= 2) && c0p >= 128 &&
+  if (xfp && (!m16e || atoi(m16e) >= 2) &&
       msml_conv_halo_persist_shape(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w))
     return 3;
-  return 1;
+  return msml_conv_halo_applies(c0p, kop, coutp, N, H, W, P, Q, R, S, stride, pad_h, pad_w, true) ? 1 : 0;
 }
 
 // Training-mode BatchNorm (+ PReLU) -> 3x3 / stride-1 / pad-1 conv in ONE launch, accumulator-mode statistics on both

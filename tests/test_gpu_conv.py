@@ -806,6 +806,7 @@ def test_conv_small_map_tiles(shape):
                                    # the persistent 128-channel tile (round 6): two and more rounds of tiles, ragged tile column
                                    # and row, 256 input channels (four slabs per tile)
                                    (128, 128, 128, 28, 28), (150, 128, 128, 27, 26), (131, 256, 128, 28, 28), (37, 128, 128, 56, 56),
+                                   (33, 64, 128, 56, 56),          # ... and its one-slab shape (conv1 of a stage's first block)
                                    # the weights-stationary 64-channel kernel (round 5): more tiles than CUs, ragged tile column, 112 x 112
                                    (24, 64, 64, 56, 56), (60, 64, 64, 28, 40), (6, 64, 64, 112, 112)])
 def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
@@ -814,7 +815,7 @@ def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     statistics updated by one workgroup) against msml_bn_fin_act_fwd + msml_conv2d_acc: activation, conv output, saved
     coefficients and running statistics bit for bit, output statistics to the order of the f64 adds."""
     n, cin, cout, h, w_ = shape
-    if cin == 64:                # (k_conv_ws's prologue transform: measured slower, experiment builds only)
+    if cin == 64 and cout == 64:  # (k_conv_ws's prologue transform: measured slower, experiment builds only)
         needs_experiments()
     g = torch.Generator().manual_seed(sum(shape) + int(with_alpha))
     x = ops.to_nhwc((torch.randn(n, cin, h, w_, generator=g) * 1.7 + 0.3).cuda(), _lib.BF16)
@@ -825,9 +826,9 @@ def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     wp = ops.pack_weight(w, False, cin, 0, _lib.BF16)
     m = n * h * w_
     tiles = n * ((h + 13) // 14) * ((w_ + 13) // 14)
-    persistent = cout == 128 and cin >= 128 and tiles >= 512          # (>= two rounds on 256 CUs: k_conv_halo_p)
+    persistent = cout == 128 and tiles >= 512                         # (>= two rounds on 256 CUs: k_conv_halo_p)
     assert _lib.value("msml_conv2d_bnin_acc_applies", cin, cout, n, h, w_, h, w_, 3, 3, 1, 1, 1) == \
-        (2 if cin == 64 else (3 if persistent else 1))
+        (3 if persistent else (2 if cin == 64 else 1))
 
     def stats_of_x():
         acc = ops.stats_acc(cin, x.device)
@@ -852,7 +853,7 @@ def test_conv_bn_from_accumulator_in_the_prologue(shape, with_alpha):
     # (64 channels: the two-launch side's conv runs on k_conv_s2r, the fused one on k_conv_ws -- identical outputs, but the
     # f32 per-workgroup partial sums of the statistics are cut differently before they meet in f64)
     sa, sb = st_a.sum(0), st_b.sum(0)
-    assert torch.allclose(sb, sa, rtol=1e-12, atol=0) if cin != 64 else \
+    assert torch.allclose(sb, sa, rtol=1e-12, atol=0) if (cin != 64 or persistent) else \
         torch.allclose(sb, sa, rtol=1e-6, atol=1e-6 * sa.abs().max().item())
 
 
