@@ -820,6 +820,10 @@ k_conv_halo(const ConvHaloArgs p) {
 // own pixels through for the weight gradient -- k_conv_halo's XF arithmetic, here ALSO for the next tile's first image,
 // which is requested during this tile's last slab.  The one-round kernel paid this transform with its 14-us tile overhead
 // on top (128 @ 28x28: bn 21 + conv 75-85 us as two launches, 96 us fused there); VERDICT r5 item 1.
+// (Tried and dropped: the write-through as always-issued buffer stores with a counted `vmcnt(4)` wait in the stage behind
+// the transform, so that the stores need not be acknowledged before the next MFMA phase -- three interleaved pairs on one
+// box: conv family 14.09 / 14.01 / 13.94 ms plain, 14.13 / 14.09 / 14.04 counted; the four extra out-of-range stores per
+// wave and slab cost more than the wait they save.)
 template <bool FUSE, bool XF = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_bytes) {
@@ -846,10 +850,6 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
   __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.w_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)out_bytes, 0x00020000);
-  // XF write-through: buffer stores, ALWAYS issued (a lane that owns no pixel stores out of range = dropped), so that the
-  // wait of the stage behind a transform can be counted (NAI stores are the only operations younger than its weights)
-  __amdgpu_buffer_rsrc_t rs_thr = __builtin_amdgcn_make_buffer_rsrc((void*)(XF ? p.xin.store : nullptr), 0,
-                                                                    XF && p.xin.store ? (int)p.in_bytes : 0, 0x00020000);
 
   auto calc_aoff = [&](int tile, unsigned int (&ao)[NAI]) {
     const int n = tile / tpi, trem = tile - n * tpi, ty = trem / p.tpx;
@@ -889,12 +889,13 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
     for (int i = 0; i < NAI; i++) {
       const int j = wave + i * NW;
       const int hp = j * 8 + (lane >> 3);
-      const bool live = ao[i] != HALO_OOB;
-      if (live) bn_in_chunk_r(a + j * 1024 + lane * 16, rsc, rsh, ral, has_alpha);
-      const int hy = hp >> PL2, hx = hp & (PITCH - 1);
-      const bool own = live & (hy >= 1) & (hy <= TH) & (hx >= 1) & (hx <= TW);
-      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(a + j * 1024 + lane * 16), rs_thr,
-                                             own ? ao[i] + cs * 128u : HALO_OOB, 0, 0);
+      if (ao[i] != HALO_OOB) {
+        bn_in_chunk_r(a + j * 1024 + lane * 16, rsc, rsh, ral, has_alpha);
+        const int hy = hp >> PL2, hx = hp & (PITCH - 1);
+        if (p.xin.store && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.xin.store) + ao[i] + cs * 128u) =
+              *reinterpret_cast<const u32x4*>(a + j * 1024 + lane * 16);
+      }
     }
   };
   unsigned int boffg[4];
@@ -983,12 +984,7 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
       if (q == 0 && !first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (XF && tr == (wave < 4 ? 0 : 1) && ts == (wave < 4 ? 2 : 0) && q >= 2) {
-        // the stage behind this wave's transform: its NAI = 4 write-through stores may still be in flight (everything
-        // older -- this stage's weights among it -- has landed)
-        static_assert(NAI == 4, "counted wait behind the transform");
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       HALO_STAMP(2);
       if (q + 1 < nstage) issue_b(ncs, ntr * 3 + nts, (gq + 1) & 1);
