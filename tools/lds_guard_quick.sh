@@ -1,3 +1,7 @@
+#!/bin/bash
+# The -DMSML_LDS_GUARD build (python tools/build_variant.py --all MSML_LDS_GUARD -> variants/) over the conv tests, one
+# bench-sized training step and config-5 inference -- tools/lds_guard_run.sh without its self-test (which TRAPS a kernel on
+# purpose and is not something to repeat on a shared box).  Log -> profiles/r06_lds_guard.log
 G=variants/libmsml_MSML_LDS_GUARD.so
 echo "== guarded library (-DMSML_LDS_GUARD, round-6 sources) over tests/test_gpu_conv.py"
 MSML_LIB=$PWD/$G timeout -k 10 600 python -m pytest tests/test_gpu_conv.py -q -x 2>&1 | tail -2
