@@ -49,6 +49,8 @@ struct ConvHalo2Args {
   const float* alpha;
   int res_first;
   int bias9;          // `bias` is float[9][coutp] by border class of the output pixel (common.h; stride-1 launches)
+  int zrev;           // GEOM 2: launch slice z serves output class 3 - z -- the four-tap class (odd, odd) first, the one-tap
+                      // class last, so that the light workgroups fill the launch's tail instead of the heavy ones making it
 };
 
 #define H2_OOB 0x78000000u
@@ -87,7 +89,8 @@ k_conv_halo2(const ConvHalo2Args p) {
   const int g0 = mg * GS, ng = NWM == 1 ? NGRP : (mg == 0 ? GS : NGRP - GS);   // this wave's groups [g0, g0 + ng)
   const int tile = blockIdx.x;
   const int n0 = blockIdx.y * BN;
-  const int cy = GEOM == 2 ? (int)(blockIdx.z >> 1) : 0, cx = GEOM == 2 ? (int)(blockIdx.z & 1) : 0;
+  const int zc = GEOM == 2 ? (p.zrev ? 3 - (int)blockIdx.z : (int)blockIdx.z) : 0;
+  const int cy = zc >> 1, cx = zc & 1;
   int tn = 0, y0 = 0, x0 = 0;                          // plain tiling: image and tile origin on the GEMM grid
   if constexpr (!MOS) {
     const int tpi = p.tpy * p.tpx;
@@ -599,6 +602,8 @@ bool msml_conv_halo2_dispatch(const void* in0, int c0p, const void* wp, int kop,
   a.bnb = BnBwdFuse{};
   if (bnb) a.bnb = *bnb;
   a.alpha = alpha; a.res_first = res_first; a.bias9 = (x3 && bias) ? msml_tl_bias9 : 0;
+  a.zrev = 1;        // (tools/bench_small.py, three interleaved pairs: 256 @ 28 -> 56 79.4 / 79.0 / 78.2 -> 76.7 / 77.7 / 77.9 us,
+                     //  128 @ 28 32.0 -> 31.3, the other shapes inside the noise; outputs bit-identical)
   const bool mos = tiling >= 2;
   const bool wide = coutp % 256 == 0 && !mos;           // mosaic: N / 4 tiles -- 128-channel tiles fill the chip sooner
   if (bnb_rows) *bnb_rows = (mos ? cdiv(N, tiling == 3 ? 6 : 4) : N * a.tpy * a.tpx) * (geom == 2 ? 4 : 1);
