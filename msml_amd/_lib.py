@@ -106,15 +106,37 @@ def _arg(a):
     return a
 
 
-_FAST = {}          # name -> (ctypes function, number of parameters, has trailing stream, returns status)
+_FAST = {}          # name -> [ctypes function, number of parameters, has trailing stream, returns status, C fast-call or None]
 _Tensor = torch.Tensor
+_FASTABI = None     # the generated CPython binding (msml_amd/fastabi_gen.py), False when it is not there
+
+
+def _fastabi():
+    """msml_amd/_msml_fastabi.so bound to the library handle ctypes holds, or False (MSML_NO_FASTABI=1, not built)."""
+    global _FASTABI
+    if _FASTABI is None:
+        _FASTABI = False
+        path = os.path.join(_HERE, "_msml_fastabi.so")
+        if not os.environ.get("MSML_NO_FASTABI") and os.path.exists(path):
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("_msml_fastabi", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                mod.bind(load()._handle)
+                _FASTABI = mod
+            except Exception as e:                      # stale build (header changed), wrong interpreter: ctypes serves
+                import sys
+                print("msml_amd: fast-call binding unusable (%r); the ctypes binding serves" % (e,), file=sys.stderr)
+    return _FASTABI
 
 
 def _bind(name):
     lib = load()
     params = _protos[name][1]
-    ent = (getattr(lib, name), len(params), bool(params) and params[-1][1] == "stream",
-           _protos[name][0] is ctypes.c_int)
+    fa = _fastabi()
+    ent = [getattr(lib, name), len(params), bool(params) and params[-1][1] == "stream",
+           _protos[name][0] is ctypes.c_int, getattr(fa, name, None) if fa else None]
     _FAST[name] = ent
     return ent
 
@@ -125,7 +147,20 @@ def call(name, *args):
     ent = _FAST.get(name)
     if ent is None:
         ent = _bind(name)
-    fn, nparams, has_stream, is_status = ent
+    fn, nparams, has_stream, is_status, fast = ent
+    if fast is not None:
+        # the generated C wrapper converts the arguments itself (None, int, float, anything with data_ptr())
+        try:
+            if has_stream and len(args) == nparams - 1:
+                rc = fast(*args, torch._C._cuda_getCurrentRawStream(_DEV if _DEV is not None else _device()))
+            else:
+                rc = fast(*args)
+        except (AttributeError, TypeError):
+            ent[4] = None            # an argument it does not take (a ctypes array / byref): this entry stays on ctypes
+            return call(name, *args)
+        if rc != 0 and is_status:
+            raise RuntimeError("%s failed (%d): %s" % (name, rc, load().msml_last_error().decode()))
+        return rc
     cargs = [a.data_ptr() if isinstance(a, _Tensor) else a for a in args]
     if has_stream and len(cargs) == nparams - 1:
         cargs.append(torch._C._cuda_getCurrentRawStream(_DEV if _DEV is not None else _device()))
