@@ -58,6 +58,10 @@ int msml_has_experiments(void);
  * side keys per-capture scratch state on it (zeroed accumulator chunks: a second capture must not inherit the
  * first one's slices, whose zero fill only the first graph replays). */
 long msml_stream_capture_id(void* stream);
+/* `waiter` waits for everything queued on `src` so far: torch.cuda.Stream.wait_stream (the fork of the weight-gradient
+ * side stream, backbones/msml.py has no counterpart: the reference runs one stream) through one re-recorded hipEvent per
+ * calling thread.  Valid inside a graph capture (the waiter joins the capture). */
+int msml_stream_wait_stream(void* waiter, void* src);
 
 /* ---------------------------------------------------------------- layout (boundary) ------
  * The reference keeps NCHW f32 tensors end to end (backbones/msml.py:150); the HIP path

@@ -98,6 +98,12 @@ def current_stream():
     return torch.cuda.Stream(stream_id=sid, device_index=didx, device_type=dtype)
 
 
+def stream_wait_current(side):
+    """`side.wait_stream(<torch's current stream>)` in one library call (msml_stream_wait_stream: no Stream / Event objects
+    on the Python side; ~125 forks of the weight-gradient stream per training step)."""
+    call("msml_stream_wait_stream", side.cuda_stream, torch._C._cuda_getCurrentRawStream(_DEV if _DEV is not None else _device()))
+
+
 def _arg(a):
     if a is None:
         return None
@@ -141,9 +147,9 @@ def _bind(name):
     return ent
 
 
-def call(name, *args):
-    """Enqueue `name` on torch's current stream; the trailing `stream` parameter is appended
-    automatically.  Raises RuntimeError with msml_last_error() on a non-zero status."""
+def _invoke(name, args):
+    """(status or result, returns-a-status) of `name` enqueued on torch's current stream; the trailing `stream` parameter is
+    appended automatically."""
     ent = _FAST.get(name)
     if ent is None:
         ent = _bind(name)
@@ -152,24 +158,23 @@ def call(name, *args):
         # the generated C wrapper converts the arguments itself (None, int, float, anything with data_ptr())
         try:
             if has_stream and len(args) == nparams - 1:
-                rc = fast(*args, torch._C._cuda_getCurrentRawStream(_DEV if _DEV is not None else _device()))
-            else:
-                rc = fast(*args)
+                return fast(*args, torch._C._cuda_getCurrentRawStream(_DEV if _DEV is not None else _device())), is_status
+            return fast(*args), is_status
         except (AttributeError, TypeError):
             ent[4] = None            # an argument it does not take (a ctypes array / byref): this entry stays on ctypes
-            return call(name, *args)
-        if rc != 0 and is_status:
-            raise RuntimeError("%s failed (%d): %s" % (name, rc, load().msml_last_error().decode()))
-        return rc
     cargs = [a.data_ptr() if isinstance(a, _Tensor) else a for a in args]
     if has_stream and len(cargs) == nparams - 1:
         cargs.append(torch._C._cuda_getCurrentRawStream(_DEV if _DEV is not None else _device()))
     if len(cargs) != nparams:
         raise TypeError("%s expects %d arguments, got %d" % (name, nparams, len(cargs)))
-    rc = fn(*cargs)
-    if not is_status:
-        return rc
-    if rc != 0:
+    return fn(*cargs), is_status
+
+
+def call(name, *args):
+    """Enqueue `name` on torch's current stream; the trailing `stream` parameter is appended
+    automatically.  Raises RuntimeError with msml_last_error() on a non-zero status."""
+    rc, is_status = _invoke(name, args)
+    if rc != 0 and is_status:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, load().msml_last_error().decode()))
     return rc
 
@@ -177,17 +182,9 @@ def call(name, *args):
 def try_call(name, *args):
     """Like call(), but returns the status code instead of raising on MSML_ERR_UNSUPPORTED:
     for entry points that cover only part of the shape space and have an unfused alternative."""
-    lib = load()
-    fn = getattr(lib, name)
-    params = _protos[name][1]
-    cargs = [_arg(a) for a in args]
-    if params and params[-1][1] == "stream" and len(cargs) == len(params) - 1:
-        cargs.append(raw_stream())
-    if len(cargs) != len(params):
-        raise TypeError("%s expects %d arguments, got %d" % (name, len(params), len(cargs)))
-    rc = fn(*cargs)
+    rc, _ = _invoke(name, args)
     if rc not in (0, UNSUPPORTED):
-        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.msml_last_error().decode()))
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, load().msml_last_error().decode()))
     return rc
 
 

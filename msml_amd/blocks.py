@@ -49,8 +49,9 @@ def _bn_coef(x, stats, bnp):
         stats = torch.empty(rows, 2, c, dtype=torch.float32, device=x.device)
         with ops.PROFILE.rec("bn_stats", 0.0, x.numel() * x.element_size()):
             call("msml_bn_stats", x, m, c, stats, BF16)
+    k = ops.rows4(coef)
     call("msml_bn_finalize", stats, stats.shape[0], c, float(m), bnp[0], bnp[1], bnp[2], bnp[3], bnp[4], bnp[5],
-         coef[0], coef[1], coef[2], coef[3])
+         k[0], k[1], k[2], k[3])
     ops.bn_counter(bnp[6])
     return coef
 
@@ -61,6 +62,7 @@ def _bn_apply(x, coef, alpha, residual, emit_stats=False, res_first=0):
     c = x.shape[-1]
     m = x.numel() // c
     y = torch.empty_like(x)
+    coef = ops.rows4(coef)
     with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
         if emit_stats:
             ystats = torch.empty(_lib.value("msml_bn_act_fwd_stats_rows", m, c), 2, c, dtype=torch.float32,
@@ -79,9 +81,10 @@ def _bn_fin_apply(x, acc, bnp, alpha, residual, emit_stats=False, res_first=0):
     coef = torch.empty(4, c, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
     yacc = ops.stats_acc(c, x.device) if emit_stats else None
+    k = ops.rows4(coef)
     with ops.PROFILE.rec("bn_act_fwd", 0.0, x.numel() * x.element_size() * (3 if residual is not None else 2)):
-        call("msml_bn_fin_act_fwd", acc, float(m), bnp[0], bnp[1], bnp[2], bnp[3], bnp[4], bnp[5], coef[0], coef[1],
-             coef[2], coef[3], x, alpha, residual, res_first, y, m, c, yacc, BF16)
+        call("msml_bn_fin_act_fwd", acc, float(m), bnp[0], bnp[1], bnp[2], bnp[3], bnp[4], bnp[5], k[0], k[1],
+             k[2], k[3], x, alpha, residual, res_first, y, m, c, yacc, BF16)
     ops.bn_counter(bnp[6])
     if emit_stats:
         return y, coef, yacc
@@ -168,7 +171,7 @@ def _wgrad(dy, x, cp, xin=None):
     dw = wparam.grad.view(wparam.shape) if inplace else torch.empty_like(wparam)
     side = ops.WGRAD_STREAM if inplace else None
     if side is not None:
-        side.wait_stream(_lib.current_stream())
+        _lib.stream_wait_current(side)
         dy.record_stream(side)             # both operands may be freed (by this stream's allocator
         x.record_stream(side)              # pool) while the side stream still reads them
         if xin is not None:
@@ -279,6 +282,9 @@ def _bn_bwd(dy, x, coef, alpha, pgr, partial=None, add=None, nxt=None, add_s2=Fa
     c = x.shape[-1]
     m = x.numel() // c
     dx = torch.empty_like(x)
+    coef = ops.rows4(coef)                     # (row addresses: four view tensors per launch otherwise)
+    if nxt:
+        nxt = (nxt[0], ops.rows4(nxt[1])) + tuple(nxt[2:])
     s2 = (add, x.shape[1], x.shape[2]) if add_s2 else (add,)
     sfx = "_s2" if add_s2 else ""
     if partial is None and ops.acc_applies(c, BF16):
@@ -640,14 +646,15 @@ class _Bottle(torch.autograd.Function):
         c = c3.shape[-1]
         m = c3.numel() // c
         dc3, dres = torch.empty_like(c3), torch.empty_like(x)
+        r3 = ops.rows4(k3)
         with ops.PROFILE.rec("bn_act_bwd", 0.0, c3.numel() * c3.element_size() * 7):
             if ops.acc_applies(c, BF16):
-                call("msml_bn_act_bwd_acc", dout, c3, k3[0], k3[1], bp["a3"], k3[2], k3[3], x, None, dc3, dres,
+                call("msml_bn_act_bwd_acc", dout, c3, r3[0], r3[1], bp["a3"], r3[2], r3[3], x, None, dc3, dres,
                      g3.tg[0], g3.tg[1], g3.tg[2], int(g3.inplace), m, c, ops.stats_acc(c, dev, 3), BF16)
             else:
                 rows = ops.bn_stats_rows(m, c)
                 ws = ops.workspace((rows * 3 * c + 2 * c) * 4, dev)
-                call("msml_bn_act_bwd", dout, c3, k3[0], k3[1], bp["a3"], k3[2], k3[3], x, dc3, dres,
+                call("msml_bn_act_bwd", dout, c3, r3[0], r3[1], bp["a3"], r3[2], r3[3], x, dc3, dres,
                      g3.tg[0], g3.tg[1], g3.tg[2], int(g3.inplace), m, c, ws, ws.numel() // 4, BF16)
         g3.done()
         dw3 = _wgrad(dc3, o2, bp["c3"])

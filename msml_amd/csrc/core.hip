@@ -38,3 +38,24 @@ extern "C" long msml_stream_capture_id(void* stream) {
   if (st != hipStreamCaptureStatusActive) return 0;
   return (long)(id & 0x3fffffffffffffffULL) + 1;      // ids start at 0 on some runtimes: keep 0 for "not capturing"
 }
+
+// `waiter` waits for everything queued on `src` so far (torch's Stream.wait_stream without the Python-side event object:
+// one hipEvent per calling thread, re-recorded each time -- a wait holds on to the record it saw when it was queued, so
+// the next record does not disturb it).  The weight-gradient side stream is forked this way ~125 times per training step.
+extern "C" int msml_stream_wait_stream(void* waiter, void* src) {
+  static thread_local hipEvent_t ev = nullptr;
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    ev = nullptr;
+    (void)hipGetLastError();
+    msml_set_error("msml_stream_wait_stream: hipEventCreateWithFlags failed");
+    return MSML_ERR_LAUNCH;
+  }
+  hipError_t e = hipEventRecord(ev, (hipStream_t)src);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    msml_set_error("msml_stream_wait_stream: %s", hipGetErrorString(e));
+    return MSML_ERR_LAUNCH;
+  }
+  return 0;
+}

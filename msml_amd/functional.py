@@ -120,7 +120,7 @@ class _Conv(torch.autograd.Function):
             dw = ctx.wparam.grad.view(w.shape) if inplace else torch.empty_like(w)
             side = ops.WGRAD_STREAM if inplace else None
             if side is not None:                       # dW has no consumer before the optimizer
-                side.wait_stream(_lib.current_stream())
+                _lib.stream_wait_current(side)
                 dy.record_stream(side)
                 for xs in (x0, x1):                    # saved activations are freed after this node
                     if xs is not None:

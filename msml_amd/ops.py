@@ -81,7 +81,7 @@ PROFILE = _Profile()
 # AccumulateGrad add kernels (~470 tiny launches per ires50 step).  The mark is per PARAMETER, so two
 # models / optimizers in one process do not interfere; the owner zeroes the arena before every backward.
 def inplace(p):
-    return p is not None and p.grad is not None and getattr(p, "_msml_arena", None) is not None
+    return p is not None and getattr(p, "_msml_arena", None) is not None and p.grad is not None
 
 
 def cpad(c):
@@ -184,6 +184,16 @@ def acc_applies(c, dtype):
 def stats_acc(c, device, nq=2):
     """Zeroed f64 [8][nq][c]: nq = 2 forward (sum, sumsq), 3 backward (sum g, sum g * xhat, sum dy * min(z, 0))."""
     return ACC_ARENA.get(c, device, nq)
+
+
+def rows4(t):
+    """Addresses of the four rows of an f32 [4][C] coefficient block (scale, shift, mean, invstd) as plain ints -- what the
+    entry points take as `const float*`.  `t[0], t[1], t[2], t[3]` builds four view tensors (~1.5 us each on the host) per
+    launch, ~1300 of them per training step; both bindings accept an int as an address.  `t` stays the caller's to keep alive."""
+    assert t.dtype is torch.float32
+    p = t.data_ptr()
+    s = t.stride(0) * 4
+    return (p, p + s, p + s + s, p + 3 * s)
 
 
 _UNIT_COEF = {}
@@ -390,6 +400,7 @@ def conv2d_bnin(x, coef, alpha, wp, coutp, real=None):
     if PROFILE.on:
         name = conv_label("N+bnin", c0p, 0, coutp, n, h, w, h, w, 3, 3, 1, 1, 1, 0, BF16, BF16, True)
     with PROFILE.rec(name, 2.0 * n * h * w * cin * cout * 9):
+        coef = rows4(coef)
         call("msml_conv2d_bnin", x, c0p, coef[0], coef[1], alpha, wp, wp.shape[0], out, coutp, stats, n, h, w,
              h, w, 3, 3, 1, 1, 1)
     return out, stats
@@ -406,6 +417,7 @@ def conv_wgrad_bnin(u, v, coef, alpha, dw, a, breal, btot, boff, accumulate=Fals
         need = _WGRAD_WS_NEED[key] = _lib.value("msml_conv_wgrad_workspace", *key)
     raw = stream.cuda_stream if stream is not None else _lib.raw_stream()
     ws = workspace(need, u.device, "wgrad", stream)
+    coef = rows4(coef)
     if PROFILE.on and stream is None:
         name = "wgrad+bnin u%d v%d %dx%d k3x3 s1 n%d" % (up, vp, p, q, n)
         with PROFILE.rec(name, 2.0 * n * p * q * a * breal * 9):
@@ -427,6 +439,7 @@ def conv_dgrad_bnbwd(dy, wp, coutp, r, s, stride, pad_h, pad_w, p, q, bn_x, coef
         return None
     out = torch.empty(n, p, q, coutp, dtype=torch.bfloat16, device=dy.device)
     cin, cout = real if real is not None else (c0p, coutp)
+    coef = rows4(coef)
     name = "conv_igemm"
     if PROFILE.on:
         name = conv_label("T+bnb", c0p, 0, coutp, n, h, w, p, q, r, s, stride, pad_h, pad_w, 1, BF16, BF16, False)

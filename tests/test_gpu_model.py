@@ -372,6 +372,27 @@ def test_partial_fc_bf16_vs_oracle():
     assert rel_err(p.sub_weight.grad.cpu().numpy(), ref.sub_weight.grad.numpy()) < 1e-2
 
 
+def test_stream_wait_stream_orders_the_waiter_behind_the_source():
+    """msml_stream_wait_stream (the fork of the weight-gradient stream, one re-recorded event per thread): work queued on the
+    waiter afterwards sees everything queued on the source before -- twice, so that the second record of the same event is
+    exercised while the first wait may still be pending."""
+    from msml_amd import _lib
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.zeros(1 << 26, device="cuda")
+    torch.cuda.synchronize()
+    seen = []
+    for rnd in range(2):
+        with torch.cuda.stream(a):
+            for _ in range(20):
+                x.add_(1.0)
+        _lib.call("msml_stream_wait_stream", b.cuda_stream, a.cuda_stream)
+        with torch.cuda.stream(b):
+            seen.append((x.min(), x.max()))
+            _lib.call("msml_stream_wait_stream", a.cuda_stream, b.cuda_stream)      # (a must not overwrite x under b's read)
+    torch.cuda.synchronize()
+    assert [(float(lo), float(hi)) for lo, hi in seen] == [(20.0, 20.0), (40.0, 40.0)]
+
+
 def test_side_streams_match_serial():
     """Eager multi-stream issue (OSB on its own stream, weight gradients on a second stream)
     gives bit-identical gradients to the single-stream order (same kernels, same inputs)."""
