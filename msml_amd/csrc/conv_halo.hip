@@ -92,11 +92,18 @@ extern "C" int msml_halo_trace_read(unsigned long long* dst, int n) {
 // shadow of the MFMAs, instead of four in front of every stage with all eight waves queueing on the CU's one path into LDS;
 // every wait is counted (s_waitcnt vmcnt(N) returns when all but the N youngest requests are done: N = 4, + 4 while a slab
 // image requested after the wanted half is still among them), and the image is requested after the mid-stage weights.
-template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false, bool R15 = false>
+// BREG (round 6, M16 kernels, experiment builds, opt-in MSML_HALO_BREG=1): the wave's weights never touch LDS.  The B fragment of the 16x16x32
+// MFMA is 16 B per lane (output channel 16 g + l16, k chunk 4 w + q16) -- exactly one buffer_load_dwordx4 per (g, w) from the
+// packed weights, four per stage and wave, double-buffered in registers (the stage's fragments are copied out of the landing
+// registers behind the stage's wait, then the next stage's loads are issued into them).  What it takes off the CU's LDS:
+// 32 KB of LDS-DMA writes and 32 KB of fragment reads per stage (of 288 KB), and the DMA requests' issue cost.
+template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false, bool R15 = false,
+          bool BREG = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv_halo(const ConvHaloArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(!R15 || M16, "the half-stage ring rides on the 16x16x32 tiling");
+  static_assert(!BREG || (M16 && !R15), "weights in registers: 16x16x32 tiling, two-slot schedule");
   constexpr int PL2 = 4, PITCH = 16, MT = 7, KG = BN / 32, NW = KG * NWM, NT = NW * 64, BM = MT * 32;
   constexpr int TW = 14, TH = 14, HR = TH + 2, HPX = HR << PL2;
   constexpr int MTW = NWM == 1 ? MT : 4;               // accumulator tiles of one wave (at most)
@@ -216,6 +223,21 @@ k_conv_halo(const ConvHaloArgs p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(b + i * 1024), 16, boffg[i] + col, 0, 0, 0);
   };
 
+  // BREG: this lane's 16 B of (channel 16 g + l16, k chunk 4 w + q16) of stage (cs, tap) straight into registers
+  u32x4 bnx[2][2];                                     // [w][g]: landing registers of the NEXT stage
+  unsigned int boffr[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++)
+    boffr[g] = (unsigned int)((n0 + kg * 32 + 16 * g + (lane & 15)) * p.Ktot) * 2u + (unsigned int)((lane >> 4) * 16);
+  auto load_b = [&](int cs_, int tap) {
+    const unsigned int col = (unsigned int)(tap * p.C + cs_ * 64) * 2u;
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+        bnx[w][g] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, boffr[g] + w * 64u, col, 0);
+  };
+
   // R15: half (tap, slab cs, window w) -> slot `buf`: two requests of 16 rows x 64 B
   auto key2 = [](int row) { return (row >> 2) & 3; };
   unsigned int boffh[2];
@@ -274,6 +296,8 @@ k_conv_halo(const ConvHaloArgs p) {
     issue_h(0, 0, 0, 0);
     issue_h(0, 0, 1, 0);
     issue_h(0, 1, 0, 1);
+  } else if constexpr (BREG) {
+    load_b(0, 0);
   } else {
     issue_b(0, 0, 0);
   }
@@ -298,6 +322,7 @@ k_conv_halo(const ConvHaloArgs p) {
   if (HALO_PRIO == 1 ? (wave >= 4) : (wave < 4)) __builtin_amdgcn_s_setprio(1);
 #endif
   u32x4 a[2][MTW], b[2];
+  u32x4 bcur[2][2];                                    // BREG: [w][g] fragments of the current stage
   int img_m1 = 0, img_m2 = 0;                          // R15: a slab image was requested in the middle of stage q - 1 / q - 2
 #ifdef HALO_ABLATE_READS
   u32x4 a16x[2][MTW], b16x[2][2];                      // (ablation build: fragments read once, reused by every stage)
@@ -329,9 +354,16 @@ k_conv_halo(const ConvHaloArgs p) {
     } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     HALO_STAMP(2);
+    if constexpr (BREG) {
+#pragma unroll
+      for (int w = 0; w < 2; w++)
+#pragma unroll
+        for (int g = 0; g < 2; g++) bcur[w][g] = bnx[w][g];
+    }
 #ifndef HALO_ABLATE_LOADS
     if (q + 1 < nstage) {
-      issue_b(ncs, ntr * 3 + nts, (q + 1) & 1);
+      if constexpr (BREG) load_b(ncs, ntr * 3 + nts);
+      else issue_b(ncs, ntr * 3 + nts, (q + 1) & 1);
       if ((tr | ts) == 0 && cs + 1 < nslab) issue_a(cs + 1, (cs + 1) & 1);
     }
 #endif
@@ -376,8 +408,10 @@ k_conv_halo(const ConvHaloArgs p) {
 #pragma unroll
       for (int j = 0; j < NGH; j++)
         if (j < ng) a16[0][j] = *reinterpret_cast<const u32x4*>(Arow + ((q16 ^ asw) << 4) + j * 2048);
+      if constexpr (!BREG) {
 #pragma unroll
-      for (int g = 0; g < 2; g++) b16[0][g] = *reinterpret_cast<const u32x4*>(B + bfr16[g][0]);
+        for (int g = 0; g < 2; g++) b16[0][g] = *reinterpret_cast<const u32x4*>(B + bfr16[g][0]);
+      }
 #endif
 #pragma unroll
       for (int ph = 0; ph < 4; ph++) {
@@ -397,7 +431,7 @@ k_conv_halo(const ConvHaloArgs p) {
 #pragma unroll
           for (int j = 0; j < NGH; j++)
             if (nhf * NGH + j < ng) a16[nb][j] = *reinterpret_cast<const u32x4*>(Arow + ao + (nhf * NGH + j) * 2048);
-          if (nhf == 0) {
+          if (nhf == 0 && !BREG) {
 #pragma unroll
             for (int g = 0; g < 2; g++) b16[nw & 1][g] = *reinterpret_cast<const u32x4*>(B + bfr16[g][nw]);
           }
@@ -410,7 +444,7 @@ k_conv_halo(const ConvHaloArgs p) {
 #pragma unroll
             for (int g = 0; g < 2; g++)
               acc4[hf * NGH + j][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8, b16[w & 1][g]), __builtin_bit_cast(bf16x8, a16[cb][j]),
+                  __builtin_bit_cast(bf16x8, BREG ? bcur[w][g] : b16[w & 1][g]), __builtin_bit_cast(bf16x8, a16[cb][j]),
                   acc4[hf * NGH + j][g], 0, 0, 0);
           }
         if constexpr (R15) {
@@ -1139,7 +1173,8 @@ k_conv_halo_p(const ConvHaloArgs p, const int ntiles, const unsigned int out_byt
 #endif
 }
 
-template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false, bool R15 = false>
+template <int BN, int NWM, bool FUSE, bool XF = false, bool X3 = false, bool M16 = false, bool XB = false, bool R15 = false,
+          bool BREG = false>
 static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   size_t lds = 2 * (size_t)256 * 128 + 8 * 8192;      // two halo images + eight private weight rings
   size_t olds = (size_t)224 * (BN + 8) * 2;
@@ -1148,11 +1183,11 @@ static void launch_halo(ConvHaloArgs& a, hipStream_t st) {
   if (XB) lds += 7 * 512 * sizeof(float);              // backward coefficient table, C <= 512
   static std::once_flag attr_once;                     // (per template instantiation; launches come from
   std::call_once(attr_once, [&] {                      //  the forward thread AND the autograd thread)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB, R15>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB, R15, BREG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   dim3 grid(a.N * a.tpy * a.tpx, a.coutp / BN);
-  k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB, R15><<<grid, dim3(512), lds, st>>>(a);
+  k_conv_halo<BN, NWM, FUSE, XF, X3, M16, XB, R15, BREG><<<grid, dim3(512), lds, st>>>(a);
 }
 
 static int halo_num_cus() {
@@ -1294,6 +1329,19 @@ bool msml_conv_halo_dispatch(const void* in0, int c0p, const void* wp, int kop, 
     if (xin) launch_halo<256, 1, false, true, false, true, false, true>(a, st);
     else if (bnb) launch_halo<256, 1, true, false, false, true, false, true>(a, st);
     else launch_halo<256, 1, false, false, false, true, false, true>(a, st);
+    return true;
+  }
+#endif
+  // weights in registers (template parameter BREG) on the 256-channel tile; MSML_HALO_BREG read per call (A/B in one process).
+  // Measured neutral (round 6, tools/bench_breg.py: bit-identical, 256 @ 14x14 forward 59.5 -> 57.4 us, with the BatchNorm
+  // prologue 60.7 -> 60.8, backward-data + sums 56.6 -> 56.2; the step 29.53 -> 29.53 ms, three interleaved pairs): the
+  // weights' trip through LDS is not what the tile waits for.  Experiment builds only.
+#ifdef MSML_EXPERIMENTS
+  const char* brege = getenv("MSML_HALO_BREG");
+  if (m16 && !x3 && wide && brege != nullptr && atoi(brege) != 0) {
+    if (xin) launch_halo<256, 1, false, true, false, true, false, false, true>(a, st);
+    else if (bnb) launch_halo<256, 1, true, false, false, true, false, false, true>(a, st);
+    else launch_halo<256, 1, false, false, false, true, false, false, true>(a, st);
     return true;
   }
 #endif
